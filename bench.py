@@ -1,0 +1,151 @@
+#!/usr/bin/env python3
+"""bench.py -- generations/s of the per-generation hot path on MI355X.
+
+A "step" is one generation of main.rs:429-464 (fitness-weighted parent draw, parent gather of
+both matrices, core mutation, accessory gain/loss, HR, HGT) on BASELINE.json configs[1]:
+--pop_size 1000 --core_size 1200000 --pan_genes 6000 (defaults otherwise), state resident in HBM.
+
+Multi-GPU (one process per GPU, launched by torch.distributed.run): the core genome is sharded
+BY SITE.  Weak scaling: every rank holds 1.2 M sites of a core genome of
+n_gpus x 1.2 M sites; the accessory matrix is replicated and every rank draws the same parents
+from the same seeded stream, so a generation needs no data-path collective.  `value` counts
+1.2 M-site shard-generations per second summed over ranks (at n_gpus = 1: plain generations/s).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s
+
+
+def cpu_baseline(kw, seed, budget_s=20.0):
+    """Reference algorithm (event-driven, rows in parallel like rayon) timed on the host cores."""
+    from oracle import oracle as o
+    threads = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    sim = o.RefSim(o.make_params(**kw), seed=seed, threads=threads)
+    t0 = time.perf_counter()
+    sim.generation(0)                      # warm-up generation (page faults, first touch)
+    first = time.perf_counter() - t0
+    n = max(1, min(8, int((budget_s - first) / max(first, 1e-3))))
+    t0 = time.perf_counter()
+    for g in range(n):
+        sim.generation(1 + g)
+    dt = time.perf_counter() - t0
+    sim.close()
+    return {"value": n / dt, "unit": "generations/s", "cores": threads, "kind": "port",
+            "sample": "%d generations of pop=%d core=%d pan=%d after 1 warm-up generation; "
+                      "event-driven reference algorithm (oracle/pansim_oracle.c orc_ref_*), %d threads"
+                      % (n, kw["pop_size"], kw["core_size"], kw["pan_genes"], threads)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--pop_size", type=int, default=1000)
+    ap.add_argument("--core_size", type=int, default=1200000, help="core sites PER GPU")
+    ap.add_argument("--pan_genes", type=int, default=6000)
+    ap.add_argument("--HR_rate", type=float, default=0.05)
+    ap.add_argument("--HGT_rate", type=float, default=0.05)
+    ap.add_argument("--max_distances", type=int, default=100000)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    import pansim_amd as pa
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d"
+                         % (args.gpus, world, args.gpus))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: pansim_amd has no CPU path")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    kw = dict(pop_size=args.pop_size, core_size=args.core_size * world, pan_genes=args.pan_genes,
+              HR_rate=args.HR_rate, HGT_rate=args.HGT_rate)
+    seed = 0
+    sim = pa.Simulation(pa.make_params(seed=seed, n_gen=args.steps + args.warmup,
+                                       max_distances=args.max_distances, shard_rank=rank,
+                                       shard_count=world, device=local_rank, **kw))
+    sim.run(args.warmup)
+    sim.sync()
+    sim.enable_timing(True)
+    sim.sweep_timing(reset=True)
+    barrier()
+    t0 = time.perf_counter()
+    sim.run(args.steps)
+    sim.sync()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    launches, sweep_ms, bytes_per_launch = sim.sweep_timing(reset=True)
+    sim.enable_timing(False)
+
+    # distance phase (main.rs:467-482): P sampled pairs, core Hamming + accessory Jaccard.
+    # Site-sharded: integer partial counts are summed over ranks (RCCL all-reduce).
+    P = args.max_distances
+    cnt = torch.zeros(P, dtype=torch.int32, device="cuda")
+    barrier()
+    t1 = time.perf_counter()
+    sim.core_genome.pairwise_counts_device(sim.range1, sim.range2, cnt.data_ptr())
+    if world > 1:
+        dist.all_reduce(cnt)
+    acc_d = sim.pan_genome.pairwise_distances(P, sim.range1, sim.range2)
+    core_d = (cnt.cpu().numpy().astype("uint32") // 2) / float(kw["core_size"])
+    barrier()
+    dist_dt = time.perf_counter() - t1
+    assert core_d.shape == acc_d.shape
+
+    if rank == 0:
+        avg_ms = sweep_ms / max(launches, 1)
+        achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if launches else 0.0
+        out = {
+            "metric": "generations/sec", "value": world * args.steps / dt,
+            "unit": "generations/s (pop=%d, %d core sites per GPU, pan=%d)" % (args.pop_size, args.core_size, args.pan_genes),
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[1]: --pop_size %d --core_size %d --pan_genes %d, seed 0, "
+                                   "HR_rate %g HGT_rate %g; core sites sharded %d-way"
+                                   % (args.pop_size, args.core_size * world, args.pan_genes, args.HR_rate,
+                                      args.HGT_rate, world),
+                       "parallelism": "site-shard x%d" % world},
+            "mpairs_per_s": P / dist_dt / 1e6,
+            "distance_ms": 1e3 * dist_dt,
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "core_sweep_kernel<gather,mutate,HR>", "avg_launch_ms": avg_ms,
+                         "algorithmic_bytes_per_launch": bytes_per_launch},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(kw, seed)
+        print(json.dumps(out), flush=True)
+    sim.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,231 @@
+/*
+ * pansim_hip.h -- C ABI of libpansim_hip.so, the MI355X (gfx950) drop-in for the
+ * per-generation hot path of bacpop/Pansim.
+ *
+ * The reference has no FFI layer; its library seam is `pub mod population`
+ * (pansim/src/lib.rs:4) consumed by main() (pansim/src/main.rs:8).  Every entry
+ * point below replaces one item of that seam and cites it.  A Rust host binds
+ * this header with `extern "C"` declarations (INTEGRATION.md shows the stub).
+ *
+ * Conventions
+ *  - every function returns 0 on success and a negative ps_status on failure;
+ *    ps_last_error() returns the message of the calling thread's last failure.
+ *    Nothing aborts or throws across the boundary (the reference panics:
+ *    population.rs:440, :484, :562, :584).
+ *  - the caller owns every buffer it passes; the library never keeps a caller
+ *    pointer after the call returns.  A handle owns its HBM state.
+ *  - handles are not thread-safe: one host thread per handle, as all reference
+ *    methods take `&mut self`.
+ *  - matrices cross the boundary in the reference's layout: one row per
+ *    individual, row-major u8 (`Array2<u8>` (N, ncols), population.rs:164-178).
+ *    In HBM the core matrix is site-major u8 and the accessory matrix is
+ *    bit-packed.
+ *  - there is no CPU fallback: without a HIP device every compute call fails
+ *    with PS_ERR_NO_DEVICE.
+ */
+#ifndef PANSIM_HIP_H
+#define PANSIM_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+    PS_OK = 0,
+    PS_ERR_INVALID = -1,    /* bad argument (reference: unwrap()/assert panic) */
+    PS_ERR_NO_DEVICE = -2,  /* no HIP device / HIP runtime failure */
+    PS_ERR_OOM = -3,
+    PS_ERR_WEIGHTS = -4,    /* WeightedIndex::new would panic (population.rs:440) */
+    PS_ERR_IO = -5,
+    PS_ERR_STATE = -6       /* call sequence invalid (e.g. rates not set) */
+} ps_status;
+
+const char *ps_last_error(void);
+/* library ABI version (bumped on any signature change) */
+int ps_abi_version(void);
+/* number of visible HIP devices, <0 on runtime failure.  Does not create a context. */
+int ps_device_count(void);
+
+/* ------------------------------------------------------------------------ */
+/* struct Population (population.rs:164-170)                                 */
+/* ------------------------------------------------------------------------ */
+typedef struct ps_population ps_population;
+
+typedef struct {
+    uint64_t pop_size;     /* N: `size` of Population::new (population.rs:182) */
+    uint64_t ncols;        /* `allele_count` held by THIS handle (a site shard for core) */
+    uint64_t global_cols;  /* full core_size / pan_size (== ncols when not sharded) */
+    uint64_t col_offset;   /* global index of local column 0 (site sharding) */
+    uint64_t core_genes;   /* population.rs:188 */
+    uint64_t seed;         /* --seed (main.rs:180); Philox key */
+    int32_t core;          /* population.rs:185: 1 = core alleles, 0 = accessory */
+    int32_t device;        /* HIP device ordinal, -1 = current device */
+} ps_config;
+
+/* Population::new (population.rs:181-242).  The reference draws ONE random
+ * vector and copies it to every individual (clonal start, :206-229); here the
+ * caller passes that vector (`init_vec`, ncols bytes; core: 1/2/4/8, accessory:
+ * 0/1).  ps_init_vector() below draws it from the build's seeded host stream. */
+int ps_population_create(const ps_config *cfg, const uint8_t *init_vec, ps_population **out);
+void ps_population_destroy(ps_population *p);
+
+/* Draw the clonal start vector of Population::new (population.rs:199-219):
+ * core: 1 << uniform{0..3}; accessory: uniform() < avg_gene_freq.  Columns
+ * [col_offset, col_offset+ncols) of the global vector are returned. */
+int ps_init_vector(uint64_t seed, int core, uint64_t col_offset, uint64_t ncols,
+                   double avg_gene_freq, uint8_t *out);
+
+/* Replace / read the whole matrix, individual-major u8 (N x ncols).  The
+ * reference has no such call (its field is private); tests use it to run the
+ * deterministic operators on identical state. */
+int ps_load_matrix(ps_population *p, const uint8_t *rows);
+int ps_read_matrix(ps_population *p, uint8_t *rows);
+
+/* The per-compartment rates the reference passes at every call:
+ * `mutations_vec` of mutate_alleles (population.rs:469; main.rs:275-276, :348,
+ * :361) and `recombinations_vec` of recombine (population.rs:546; main.rs:279,
+ * :349-351, :364-366), with the gene range of each compartment's weight mask
+ * (main.rs:342-345, :356-359; core: one compartment [0, global_cols)).  They are
+ * set once because the keyed dense form decides mutation and recombination of a
+ * cell from one random word. */
+int ps_set_rates(ps_population *p, int n_comp, const double *lam_mut, const double *lam_rec,
+                 const uint64_t *comp_begin, const uint64_t *comp_end);
+
+/* Population::next_generation(&sample) (population.rs:450-465) */
+int ps_next_generation(ps_population *p, const uint32_t *sample);
+/* Population::mutate_alleles (population.rs:467-542), generation = loop index j of main.rs:429 */
+int ps_mutate_alleles(ps_population *p, uint32_t generation);
+/* Population::recombine (population.rs:544-751) */
+int ps_recombine(ps_population *p, uint32_t generation);
+/* Fused next_generation + mutate_alleles + recombine in one pass over HBM
+ * (main.rs:445-464 for one matrix); bit-identical to the three calls in order.
+ * do_recombine mirrors the `HR_rate > 0.0` / `HGT_rate > 0.0` guards (main.rs:459-464). */
+int ps_step(ps_population *p, uint32_t generation, const uint32_t *sample, int do_recombine);
+
+/* Population::sample_indices (population.rs:270-448) on the accessory matrix.
+ * avg_pairwise_dists: N values (main.rs:435-440).  out_idx: N parent indices. */
+int ps_sample_indices(ps_population *acc, uint32_t generation, int32_t avg_gene_num,
+                      const double *avg_pairwise_dists, const double *selection_coefficients,
+                      int verbose, int no_control_genome_size, double genome_size_penalty,
+                      double competition_strength, uint32_t *out_idx);
+/* The device half of sample_indices: num_genes (population.rs:282-291) and the
+ * per-row log-fitness with the -inf reset (population.rs:299-322). */
+int ps_fitness_terms(ps_population *acc, const double *selection_coefficients,
+                     int32_t *num_genes, double *logw);
+/* The host half: weights (population.rs:293-437), then draws (:440-443). */
+int ps_sample_weights(const int32_t *num_genes, const double *logw, uint64_t n, uint64_t n_genes,
+                      int32_t avg_gene_num, const double *avg_pairwise_dists,
+                      int no_control_genome_size, double genome_size_penalty,
+                      double competition_strength, double *weights);
+int ps_draw_parents(const double *weights, uint64_t n, uint64_t seed, uint32_t generation,
+                    uint32_t *out_idx);
+
+/* Population::average_distance (population.rs:753-784) */
+int ps_average_distance(ps_population *p, double *out);
+/* Population::pairwise_distances (population.rs:787-837) */
+int ps_pairwise_distances(ps_population *p, uint64_t max_distances, const uint32_t *range1,
+                          const uint32_t *range2, double *out);
+/* Integer numerators of pairwise_distances for this handle's columns: core:
+ * out_a = sum popcount(x^y) (distances.rs:22-52, before the /2 of
+ * population.rs:817); accessory: out_a = intersection, out_b = union
+ * (distances.rs:55-77).  out_is_device != 0: out_a/out_b are device pointers
+ * (site-sharded runs all-reduce them over RCCL). */
+int ps_pairwise_counts(ps_population *p, uint64_t max_distances, const uint32_t *range1,
+                       const uint32_t *range2, uint32_t *out_a, uint32_t *out_b,
+                       int out_is_device);
+/* Population::gene_frequencies (population.rs:840-863): ncols + core_genes values */
+int ps_gene_frequencies(ps_population *p, double *out);
+/* Population::calc_gene_freq (population.rs:244-268) */
+int ps_calc_gene_freq(ps_population *p, double *out);
+/* Population::write (population.rs:865-897): <outpref>_core_genome.csv / _pangenome.csv */
+int ps_write(ps_population *p, const char *outpref);
+/* wait for all queued device work of this handle */
+int ps_sync(ps_population *p);
+
+/* ------------------------------------------------------------------------ */
+/* free functions of the seam                                                */
+/* ------------------------------------------------------------------------ */
+/* distances.rs:22-52 and :55-77, computed on the device from host slices */
+int ps_hamming_bitwise_fast(const uint8_t *x, const uint8_t *y, size_t n, uint32_t *out);
+int ps_jaccard_distance_fast(const uint8_t *x, const uint8_t *y, size_t n, uint32_t *inter,
+                             uint32_t *uni);
+/* population.rs:87-94: returns (std, mean), population sigma */
+int ps_standard_deviation(const double *values, uint64_t n, double *std_out, double *mean_out);
+/* population.rs:154-162 */
+char ps_int_to_base(uint8_t n);
+/* Rust `{}` Display of f64 as used by every writer (main.rs:328, :481, :496, :546) */
+int ps_fmt_f64(double v, char *buf, size_t cap);
+
+/* ------------------------------------------------------------------------ */
+/* main() as a library: parameter derivation and the generation loop         */
+/* ------------------------------------------------------------------------ */
+typedef struct {
+    uint64_t pop_size, core_size, pan_genes, core_genes;      /* main.rs:155-162 */
+    double avg_gene_freq, HR_rate, HGT_rate;                   /* :163-165 */
+    int32_t n_gen;                                             /* :166-167 */
+    uint64_t max_distances;                                    /* :169 */
+    double core_mu, rate_genes1, rate_genes2, prop_genes2;     /* :170-173 */
+    double prop_positive, pos_lambda, neg_lambda;              /* :174-176 */
+    uint64_t seed;                                             /* :180 */
+    int32_t print_dist, print_matrices, print_selection, verbose; /* :178-183 */
+    int32_t no_control_genome_size;                            /* :184 */
+    double genome_size_penalty, competition_strength;          /* :185-186 */
+    /* site sharding: this process holds core sites
+     * [core_size*shard_rank/shard_count, core_size*(shard_rank+1)/shard_count) */
+    int32_t shard_rank, shard_count;
+    int32_t device;                                            /* HIP device, -1 = current */
+} ps_sim_params;
+
+typedef struct {
+    uint64_t pan_size;                  /* main.rs:259 */
+    double avg_gene_freq_adj;           /* :263-268 */
+    int32_t avg_gene_num;               /* :272 */
+    double n_core_mutations;            /* :275-276 */
+    double n_recombinations_core;       /* :279 */
+    double n_recombinations_pan_total;  /* :280 */
+    int32_t n_comp;                     /* :341, :355 */
+    uint64_t comp_begin[2], comp_end[2];
+    double n_pan_mutations[2];          /* :348, :361 */
+    double n_recombinations_pan[2];     /* :349-351, :364-366 */
+} ps_derived;
+
+void ps_sim_default_params(ps_sim_params *p);                  /* defaults of main.rs:21-151 */
+/* main.rs:195-247: 0 if valid; otherwise the reference's stdout text is written to msg */
+int ps_sim_validate(const ps_sim_params *p, char *msg, size_t cap);
+int ps_sim_derive(const ps_sim_params *p, ps_derived *d);      /* main.rs:259-367 */
+/* main.rs:287-319 (build's seeded host stream) */
+int ps_selection_coefficients(uint64_t seed, uint64_t n_genes, double prop_positive,
+                              double pos_lambda, double neg_lambda, double *out);
+/* main.rs:413-427 */
+int ps_sample_pairs(uint64_t seed, uint64_t pop_size, uint64_t max_distances, uint32_t *range1,
+                    uint32_t *range2);
+
+typedef struct ps_sim ps_sim;
+/* main.rs:259-427: derive, draw selection coefficients, build both populations and the pair list */
+int ps_sim_create(const ps_sim_params *p, ps_sim **out);
+void ps_sim_destroy(ps_sim *s);
+/* main.rs:429-464 for generations [first, first+count): select, gather x2,
+ * mutate x2, HR, HGT.  Asynchronous on the device; ps_sim_sync() waits. */
+int ps_sim_run(ps_sim *s, uint32_t first_generation, uint32_t count);
+int ps_sim_sync(ps_sim *s);
+ps_population *ps_sim_core(ps_sim *s);
+ps_population *ps_sim_acc(ps_sim *s);
+const double *ps_sim_selection(ps_sim *s);                     /* pan_size values */
+const uint32_t *ps_sim_range1(ps_sim *s);
+const uint32_t *ps_sim_range2(ps_sim *s);
+/* parent indices drawn for the most recent generation (N values) */
+int ps_sim_last_parents(ps_sim *s, uint32_t *out_idx);
+/* Device timing of the core sweep kernel, measured with HIP events on the
+ * stream it is launched on, accumulated since the last reset: launches, total
+ * milliseconds, and algorithmic bytes per launch (2*N*L_local). */
+int ps_sim_sweep_timing(ps_sim *s, int reset, uint64_t *launches, double *total_ms,
+                        double *bytes_per_launch);
+int ps_sim_enable_timing(ps_sim *s, int on);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

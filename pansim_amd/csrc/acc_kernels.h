@@ -1,0 +1,261 @@
+// acc_kernels.h -- gfx950 kernels for the accessory (gene presence/absence) matrix.
+//
+// HBM layout (bit-packed, two coherent views):
+//   G-major  accG[g][w]  (u64, W = ceil(N/64) words per gene): bit (i & 63) of word
+//            i >> 6 is the presence of gene g in individual i.  One wave64 ballot
+//            builds one word, so gather/mutation edit the bitset with ballots.
+//   I-major  accI[i][gw] (u64, GW = ceil(G/64) words per individual): the row of an
+//            individual; used for rank/select of HGT donors (population.rs:636-680),
+//            per-individual fitness sums (:282-322) and Jaccard pairs (:824-830).
+// Padding bits (i >= N, g >= G) are always zero.
+#pragma once
+
+#include "ps_common.h"
+
+struct acc_dims { uint32_t N, G, W, GW; };
+
+// clonal start (population.rs:221-229)
+__global__ void acc_init_kernel(uint64_t *accG, uint64_t *accI, const uint8_t *init_vec, acc_dims d)
+{
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t nG = (uint64_t)d.G * d.W, nI = (uint64_t)d.N * d.GW;
+    if (t < nG) {
+        const uint32_t g = (uint32_t)(t / d.W), w = (uint32_t)(t % d.W);
+        const uint32_t nb = min(64u, d.N - w * 64u);
+        const uint64_t m = (nb == 64u) ? ~0ull : ((1ull << nb) - 1ull);
+        accG[t] = init_vec[g] ? m : 0ull;
+    } else if (t < nG + nI) {
+        const uint64_t u = t - nG;
+        const uint32_t gw = (uint32_t)(u % d.GW);
+        uint64_t word = 0;
+        for (uint32_t b = 0; b < 64; b++) {
+            const uint32_t g = gw * 64u + b;
+            if (g < d.G && init_vec[g]) word |= 1ull << b;
+        }
+        accI[u] = word;
+    }
+}
+
+// u8 rows[N][G] -> I-major
+__global__ void acc_pack_rows_kernel(const uint8_t *rows, uint64_t *accI, acc_dims d)
+{
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (uint64_t)d.N * d.GW) return;
+    const uint32_t i = (uint32_t)(t / d.GW), gw = (uint32_t)(t % d.GW);
+    uint64_t word = 0;
+    for (uint32_t b = 0; b < 64; b++) {
+        const uint32_t g = gw * 64u + b;
+        if (g < d.G && rows[(uint64_t)i * d.G + g] != 0) word |= 1ull << b;
+    }
+    accI[t] = word;
+}
+
+// I-major -> G-major (one wave per (gene block, individual word): ballot per gene)
+__global__ void __launch_bounds__(64) acc_i_to_g_kernel(const uint64_t *accI, uint64_t *accG, acc_dims d)
+{
+    const uint32_t w = blockIdx.x, gw = blockIdx.y, lane = threadIdx.x;
+    const uint32_t i = w * 64u + lane;
+    const uint64_t mine = (i < d.N) ? accI[(uint64_t)i * d.GW + gw] : 0ull;
+    for (uint32_t b = 0; b < 64; b++) {
+        const uint32_t g = gw * 64u + b;
+        if (g >= d.G) break;
+        const uint64_t word = __ballot((mine >> b) & 1ull);
+        if (lane == 0) accG[(uint64_t)g * d.W + w] = word;
+    }
+}
+
+// I-major -> u8 rows[N][G]
+__global__ void acc_unpack_rows_kernel(const uint64_t *accI, uint8_t *rows, acc_dims d)
+{
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (uint64_t)d.N * d.G) return;
+    const uint32_t i = (uint32_t)(t / d.G), g = (uint32_t)(t % d.G);
+    rows[t] = (uint8_t)((accI[(uint64_t)i * d.GW + (g >> 6)] >> (g & 63u)) & 1ull);
+}
+
+struct acc_step_args {
+    const uint64_t *srcG;
+    uint64_t *dstG, *dstI;
+    const uint32_t *idx;
+    acc_dims d;
+    uint32_t gen, k0, k1;
+    ps_acc_plan plan;
+};
+
+// Fused parent gather (population.rs:450-465) and gain/loss (population.rs:486-510):
+// lane = individual, loop over the 64 genes of the block; the new bits of 64
+// individuals are assembled with one ballot per gene.
+template <bool DO_GATHER, bool DO_MUT>
+__global__ void __launch_bounds__(64) acc_step_kernel(acc_step_args a)
+{
+    const uint32_t w = blockIdx.x, gw = blockIdx.y, lane = threadIdx.x;
+    const acc_dims d = a.d;
+    const uint32_t i = w * 64u + lane;
+    const bool valid = i < d.N;
+    const uint32_t p = (DO_GATHER && valid) ? a.idx[i] : (valid ? i : 0u);
+    const uint32_t pw = p >> 6, pb = p & 63u;
+    uint64_t rowword = 0;
+    ps_u4 rnd = { 0, 0, 0, 0 };
+    for (uint32_t b = 0; b < 64; b++) {
+        const uint32_t g = gw * 64u + b;
+        if (g >= d.G) break;
+        uint32_t bit = (uint32_t)((a.srcG[(uint64_t)g * d.W + pw] >> pb) & 1ull);
+        if (DO_MUT) {
+            if ((b & 3u) == 0u)
+                rnd = ps_philox(g >> 2, i, a.gen, PS_STREAM_ACC_MUT, a.k0, a.k1);
+            const uint32_t word = ((b & 3u) == 0u) ? rnd.x : ((b & 3u) == 1u) ? rnd.y
+                                  : ((b & 3u) == 2u) ? rnd.z : rnd.w;
+            uint32_t thr = 0;
+#pragma unroll
+            for (int c = 0; c < PS_MAX_COMP; c++)
+                if (c < a.plan.n_comp && g >= a.plan.comp_begin[c] && g < a.plan.comp_end[c])
+                    thr = a.plan.flip_thr[c];
+            bit ^= (word < thr) ? 1u : 0u;                 // population.rs:505
+        }
+        bit = valid ? bit : 0u;
+        const uint64_t gword = __ballot(bit);
+        if (lane == 0) a.dstG[(uint64_t)g * d.W + w] = gword;
+        rowword |= (uint64_t)bit << b;
+    }
+    if (valid) a.dstI[(uint64_t)i * d.GW + gw] = rowword;
+}
+
+// number of present genes of every individual inside each compartment
+__global__ void acc_comp_counts_kernel(const uint64_t *accI, uint32_t *cnt /* [n_comp][N] */,
+                                       acc_dims d, ps_acc_plan plan)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= d.N) return;
+    for (int c = 0; c < plan.n_comp; c++) {
+        const uint32_t gb = plan.comp_begin[c], ge = plan.comp_end[c];
+        uint32_t n = 0;
+        for (uint32_t gw = gb >> 6; gw * 64u < ge; gw++) {
+            uint64_t word = accI[(uint64_t)i * d.GW + gw];
+            const uint32_t lo = gw * 64u;
+            if (lo < gb) word &= ~0ull << (gb - lo);
+            if (lo + 64u > ge) word &= (ge - lo >= 64u) ? ~0ull : ((1ull << (ge - lo)) - 1ull);
+            n += __popcll(word);
+        }
+        cnt[(uint64_t)c * d.N + i] = n;
+    }
+}
+
+__device__ __forceinline__ uint32_t ps_select64(uint64_t word, uint32_t j)
+{
+    for (uint32_t t = 0; t < j; t++) word &= word - 1ull;   // drop the j lowest set bits
+    return (uint32_t)__builtin_ctzll(word);
+}
+
+// HGT events of one compartment (population.rs:544-751 accessory path): event e
+// picks a uniform donor, a uniform other recipient and a uniform gene among the
+// donor's present genes of the compartment IN THE SNAPSHOT; the recipient gains
+// the gene (value always 1, :632) -- an idempotent OR, so order does not matter.
+__global__ void __launch_bounds__(256) acc_hgt_kernel(const uint64_t *snapI, const uint32_t *cnt,
+                                                      uint64_t *dstG, uint64_t *dstI, acc_dims d,
+                                                      uint32_t gb, uint32_t ge, uint32_t comp,
+                                                      uint64_t K, uint32_t gen, uint32_t k0, uint32_t k1)
+{
+    const uint32_t stream = PS_STREAM_HGT | (comp << 8);
+    for (uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; e < K;
+         e += (uint64_t)gridDim.x * blockDim.x) {
+        const ps_u4 r = ps_philox((uint32_t)e, (uint32_t)(e >> 32), gen, stream, k0, k1);
+        const uint32_t dn = ps_mulhi(r.x, d.N);
+        uint32_t rc = ps_mulhi(r.y, d.N - 1u);
+        rc += (rc >= dn) ? 1u : 0u;                         // population.rs:618
+        const uint32_t n = cnt[(uint64_t)comp * d.N + dn];
+        if (n == 0) continue;                               // population.rs:672
+        uint32_t j = ps_mulhi(r.z, n);
+        uint32_t gene = 0;
+        for (uint32_t gw = gb >> 6; gw * 64u < ge; gw++) {
+            uint64_t word = snapI[(uint64_t)dn * d.GW + gw];
+            const uint32_t lo = gw * 64u;
+            if (lo < gb) word &= ~0ull << (gb - lo);
+            if (lo + 64u > ge) word &= (ge - lo >= 64u) ? ~0ull : ((1ull << (ge - lo)) - 1ull);
+            const uint32_t pc = __popcll(word);
+            if (j < pc) { gene = lo + ps_select64(word, j); break; }
+            j -= pc;
+        }
+        atomicOr((unsigned long long *)&dstG[(uint64_t)gene * d.W + (rc >> 6)], 1ull << (rc & 63u));
+        atomicOr((unsigned long long *)&dstI[(uint64_t)rc * d.GW + (gene >> 6)], 1ull << (gene & 63u));
+    }
+}
+
+// population.rs:282-322: gene count and left-to-right f64 sum of ln(1+s_g) over
+// the present genes (absent genes add ln(1+0) = +0.0, which leaves an f64 sum
+// unchanged); a present gene with ln(1+s_g) == -inf resets the row to 0.0.
+__global__ void acc_fitness_kernel(const uint64_t *accI, const double *log1p_s, int need_logw,
+                                   int32_t *num_genes, double *logw, acc_dims d)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= d.N) return;
+    int32_t n = 0;
+    double sum = 0.0;
+    bool neg_inf = false;
+    for (uint32_t gw = 0; gw < d.GW; gw++) {
+        uint64_t word = accI[(uint64_t)i * d.GW + gw];
+        n += __popcll(word);
+        if (need_logw) {
+            while (word) {
+                const uint32_t b = (uint32_t)__builtin_ctzll(word);
+                word &= word - 1ull;
+                const double c = log1p_s[gw * 64u + b];
+                if (c == -INFINITY) neg_inf = true;
+                sum += c;
+            }
+        }
+    }
+    num_genes[i] = n;
+    logw[i] = neg_inf ? 0.0 : sum;
+}
+
+// population.rs:840-863 numerators: number of individuals carrying gene g
+__global__ void acc_gene_counts_kernel(const uint64_t *accG, uint32_t *counts, acc_dims d)
+{
+    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= d.G) return;
+    uint32_t n = 0;
+    for (uint32_t w = 0; w < d.W; w++) n += __popcll(accG[(uint64_t)g * d.W + w]);
+    counts[g] = n;
+}
+
+// distances.rs:55-77 numerators for sampled pairs
+__global__ void acc_pair_counts_kernel(const uint64_t *accI, const uint32_t *r1, const uint32_t *r2,
+                                       uint64_t P, uint32_t *inter, uint32_t *uni, acc_dims d)
+{
+    const uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= P) return;
+    const uint64_t *x = accI + (uint64_t)r1[k] * d.GW, *y = accI + (uint64_t)r2[k] * d.GW;
+    uint32_t in = 0, un = 0;
+    for (uint32_t gw = 0; gw < d.GW; gw++) {
+        const uint64_t a = x[gw], b = y[gw];
+        in += __popcll(a & b);
+        un += __popcll(a | b);
+    }
+    inter[k] = in;
+    uni[k] = un;
+}
+
+// population.rs:753-784 on the accessory matrix: mean Jaccard distance of i to all
+// others, summed in ascending j like the reference's fold (:770).
+__global__ void acc_average_distance_kernel(const uint64_t *accI, double *out, acc_dims d,
+                                            double core_genes)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= d.N) return;
+    const uint64_t *x = accI + (uint64_t)i * d.GW;
+    double sum = 0.0;
+    for (uint32_t j = 0; j < d.N; j++) {
+        if (j == i) continue;
+        const uint64_t *y = accI + (uint64_t)j * d.GW;
+        uint32_t in = 0, un = 0;
+        for (uint32_t gw = 0; gw < d.GW; gw++) {
+            in += __popcll(x[gw] & y[gw]);
+            un += __popcll(x[gw] | y[gw]);
+        }
+        const double pd = 1.0 - (((double)in + 0.0 + core_genes) / ((double)un + 0.0 + core_genes));
+        sum = sum + pd;
+    }
+    double fd = sum / (double)(d.N - 1u);
+    if (fd == 0.0) fd = 2.2250738585072014e-308;   // f64::MIN_POSITIVE, population.rs:774-776
+    out[i] = fd;
+}

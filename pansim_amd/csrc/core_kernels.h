@@ -1,0 +1,345 @@
+// core_kernels.h -- gfx950 kernels for the core-genome matrix (site-major u8 in HBM).
+//
+// HBM layout: state[row][pitch], one row per core SITE, byte i of a row is the
+// allele (1/2/4/8) of individual i at that site; pitch = N rounded up to 128 so
+// that a row is a whole number of 16-byte lane chunks and starts 128-B aligned.
+// Every per-generation operator is row-local in this layout:
+//   gather  child[s][i] = parent[s][idx[i]]                 population.rs:450-465
+//   mutate  cell (s,i) <- 2/4/8 with prob 1-exp(-lam/L)     population.rs:511-540
+//   HR      cell (s,r) <- post-mutation cell (s,d)          population.rs:544-751
+// so one workgroup owns a row at a time, stages it in LDS, and writes it back in
+// place: algorithmic HBM traffic is one read and one write of N*L bytes.
+#pragma once
+
+#include "ps_common.h"
+
+struct core_sweep_args {
+    uint8_t *state;
+    const uint32_t *idx;   // parents (device), DO_GATHER only
+    uint32_t N, pitch, cpr, rows;
+    uint32_t site_offset;  // global site index of local row 0 (Philox counter)
+    uint32_t gen, k0, k1;
+    ps_core_plan plan;
+};
+
+__device__ __forceinline__ void ps_set_byte(uint32_t (&w)[4], uint32_t k, uint32_t v)
+{
+    const uint32_t j = k >> 2, sh = (k & 3u) * 8u;
+    const uint32_t m = ~(0xFFu << sh), val = v << sh;
+#pragma unroll
+    for (uint32_t jj = 0; jj < 4; jj++) w[jj] = (jj == j) ? ((w[jj] & m) | val) : w[jj];
+}
+
+// 16-bit mask of the level-1 bytes that may hold an event (byte <= bC)
+__device__ __forceinline__ uint32_t ps_candidate_mask(const ps_u4 &l1, uint32_t bC)
+{
+    const uint32_t w[4] = { l1.x, l1.y, l1.z, l1.w };
+    uint32_t cm = 0;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+#pragma unroll
+        for (int b = 0; b < 4; b++) {
+            const uint32_t byte = (w[j] >> (8 * b)) & 0xFFu;
+            cm |= (byte <= bC ? 1u : 0u) << (4 * j + b);
+        }
+    }
+    return cm;
+}
+
+__device__ __forceinline__ uint32_t ps_l1_byte(const ps_u4 &l1, uint32_t k)
+{
+    const uint32_t j = k >> 2;
+    const uint32_t w = (j == 0) ? l1.x : (j == 1) ? l1.y : (j == 2) ? l1.z : l1.w;
+    return (w >> ((k & 3u) * 8u)) & 0xFFu;
+}
+
+// One pass over the matrix: optional gather, mutation and HR, fused.
+// WAVE_ROW: a row fits one wavefront (pitch <= 1024): each of the block's waves
+// owns its own row and keeps its 16 parent indices in registers.  Otherwise the
+// whole block cooperates on one row and lanes loop over its chunks.
+template <bool WAVE_ROW, bool DO_GATHER, bool DO_MUT, bool DO_HR>
+__global__ void __launch_bounds__(1024) core_sweep_kernel(core_sweep_args a)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t lpr = WAVE_ROW ? 64u : blockDim.x;
+    const uint32_t rpb = WAVE_ROW ? (blockDim.x >> 6) : 1u;
+    const uint32_t slot = WAVE_ROW ? (tid >> 6) : 0u;
+    const uint32_t lane = WAVE_ROW ? (tid & 63u) : tid;
+    const uint32_t hrm_bytes = (a.cpr * 2u + 15u) & ~15u;
+    const uint32_t slot_bytes = 2u * a.pitch + hrm_bytes;
+    uint8_t *rowA = lds + slot * slot_bytes;
+    uint8_t *rowS = rowA + a.pitch;
+    uint16_t *hrm = (uint16_t *)(rowS + a.pitch);
+    const ps_core_plan pl = a.plan;
+    const bool events = pl.has_events && (DO_MUT || DO_HR);
+
+    uint32_t pidx[16];
+    if (WAVE_ROW && DO_GATHER) {
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            const uint32_t i = lane * 16u + k;
+            pidx[k] = (i < a.N) ? a.idx[i] : 0u;
+        }
+    }
+
+    for (uint32_t r0 = blockIdx.x * rpb; r0 < a.rows; r0 += gridDim.x * rpb) {
+        const uint32_t row = r0 + slot;
+        const bool active = row < a.rows;
+        const uint32_t site = a.site_offset + row;
+        uint8_t *grow = a.state + (size_t)row * a.pitch;
+
+        if (DO_GATHER) {
+            if (active)
+                for (uint32_t c = lane; c < a.cpr; c += lpr)
+                    *(uint4 *)(rowA + 16u * c) = *(const uint4 *)(grow + 16u * c);
+            __syncthreads();
+        }
+
+        uint32_t d_keep[4] = { 0, 0, 0, 0 };
+        uint32_t hm_keep = 0;
+        if (active) {
+            for (uint32_t c = lane; c < a.cpr; c += lpr) {
+                uint32_t d[4];
+                if (DO_GATHER) {
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        uint32_t w = 0;
+#pragma unroll
+                        for (int b = 0; b < 4; b++) {
+                            const uint32_t i = c * 16u + 4 * j + b;
+                            uint32_t p;
+                            if (WAVE_ROW) p = pidx[4 * j + b];
+                            else p = (i < a.N) ? a.idx[i] : 0u;
+                            const uint32_t v = (i < a.N) ? (uint32_t)rowA[p] : 0u;
+                            w |= v << (8 * b);
+                        }
+                        d[j] = w;
+                    }
+                } else {
+                    const uint4 v = *(const uint4 *)(grow + 16u * c);
+                    d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+                }
+                uint32_t hm = 0;
+                if (events) {
+                    const ps_u4 l1 = ps_philox(site, c, a.gen, PS_STREAM_CORE_L1, a.k0, a.k1);
+                    uint32_t cm = ps_candidate_mask(l1, pl.bC);
+                    while (cm) {
+                        const uint32_t k = __builtin_ctz(cm);
+                        cm &= cm - 1u;
+                        const uint32_t i = c * 16u + k;
+                        if (i >= a.N) continue;
+                        const ps_u4 l2 = ps_philox(site, i, a.gen, PS_STREAM_CORE_L2, a.k0, a.k1);
+                        const uint32_t u = (ps_l1_byte(l1, k) << 24) | (l2.x >> 8);
+                        const ps_cell cell = ps_classify(u, pl);
+                        if (DO_MUT && cell.mut) ps_set_byte(d, k, cell.mut);
+                        if (DO_HR && cell.hr) hm |= 1u << k;
+                    }
+                }
+                if (DO_HR) {
+                    *(uint4 *)(rowS + 16u * c) = make_uint4(d[0], d[1], d[2], d[3]);
+                    if (WAVE_ROW) {
+                        d_keep[0] = d[0]; d_keep[1] = d[1]; d_keep[2] = d[2]; d_keep[3] = d[3];
+                        hm_keep = hm;
+                    } else {
+                        hrm[c] = (uint16_t)hm;
+                    }
+                } else {
+                    *(uint4 *)(grow + 16u * c) = make_uint4(d[0], d[1], d[2], d[3]);
+                }
+            }
+        }
+
+        if (DO_HR) {
+            __syncthreads();   // rowS now holds the post-mutation snapshot of the row
+            if (active) {
+                for (uint32_t c = lane; c < a.cpr; c += lpr) {
+                    uint32_t d[4];
+                    uint32_t hm;
+                    if (WAVE_ROW) {
+                        d[0] = d_keep[0]; d[1] = d_keep[1]; d[2] = d_keep[2]; d[3] = d_keep[3];
+                        hm = hm_keep;
+                    } else {
+                        const uint4 v = *(const uint4 *)(rowS + 16u * c);
+                        d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+                        hm = hrm[c];
+                    }
+                    while (hm) {
+                        const uint32_t k = __builtin_ctz(hm);
+                        hm &= hm - 1u;
+                        const uint32_t i = c * 16u + k;
+                        const ps_u4 l2 = ps_philox(site, i, a.gen, PS_STREAM_CORE_L2, a.k0, a.k1);
+                        uint32_t donor = ps_mulhi(l2.y, a.N - 1u);
+                        donor += (donor >= i) ? 1u : 0u;          // population.rs:618
+                        ps_set_byte(d, k, (uint32_t)rowS[donor]); // snapshot read, :693-695
+                    }
+                    *(uint4 *)(grow + 16u * c) = make_uint4(d[0], d[1], d[2], d[3]);
+                }
+            }
+            if (!DO_GATHER) __syncthreads();   // rowS is rewritten by the next row
+        }
+    }
+}
+
+// clonal start: every individual gets allele_vec[site] (population.rs:206-212)
+__global__ void core_init_kernel(uint8_t *state, const uint8_t *allele_vec, uint32_t N,
+                                 uint32_t pitch, uint32_t rows)
+{
+    const uint32_t cpr = pitch >> 4;
+    const uint64_t total = (uint64_t)rows * cpr;
+    for (uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total;
+         t += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t row = (uint32_t)(t / cpr), c = (uint32_t)(t % cpr);
+        const uint32_t v = allele_vec[row];
+        uint32_t w[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            uint32_t x = 0;
+#pragma unroll
+            for (int b = 0; b < 4; b++)
+                x |= ((c * 16u + 4 * j + b < N) ? v : 0u) << (8 * b);
+            w[j] = x;
+        }
+        *(uint4 *)(state + (size_t)row * pitch + 16u * c) = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+}
+
+// individual-major rows[N][L] <-> site-major state[L][pitch], 64x64 tiles through LDS
+template <bool TO_STATE>
+__global__ void __launch_bounds__(256) core_transpose_kernel(uint8_t *state, uint8_t *rows_im,
+                                                             uint32_t N, uint32_t pitch, uint64_t L)
+{
+    __shared__ uint8_t tile[64][65];
+    const uint32_t tx = threadIdx.x & 63u, ty = threadIdx.x >> 6;
+    const uint64_t s0 = (uint64_t)blockIdx.x * 64u;
+    const uint32_t i0 = blockIdx.y * 64u;
+    if (TO_STATE) {
+        for (uint32_t r = ty; r < 64; r += 4) {
+            const uint32_t i = i0 + r;
+            const uint64_t s = s0 + tx;
+            tile[r][tx] = (i < N && s < L) ? rows_im[(uint64_t)i * L + s] : 0;
+        }
+        __syncthreads();
+        for (uint32_t r = ty; r < 64; r += 4) {
+            const uint64_t s = s0 + r;
+            const uint32_t i = i0 + tx;
+            if (s < L && i < pitch) state[s * pitch + i] = (i < N) ? tile[tx][r] : 0;
+        }
+    } else {
+        for (uint32_t r = ty; r < 64; r += 4) {
+            const uint64_t s = s0 + r;
+            const uint32_t i = i0 + tx;
+            tile[r][tx] = (s < L && i < N) ? state[s * pitch + i] : 0;
+        }
+        __syncthreads();
+        for (uint32_t r = ty; r < 64; r += 4) {
+            const uint32_t i = i0 + r;
+            const uint64_t s = s0 + tx;
+            if (i < N && s < L) rows_im[(uint64_t)i * L + s] = tile[tx][r];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// sampled-pair Hamming numerators: out[k] += sum_s popcount(x[s][i_k] ^ x[s][j_k])
+// (distances.rs:22-52 over the columns held by this handle).
+//
+// Tiled form: a workgroup packs a tile of SITES x all N individuals into LDS as
+// individual-major nibble strings (8 sites per dword, alleles are one-hot < 16),
+// then every thread compares the two strings of each of its A pairs with 16-byte
+// LDS reads.  Each pair keeps its partial count in a register across the tiles
+// of the block's site range; one atomicAdd per (range, pair).
+// ---------------------------------------------------------------------------
+template <int A>
+__global__ void __launch_bounds__(1024) core_pair_counts_tiled(
+    const uint8_t *state, uint32_t N, uint32_t pitch, uint32_t rows, const uint32_t *r1,
+    const uint32_t *r2, uint64_t P, uint32_t *out, uint32_t W /* dwords per individual per tile */,
+    uint32_t tiles_per_range)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t T[];
+    const uint32_t RS = W + 4u;
+    const uint32_t tid = threadIdx.x;
+    const uint32_t sites_per_tile = W * 8u;
+    uint32_t pi[A], pj[A], acc[A];
+    uint64_t pk[A];
+#pragma unroll
+    for (int q = 0; q < A; q++) {
+        const uint64_t k = ((uint64_t)blockIdx.y * A + q) * blockDim.x + tid;
+        pk[q] = k;
+        acc[q] = 0;
+        if (k < P) { pi[q] = r1[k] * RS; pj[q] = r2[k] * RS; }
+        else { pi[q] = 0; pj[q] = 0; }
+    }
+    for (uint32_t t = 0; t < tiles_per_range; t++) {
+        const uint32_t s0 = (blockIdx.x * tiles_per_range + t) * sites_per_tile;
+        if (s0 >= rows) break;
+        __syncthreads();
+        for (uint32_t e = tid; e < N * W; e += blockDim.x) {
+            const uint32_t w = e / N, i = e % N;   // consecutive lanes -> consecutive individuals
+            uint32_t packed = 0;
+#pragma unroll
+            for (int b = 0; b < 8; b++) {
+                const uint32_t s = s0 + w * 8u + b;
+                const uint32_t v = (s < rows) ? (uint32_t)state[(size_t)s * pitch + i] : 0u;
+                packed |= (v & 0xFu) << (4 * b);
+            }
+            T[i * RS + w] = packed;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < A; q++) {
+            uint32_t s = 0;
+            for (uint32_t w = 0; w < W; w += 4) {
+                const uint4 x = *(const uint4 *)&T[pi[q] + w];
+                const uint4 y = *(const uint4 *)&T[pj[q] + w];
+                s += __popc(x.x ^ y.x) + __popc(x.y ^ y.y) + __popc(x.z ^ y.z) + __popc(x.w ^ y.w);
+            }
+            acc[q] += s;
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < A; q++)
+        if (pk[q] < P && acc[q]) atomicAdd(&out[pk[q]], acc[q]);
+}
+
+// generic form (any N, any byte values): one thread per pair, blockIdx.y splits the sites
+__global__ void __launch_bounds__(256) core_pair_counts_simple(
+    const uint8_t *state, uint32_t pitch, uint32_t rows, const uint32_t *r1, const uint32_t *r2,
+    uint64_t P, uint32_t *out, uint32_t rows_per_slice)
+{
+    const uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= P) return;
+    const uint32_t i = r1[k], j = r2[k];
+    const uint32_t sb = blockIdx.y * rows_per_slice;
+    const uint32_t se = min(rows, sb + rows_per_slice);
+    uint32_t acc = 0;
+    for (uint32_t s = sb; s < se; s++) {
+        const uint8_t *row = state + (size_t)s * pitch;
+        acc += __popc((uint32_t)(row[i] ^ row[j]));
+    }
+    if (acc) atomicAdd(&out[k], acc);
+}
+
+// distances.rs:22-52 / :55-77 on two byte slices already in device memory
+__global__ void __launch_bounds__(256) slice_counts_kernel(const uint8_t *x, const uint8_t *y,
+                                                           uint64_t n, uint32_t *out3)
+{
+    uint32_t h = 0, in = 0, un = 0;
+    for (uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n;
+         t += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t a = x[t], b = y[t];
+        h += __popc(a ^ b);
+        in += __popc(a & b);
+        un += __popc(a | b);
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        h += __shfl_down(h, off, 64);
+        in += __shfl_down(in, off, 64);
+        un += __shfl_down(un, off, 64);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        if (h) atomicAdd(&out3[0], h);
+        if (in) atomicAdd(&out3[1], in);
+        if (un) atomicAdd(&out3[2], un);
+    }
+}

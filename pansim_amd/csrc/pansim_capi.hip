@@ -1,0 +1,1388 @@
+// pansim_capi.hip -- implementation of include/pansim_hip.h for gfx950 (MI355X).
+//
+// Host side of the per-generation hot path of bacpop/Pansim
+// (pansim/src/population.rs, pansim/src/main.rs:259-553) above hand-written HIP
+// kernels.  There is no CPU compute path in this library: every operator runs on
+// the device and fails with PS_ERR_NO_DEVICE when none is present.
+#include "../../include/pansim_hip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <charconv>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "acc_kernels.h"
+#include "core_kernels.h"
+#include "ps_common.h"
+
+// ---------------------------------------------------------------------------
+// errors
+// ---------------------------------------------------------------------------
+static thread_local std::string g_err;
+
+static int ps_fail(int code, const char *fmt, ...)
+{
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define HIPCHK(expr)                                                                     \
+    do {                                                                                 \
+        hipError_t e_ = (expr);                                                          \
+        if (e_ != hipSuccess)                                                            \
+            return ps_fail(e_ == hipErrorOutOfMemory ? PS_ERR_OOM : PS_ERR_NO_DEVICE,    \
+                           "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, \
+                           __LINE__);                                                    \
+    } while (0)
+
+#define PSCHK(expr)              \
+    do {                         \
+        int rc_ = (expr);        \
+        if (rc_ != PS_OK) return rc_; \
+    } while (0)
+
+extern "C" const char *ps_last_error(void) { return g_err.c_str(); }
+extern "C" int ps_abi_version(void) { return 1; }
+extern "C" int ps_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return -1;
+    return n;
+}
+
+// ---------------------------------------------------------------------------
+// seeded host streams: stateless, indexed Philox draws
+// ---------------------------------------------------------------------------
+static inline ps_u4 hs_block(uint64_t seed, uint32_t stream, uint32_t gen, uint64_t blk)
+{
+    return ps_philox((uint32_t)blk, (uint32_t)(blk >> 32), gen, stream, (uint32_t)seed,
+                     (uint32_t)(seed >> 32));
+}
+static inline double hs_f64(uint64_t seed, uint32_t stream, uint32_t gen, uint64_t n)
+{
+    const ps_u4 w = hs_block(seed, stream, gen, n >> 1);
+    const uint64_t x = (n & 1) ? (((uint64_t)w.w << 32) | w.z) : (((uint64_t)w.y << 32) | w.x);
+    return (double)(x >> 11) * (1.0 / 9007199254740992.0);
+}
+static inline uint32_t hs_u32(uint64_t seed, uint32_t stream, uint32_t gen, uint64_t n)
+{
+    const ps_u4 w = hs_block(seed, stream, gen, n >> 2);
+    switch (n & 3) {
+    case 0: return w.x;
+    case 1: return w.y;
+    case 2: return w.z;
+    default: return w.w;
+    }
+}
+
+// Poisson(mean): Knuth product below 10, Hoermann's PTRS above (the reference uses
+// statrs::Poisson, population.rs:484, :562; only the distribution is contractual).
+static uint64_t hs_poisson(double mean, uint64_t seed, uint32_t stream, uint32_t gen)
+{
+    uint64_t n = 0;
+    if (!(mean > 0.0)) return 0;
+    if (mean < 10.0) {
+        const double lim = std::exp(-mean);
+        double p = 1.0;
+        uint64_t k = 0;
+        do { k++; p *= hs_f64(seed, stream, gen, n++); } while (p > lim);
+        return k - 1;
+    }
+    const double slam = std::sqrt(mean), loglam = std::log(mean);
+    const double b = 0.931 + 2.53 * slam;
+    const double a = -0.059 + 0.02483 * b;
+    const double invalpha = 1.1239 + 1.1328 / (b - 3.4);
+    const double vr = 0.9277 - 3.6224 / (b - 2.0);
+    for (;;) {
+        const double U = hs_f64(seed, stream, gen, n++) - 0.5;
+        const double V = hs_f64(seed, stream, gen, n++);
+        const double us = 0.5 - std::fabs(U);
+        const double kf = std::floor((2.0 * a / us + b) * U + mean + 0.43);
+        if (us >= 0.07 && V <= vr) return (uint64_t)kf;
+        if (kf < 0.0 || (us < 0.013 && V > us)) continue;
+        if (std::log(V) + std::log(invalpha) - std::log(a / (us * us) + b)
+            <= -mean + kf * loglam - std::lgamma(kf + 1.0))
+            return (uint64_t)kf;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// keyed dense plans
+// ---------------------------------------------------------------------------
+static uint32_t prob_to_u32(double p)
+{
+    const double x = std::floor(p * 4294967296.0);
+    if (!(x > 0.0)) return 0u;
+    if (x >= 4294967295.0) return 0xFFFFFFFFu;
+    return (uint32_t)x;
+}
+
+static void make_core_plan(double lam_mut, double lam_hr, uint64_t L, ps_core_plan *plan)
+{
+    const double p = (lam_mut > 0.0) ? -std::expm1(-lam_mut / (double)L) : 0.0;
+    const double q = (lam_hr > 0.0) ? -std::expm1(-lam_hr / (double)L) : 0.0;
+    const double a = p * (1.0 - q) / 3.0;
+    const double b = p * q / 3.0;
+    const double c = (1.0 - p) * q;
+    double cum[7];
+    cum[0] = a;
+    cum[1] = a + a;
+    cum[2] = a + a + a;
+    cum[3] = cum[2] + b;
+    cum[4] = cum[2] + b + b;
+    cum[5] = cum[2] + b + b + b;
+    cum[6] = cum[5] + c;
+    uint32_t prev = 0;
+    for (int k = 0; k < 7; k++) {
+        uint32_t t = prob_to_u32(cum[k]);
+        if (t < prev) t = prev;
+        plan->T[k] = t;
+        prev = t;
+    }
+    plan->has_events = plan->T[6] > 0u;
+    plan->bC = plan->has_events ? ((plan->T[6] - 1u) >> 24) : 0u;
+}
+
+static uint32_t acc_flip_threshold(double lam, uint64_t n_genes)
+{
+    if (!(lam > 0.0) || n_genes == 0) return 0u;
+    const double pf = -std::expm1(-2.0 * lam / (double)n_genes) / 2.0;
+    return prob_to_u32(pf);
+}
+
+// ---------------------------------------------------------------------------
+// struct Population (population.rs:164-170)
+// ---------------------------------------------------------------------------
+struct ps_population {
+    ps_config cfg{};
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool rates_set = false;
+    // core: site-major u8
+    uint8_t *state = nullptr;
+    uint32_t pitch = 0, cpr = 0;
+    ps_core_plan cplan{};
+    bool nibble_safe = true;
+    // accessory: bit-packed, two views, ping-pong
+    acc_dims d{};
+    uint64_t *G[2] = { nullptr, nullptr };
+    uint64_t *I[2] = { nullptr, nullptr };
+    uint64_t *Isnap = nullptr;
+    uint32_t *cnt = nullptr;
+    int cur = 0;
+    ps_acc_plan aplan{};
+    // scratch
+    uint32_t *d_idx = nullptr;       // N parents
+    double *d_log1p = nullptr;       // G
+    int32_t *d_num_genes = nullptr;  // N
+    double *d_logw = nullptr;        // N
+    void *d_pairs = nullptr;         // r1|r2|outA|outB
+    uint64_t pairs_cap = 0;
+    uint32_t lds_limit = 160 * 1024;
+};
+
+static int use_device(const ps_population *p)
+{
+    HIPCHK(hipSetDevice(p->device));
+    return PS_OK;
+}
+
+extern "C" void ps_population_destroy(ps_population *p)
+{
+    if (!p) return;
+    (void)hipSetDevice(p->device);
+    if (p->stream) (void)hipStreamSynchronize(p->stream);
+    void *ptrs[] = { p->state, p->G[0], p->G[1], p->I[0], p->I[1], p->Isnap, p->cnt, p->d_idx,
+                     p->d_log1p, p->d_num_genes, p->d_logw, p->d_pairs };
+    for (void *q : ptrs)
+        if (q) (void)hipFree(q);
+    if (p->stream) (void)hipStreamDestroy(p->stream);
+    delete p;
+}
+
+static int pop_create_impl(const ps_config *cfg, const uint8_t *init_vec, ps_population *p)
+{
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return ps_fail(PS_ERR_NO_DEVICE, "no HIP device is visible: libpansim_hip has no CPU path");
+    if (cfg->device >= 0) {
+        if (cfg->device >= ndev) return ps_fail(PS_ERR_INVALID, "device %d out of range", cfg->device);
+        p->device = cfg->device;
+    } else {
+        HIPCHK(hipGetDevice(&p->device));
+    }
+    PSCHK(use_device(p));
+    HIPCHK(hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking));
+    const uint64_t N = cfg->pop_size, C = cfg->ncols;
+    HIPCHK(hipMalloc(&p->d_idx, std::max<uint64_t>(N, 1) * sizeof(uint32_t)));
+    uint8_t *d_vec = nullptr;
+    HIPCHK(hipMalloc(&d_vec, std::max<uint64_t>(C, 1)));
+    if (C) HIPCHK(hipMemcpyAsync(d_vec, init_vec, C, hipMemcpyHostToDevice, p->stream));
+    if (cfg->core) {
+        p->pitch = (uint32_t)((N + 127) / 128 * 128);
+        p->cpr = p->pitch / 16;
+        HIPCHK(hipMalloc(&p->state, std::max<uint64_t>(C, 1) * p->pitch));
+        if (C) {
+            const uint64_t total = C * p->cpr;
+            const uint32_t blocks = (uint32_t)std::min<uint64_t>((total + 255) / 256, 65536);
+            core_init_kernel<<<blocks, 256, 0, p->stream>>>(p->state, d_vec, (uint32_t)N, p->pitch,
+                                                            (uint32_t)C);
+        }
+    } else {
+        p->d.N = (uint32_t)N;
+        p->d.G = (uint32_t)C;
+        p->d.W = (uint32_t)((N + 63) / 64);
+        p->d.GW = (uint32_t)((C + 63) / 64);
+        const uint64_t nG = std::max<uint64_t>((uint64_t)p->d.G * p->d.W, 1) * 8;
+        const uint64_t nI = std::max<uint64_t>((uint64_t)p->d.N * p->d.GW, 1) * 8;
+        for (int k = 0; k < 2; k++) {
+            HIPCHK(hipMalloc(&p->G[k], nG));
+            HIPCHK(hipMalloc(&p->I[k], nI));
+        }
+        HIPCHK(hipMalloc(&p->Isnap, nI));
+        HIPCHK(hipMalloc(&p->cnt, std::max<uint64_t>(N, 1) * PS_MAX_COMP * sizeof(uint32_t)));
+        HIPCHK(hipMalloc(&p->d_log1p, std::max<uint64_t>(C, 1) * sizeof(double)));
+        HIPCHK(hipMalloc(&p->d_num_genes, std::max<uint64_t>(N, 1) * sizeof(int32_t)));
+        HIPCHK(hipMalloc(&p->d_logw, std::max<uint64_t>(N, 1) * sizeof(double)));
+        const uint64_t total = (uint64_t)p->d.G * p->d.W + (uint64_t)p->d.N * p->d.GW;
+        if (total)
+            acc_init_kernel<<<(uint32_t)((total + 255) / 256), 256, 0, p->stream>>>(p->G[0], p->I[0],
+                                                                                d_vec, p->d);
+    }
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(p->stream));
+    HIPCHK(hipFree(d_vec));
+    return PS_OK;
+}
+
+extern "C" int ps_population_create(const ps_config *cfg, const uint8_t *init_vec, ps_population **out)
+{
+    if (!cfg || !out) return ps_fail(PS_ERR_INVALID, "null argument");
+    *out = nullptr;
+    if (cfg->pop_size < 1) return ps_fail(PS_ERR_INVALID, "pop_size must be >= 1");
+    if (cfg->pop_size > 0xFFFFFFFFull - 128 || cfg->global_cols > 0xFFFFFFFFull
+        || cfg->ncols > 0xFFFFFFFFull)
+        return ps_fail(PS_ERR_INVALID, "pop_size and column counts must fit 32 bits");
+    if (cfg->col_offset + cfg->ncols > cfg->global_cols)
+        return ps_fail(PS_ERR_INVALID, "column shard [%llu,%llu) exceeds global_cols %llu",
+                       (unsigned long long)cfg->col_offset,
+                       (unsigned long long)(cfg->col_offset + cfg->ncols),
+                       (unsigned long long)cfg->global_cols);
+    if (!cfg->core && (cfg->col_offset != 0 || cfg->ncols != cfg->global_cols))
+        return ps_fail(PS_ERR_INVALID, "the accessory matrix is replicated, not sharded");
+    if (cfg->ncols && !init_vec) return ps_fail(PS_ERR_INVALID, "init_vec is null");
+    ps_population *p = new ps_population();
+    p->cfg = *cfg;
+    const int rc = pop_create_impl(cfg, init_vec, p);
+    if (rc != PS_OK) {
+        const std::string keep = g_err;
+        ps_population_destroy(p);
+        g_err = keep;
+        return rc;
+    }
+    *out = p;
+    return PS_OK;
+}
+
+extern "C" int ps_init_vector(uint64_t seed, int core, uint64_t col_offset, uint64_t ncols,
+                              double avg_gene_freq, uint8_t *out)
+{
+    if (!out && ncols) return ps_fail(PS_ERR_INVALID, "null output");
+    for (uint64_t c = 0; c < ncols; c++) {
+        const uint64_t g = col_offset + c;
+        if (core)   // population.rs:201-204
+            out[c] = (uint8_t)(1u << (hs_u32(seed, PS_STREAM_INIT_CORE, 0, g) >> 30));
+        else        // population.rs:217-218
+            out[c] = hs_f64(seed, PS_STREAM_INIT_ACC, 0, g) < avg_gene_freq ? 1 : 0;
+    }
+    return PS_OK;
+}
+
+extern "C" int ps_sync(ps_population *p)
+{
+    if (!p) return ps_fail(PS_ERR_INVALID, "null handle");
+    PSCHK(use_device(p));
+    HIPCHK(hipStreamSynchronize(p->stream));
+    return PS_OK;
+}
+
+// ---------------------------------------------------------------------------
+// whole-matrix load / read (individual-major u8 at the boundary)
+// ---------------------------------------------------------------------------
+extern "C" int ps_load_matrix(ps_population *p, const uint8_t *rows)
+{
+    if (!p || !rows) return ps_fail(PS_ERR_INVALID, "null argument");
+    PSCHK(use_device(p));
+    const uint64_t N = p->cfg.pop_size, C = p->cfg.ncols;
+    if (N * C == 0) return PS_OK;
+    uint8_t *d_rows = nullptr;
+    HIPCHK(hipMalloc(&d_rows, N * C));
+    HIPCHK(hipMemcpyAsync(d_rows, rows, N * C, hipMemcpyHostToDevice, p->stream));
+    if (p->cfg.core) {
+        bool safe = true;
+        for (uint64_t k = 0; k < N * C; k++)
+            if (rows[k] > 15) { safe = false; break; }
+        p->nibble_safe = safe;
+        dim3 grid((uint32_t)((C + 63) / 64), (uint32_t)((p->pitch + 63) / 64));
+        core_transpose_kernel<true><<<grid, 256, 0, p->stream>>>(p->state, d_rows, (uint32_t)N,
+                                                                 p->pitch, C);
+    } else {
+        const uint64_t nI = (uint64_t)p->d.N * p->d.GW;
+        acc_pack_rows_kernel<<<(uint32_t)((nI + 255) / 256), 256, 0, p->stream>>>(d_rows, p->I[p->cur],
+                                                                              p->d);
+        dim3 grid(p->d.W, p->d.GW);
+        acc_i_to_g_kernel<<<grid, 64, 0, p->stream>>>(p->I[p->cur], p->G[p->cur], p->d);
+    }
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(p->stream));
+    HIPCHK(hipFree(d_rows));
+    return PS_OK;
+}
+
+extern "C" int ps_read_matrix(ps_population *p, uint8_t *rows)
+{
+    if (!p || !rows) return ps_fail(PS_ERR_INVALID, "null argument");
+    PSCHK(use_device(p));
+    const uint64_t N = p->cfg.pop_size, C = p->cfg.ncols;
+    if (N * C == 0) return PS_OK;
+    uint8_t *d_rows = nullptr;
+    HIPCHK(hipMalloc(&d_rows, N * C));
+    if (p->cfg.core) {
+        dim3 grid((uint32_t)((C + 63) / 64), (uint32_t)((N + 63) / 64));
+        core_transpose_kernel<false><<<grid, 256, 0, p->stream>>>(p->state, d_rows, (uint32_t)N,
+                                                                  p->pitch, C);
+    } else {
+        acc_unpack_rows_kernel<<<(uint32_t)((N * C + 255) / 256), 256, 0, p->stream>>>(
+            p->I[p->cur], d_rows, p->d);
+    }
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(rows, d_rows, N * C, hipMemcpyDeviceToHost, p->stream));
+    HIPCHK(hipStreamSynchronize(p->stream));
+    HIPCHK(hipFree(d_rows));
+    return PS_OK;
+}
+
+// ---------------------------------------------------------------------------
+// rates
+// ---------------------------------------------------------------------------
+extern "C" int ps_set_rates(ps_population *p, int n_comp, const double *lam_mut, const double *lam_rec,
+                            const uint64_t *comp_begin, const uint64_t *comp_end)
+{
+    if (!p) return ps_fail(PS_ERR_INVALID, "null handle");
+    if (n_comp < 0 || n_comp > PS_MAX_COMP) return ps_fail(PS_ERR_INVALID, "n_comp must be 0..2");
+    for (int c = 0; c < n_comp; c++) {
+        // statrs Poisson::new(lambda).unwrap() panics on lambda <= 0 or NaN; 0 is skipped
+        // before (population.rs:480, :558)
+        if (!(lam_mut[c] >= 0.0) || !(lam_rec[c] >= 0.0) || std::isinf(lam_mut[c]) || std::isinf(lam_rec[c]))
+            return ps_fail(PS_ERR_INVALID, "rates must be finite and >= 0");
+        if (comp_begin[c] > comp_end[c] || comp_end[c] > p->cfg.global_cols)
+            return ps_fail(PS_ERR_INVALID, "compartment range out of bounds");
+    }
+    if (p->cfg.core) {
+        if (n_comp != 1) return ps_fail(PS_ERR_INVALID, "the core matrix has one compartment (main.rs:276, :279)");
+        if (p->cfg.pop_size < 2 && lam_rec[0] > 0.0)
+            return ps_fail(PS_ERR_INVALID, "recombination needs pop_size >= 2 (population.rs:584 panics)");
+        make_core_plan(lam_mut[0], lam_rec[0], p->cfg.global_cols, &p->cplan);
+    } else {
+        p->aplan = ps_acc_plan{};
+        p->aplan.n_comp = n_comp;
+        for (int c = 0; c < n_comp; c++) {
+            if (p->cfg.pop_size < 2 && lam_rec[c] > 0.0)
+                return ps_fail(PS_ERR_INVALID, "recombination needs pop_size >= 2 (population.rs:584 panics)");
+            p->aplan.comp_begin[c] = (uint32_t)comp_begin[c];
+            p->aplan.comp_end[c] = (uint32_t)comp_end[c];
+            p->aplan.flip_thr[c] = acc_flip_threshold(lam_mut[c], comp_end[c] - comp_begin[c]);
+            p->aplan.lam_rec[c] = lam_rec[c];
+        }
+    }
+    p->rates_set = true;
+    return PS_OK;
+}
+
+// ---------------------------------------------------------------------------
+// core sweep launch
+// ---------------------------------------------------------------------------
+template <bool WAVE, bool GA, bool MU, bool HR>
+static int launch_core_sweep_t(ps_population *p, const core_sweep_args &a, hipStream_t st)
+{
+    const uint32_t block = WAVE ? 256u : 1024u;
+    const uint32_t rpb = WAVE ? block / 64u : 1u;
+    const uint32_t hrm_bytes = (a.cpr * 2u + 15u) & ~15u;
+    const uint32_t lds = rpb * (2u * a.pitch + hrm_bytes);
+    if (lds > p->lds_limit)
+        return ps_fail(PS_ERR_INVALID, "pop_size %u needs %u bytes of LDS per row (limit %u)", a.N, lds,
+                       p->lds_limit);
+    auto kern = core_sweep_kernel<WAVE, GA, MU, HR>;
+    if (lds > 64 * 1024)
+        HIPCHK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const uint32_t want = (a.rows + rpb - 1) / rpb;
+    const uint32_t cap = WAVE ? 256u * 8u : 256u * (lds > 80 * 1024 ? 1u : 2u);
+    const uint32_t grid = std::max(1u, std::min(want, cap));
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(block), lds, st, a);
+    HIPCHK(hipGetLastError());
+    return PS_OK;
+}
+
+static int launch_core_sweep(ps_population *p, const uint32_t *d_idx, uint32_t gen, bool ga, bool mu,
+                             bool hr, hipStream_t st)
+{
+    if (p->cfg.ncols == 0) return PS_OK;
+    core_sweep_args a;
+    a.state = p->state;
+    a.idx = d_idx;
+    a.N = (uint32_t)p->cfg.pop_size;
+    a.pitch = p->pitch;
+    a.cpr = p->cpr;
+    a.rows = (uint32_t)p->cfg.ncols;
+    a.site_offset = (uint32_t)p->cfg.col_offset;
+    a.gen = gen;
+    a.k0 = (uint32_t)p->cfg.seed;
+    a.k1 = (uint32_t)(p->cfg.seed >> 32);
+    a.plan = p->cplan;
+    if (!mu && !hr) a.plan.has_events = 0;
+    const bool wave = p->pitch <= 1024;
+#define PS_DISPATCH(W, G_, M_, H_) \
+    if (wave == W && ga == G_ && mu == M_ && hr == H_) return launch_core_sweep_t<W, G_, M_, H_>(p, a, st);
+    PS_DISPATCH(true, true, false, false)
+    PS_DISPATCH(true, false, true, false)
+    PS_DISPATCH(true, false, false, true)
+    PS_DISPATCH(true, true, true, false)
+    PS_DISPATCH(true, true, true, true)
+    PS_DISPATCH(false, true, false, false)
+    PS_DISPATCH(false, false, true, false)
+    PS_DISPATCH(false, false, false, true)
+    PS_DISPATCH(false, true, true, false)
+    PS_DISPATCH(false, true, true, true)
+#undef PS_DISPATCH
+    return ps_fail(PS_ERR_INVALID, "unsupported operator combination");
+}
+
+// ---------------------------------------------------------------------------
+// accessory step launches
+// ---------------------------------------------------------------------------
+static int launch_acc_step(ps_population *p, const uint32_t *d_idx, uint32_t gen, bool ga, bool mu,
+                           hipStream_t st)
+{
+    if (p->d.G == 0) return PS_OK;
+    acc_step_args a;
+    a.srcG = p->G[p->cur];
+    a.dstG = p->G[1 - p->cur];
+    a.dstI = p->I[1 - p->cur];
+    a.idx = d_idx;
+    a.d = p->d;
+    a.gen = gen;
+    a.k0 = (uint32_t)p->cfg.seed;
+    a.k1 = (uint32_t)(p->cfg.seed >> 32);
+    a.plan = p->aplan;
+    dim3 grid(p->d.W, p->d.GW);
+    if (ga && mu) acc_step_kernel<true, true><<<grid, 64, 0, st>>>(a);
+    else if (ga) acc_step_kernel<true, false><<<grid, 64, 0, st>>>(a);
+    else acc_step_kernel<false, true><<<grid, 64, 0, st>>>(a);
+    HIPCHK(hipGetLastError());
+    p->cur = 1 - p->cur;
+    return PS_OK;
+}
+
+static int launch_acc_hgt(ps_population *p, uint32_t gen, hipStream_t st)
+{
+    if (p->d.G == 0 || p->d.N < 2) return PS_OK;
+    bool any = false;
+    for (int c = 0; c < p->aplan.n_comp; c++) any |= p->aplan.lam_rec[c] != 0.0;
+    if (!any) return PS_OK;
+    const uint64_t nI = (uint64_t)p->d.N * p->d.GW * 8;
+    HIPCHK(hipMemcpyAsync(p->Isnap, p->I[p->cur], nI, hipMemcpyDeviceToDevice, st));
+    acc_comp_counts_kernel<<<(p->d.N + 255) / 256, 256, 0, st>>>(p->Isnap, p->cnt, p->d, p->aplan);
+    for (int c = 0; c < p->aplan.n_comp; c++) {
+        if (p->aplan.lam_rec[c] == 0.0) continue;      // population.rs:558
+        const uint64_t K = hs_poisson((double)p->d.N * p->aplan.lam_rec[c], p->cfg.seed,
+                                      PS_STREAM_HGT_COUNT | ((uint32_t)c << 8), gen);
+        if (K == 0) continue;
+        const uint32_t blocks = (uint32_t)std::min<uint64_t>((K + 255) / 256, 256 * 16);
+        acc_hgt_kernel<<<blocks, 256, 0, st>>>(p->Isnap, p->cnt, p->G[p->cur], p->I[p->cur], p->d,
+                                               p->aplan.comp_begin[c], p->aplan.comp_end[c], (uint32_t)c,
+                                               K, gen, (uint32_t)p->cfg.seed, (uint32_t)(p->cfg.seed >> 32));
+    }
+    HIPCHK(hipGetLastError());
+    return PS_OK;
+}
+
+static int upload_idx(ps_population *p, const uint32_t *sample)
+{
+    const uint64_t N = p->cfg.pop_size;
+    for (uint64_t i = 0; i < N; i++)
+        if (sample[i] >= N) return ps_fail(PS_ERR_INVALID, "parent index %u out of range", sample[i]);
+    HIPCHK(hipMemcpyAsync(p->d_idx, sample, N * sizeof(uint32_t), hipMemcpyHostToDevice, p->stream));
+    return PS_OK;
+}
+
+static int step_device(ps_population *p, const uint32_t *d_idx, uint32_t gen, bool ga, bool mu, bool hr,
+                       hipStream_t st)
+{
+    if (p->cfg.core) return launch_core_sweep(p, d_idx, gen, ga, mu, hr, st);
+    if (ga || mu) PSCHK(launch_acc_step(p, d_idx, gen, ga, mu, st));
+    if (hr) PSCHK(launch_acc_hgt(p, gen, st));
+    return PS_OK;
+}
+
+extern "C" int ps_next_generation(ps_population *p, const uint32_t *sample)
+{
+    if (!p || !sample) return ps_fail(PS_ERR_INVALID, "null argument");
+    PSCHK(use_device(p));
+    PSCHK(upload_idx(p, sample));
+    PSCHK(step_device(p, p->d_idx, 0, true, false, false, p->stream));
+    HIPCHK(hipStreamSynchronize(p->stream));
+    return PS_OK;
+}
+
+extern "C" int ps_mutate_alleles(ps_population *p, uint32_t generation)
+{
+    if (!p) return ps_fail(PS_ERR_INVALID, "null handle");
+    if (!p->rates_set) return ps_fail(PS_ERR_STATE, "ps_set_rates has not been called");
+    PSCHK(use_device(p));
+    PSCHK(step_device(p, nullptr, generation, false, true, false, p->stream));
+    HIPCHK(hipStreamSynchronize(p->stream));
+    return PS_OK;
+}
+
+extern "C" int ps_recombine(ps_population *p, uint32_t generation)
+{
+    if (!p) return ps_fail(PS_ERR_INVALID, "null handle");
+    if (!p->rates_set) return ps_fail(PS_ERR_STATE, "ps_set_rates has not been called");
+    PSCHK(use_device(p));
+    PSCHK(step_device(p, nullptr, generation, false, false, true, p->stream));
+    HIPCHK(hipStreamSynchronize(p->stream));
+    return PS_OK;
+}
+
+extern "C" int ps_step(ps_population *p, uint32_t generation, const uint32_t *sample, int do_recombine)
+{
+    if (!p || !sample) return ps_fail(PS_ERR_INVALID, "null argument");
+    if (!p->rates_set) return ps_fail(PS_ERR_STATE, "ps_set_rates has not been called");
+    PSCHK(use_device(p));
+    PSCHK(upload_idx(p, sample));
+    PSCHK(step_device(p, p->d_idx, generation, true, true, do_recombine != 0, p->stream));
+    HIPCHK(hipStreamSynchronize(p->stream));
+    return PS_OK;
+}
+
+// ---------------------------------------------------------------------------
+// parent sampling (population.rs:270-448)
+// ---------------------------------------------------------------------------
+static int fitness_terms_device(ps_population *acc, const double *sel, int32_t *num_genes, double *logw,
+                                hipStream_t st)
+{
+    const uint64_t N = acc->cfg.pop_size, G = acc->cfg.ncols;
+    int need = 0;
+    if (G) {
+        std::vector<double> l1p(G);
+        for (uint64_t g = 0; g < G; g++) {
+            l1p[g] = std::log(1.0 + sel[g] * 1.0);           // population.rs:306 with col_val = 1
+            if (l1p[g] != 0.0) need = 1;
+            if (std::isnan(l1p[g])) need = 1;
+        }
+        if (need)
+            HIPCHK(hipMemcpyAsync(acc->d_log1p, l1p.data(), G * sizeof(double), hipMemcpyHostToDevice, st));
+        // l1p must outlive the async copy: pageable memcpy is staged before return
+        HIPCHK(hipStreamSynchronize(st));
+    }
+    acc_fitness_kernel<<<(uint32_t)((N + 255) / 256), 256, 0, st>>>(acc->I[acc->cur], acc->d_log1p, need,
+                                                                 acc->d_num_genes, acc->d_logw, acc->d);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(num_genes, acc->d_num_genes, N * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(logw, acc->d_logw, N * sizeof(double), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    return PS_OK;
+}
+
+extern "C" int ps_fitness_terms(ps_population *acc, const double *sel, int32_t *num_genes, double *logw)
+{
+    if (!acc || !num_genes || !logw) return ps_fail(PS_ERR_INVALID, "null argument");
+    if (acc->cfg.core) return ps_fail(PS_ERR_INVALID, "sample_indices runs on the accessory matrix (main.rs:442)");
+    if (acc->cfg.ncols && !sel) return ps_fail(PS_ERR_INVALID, "null selection coefficients");
+    PSCHK(use_device(acc));
+    return fitness_terms_device(acc, sel, num_genes, logw, acc->stream);
+}
+
+// logsumexp 0.1 `ln_sum_exp` in its one-pass streaming form
+static double ln_sum_exp(const double *x, uint64_t n)
+{
+    double alpha = -INFINITY, r = 0.0;
+    for (uint64_t i = 0; i < n; i++) {
+        if (x[i] <= alpha) r += std::exp(x[i] - alpha);
+        else { r *= std::exp(alpha - x[i]); r += 1.0; alpha = x[i]; }
+    }
+    return std::log(r) + alpha;
+}
+static void softmax_norm(double *v, uint64_t n)
+{
+    const double lse = ln_sum_exp(v, n);
+    for (uint64_t i = 0; i < n; i++) v[i] = std::exp(v[i] - lse);
+    double sum = 0.0;
+    for (uint64_t i = 0; i < n; i++) sum += v[i];
+    for (uint64_t i = 0; i < n; i++) v[i] = (v[i] != -INFINITY) ? v[i] / sum : 0.0;
+}
+
+extern "C" int ps_sample_weights(const int32_t *num_genes, const double *logw, uint64_t n, uint64_t n_genes,
+                                 int32_t avg_gene_num, const double *avg_pairwise_dists,
+                                 int no_control_genome_size, double genome_size_penalty,
+                                 double competition_strength, double *weights)
+{
+    if (!num_genes || !logw || !avg_pairwise_dists || !weights || n == 0)
+        return ps_fail(PS_ERR_INVALID, "null argument");
+    std::vector<double> sel(n, 1.0), tmp(n);                       // population.rs:293
+    if (n_genes > 0) {                                             // :296
+        for (uint64_t i = 0; i < n; i++) sel[i] = logw[i];
+        softmax_norm(sel.data(), n);                               // :325-340
+    }
+    if (!no_control_genome_size) {                                 // :346
+        const double lp = std::log(genome_size_penalty);
+        for (uint64_t i = 0; i < n; i++) tmp[i] = (double)(num_genes[i] - avg_gene_num) * lp; // :350-355
+        softmax_norm(tmp.data(), n);                               // :356-361
+        for (uint64_t i = 0; i < n; i++) weights[i] = tmp[i] * sel[i]; // :368
+    } else {
+        for (uint64_t i = 0; i < n; i++) weights[i] = sel[i];      // :371
+    }
+    for (uint64_t i = 0; i < n; i++) tmp[i] = competition_strength * std::log(avg_pairwise_dists[i]); // :375
+    softmax_norm(tmp.data(), n);                                   // :377-382
+    for (uint64_t i = 0; i < n; i++) weights[i] = weights[i] * tmp[i]; // :389-393
+    double mx = -INFINITY;
+    for (uint64_t i = 0; i < n; i++) mx = std::fmax(mx, weights[i]); // :403
+    if (mx == 0.0)
+        for (uint64_t i = 0; i < n; i++) weights[i] = 1.0;         // :435-437
+    double total = 0.0;                                            // WeightedIndex::new, :440
+    for (uint64_t i = 0; i < n; i++) {
+        if (!(weights[i] >= 0.0))
+            return ps_fail(PS_ERR_WEIGHTS, "invalid sampling weight %g at %llu (reference panics, population.rs:440)",
+                           weights[i], (unsigned long long)i);
+        total += weights[i];
+    }
+    if (!(total > 0.0) || std::isinf(total))
+        return ps_fail(PS_ERR_WEIGHTS, "sampling weights sum to %g (reference panics, population.rs:440)", total);
+    return PS_OK;
+}
+
+extern "C" int ps_draw_parents(const double *weights, uint64_t n, uint64_t seed, uint32_t generation,
+                               uint32_t *out_idx)
+{
+    if (!weights || !out_idx || n == 0) return ps_fail(PS_ERR_INVALID, "null argument");
+    std::vector<double> cum(n);
+    double total = weights[0];
+    for (uint64_t i = 1; i < n; i++) { cum[i - 1] = total; total += weights[i]; }
+    for (uint64_t k = 0; k < n; k++) {
+        const double x = hs_f64(seed, PS_STREAM_PARENTS, generation, k) * total;
+        out_idx[k] = (uint32_t)(std::upper_bound(cum.begin(), cum.begin() + (n - 1), x) - cum.begin());
+    }
+    return PS_OK;
+}
+
+extern "C" int ps_sample_indices(ps_population *acc, uint32_t generation, int32_t avg_gene_num,
+                                 const double *avg_pairwise_dists, const double *sel, int verbose,
+                                 int no_control_genome_size, double genome_size_penalty,
+                                 double competition_strength, uint32_t *out_idx)
+{
+    (void)verbose;
+    if (!acc || !out_idx || !avg_pairwise_dists) return ps_fail(PS_ERR_INVALID, "null argument");
+    const uint64_t N = acc->cfg.pop_size;
+    std::vector<int32_t> ng(N);
+    std::vector<double> lw(N), w(N);
+    PSCHK(ps_fitness_terms(acc, sel, ng.data(), lw.data()));
+    PSCHK(ps_sample_weights(ng.data(), lw.data(), N, acc->cfg.ncols, avg_gene_num, avg_pairwise_dists,
+                            no_control_genome_size, genome_size_penalty, competition_strength, w.data()));
+    return ps_draw_parents(w.data(), N, acc->cfg.seed, generation, out_idx);
+}
+
+// ---------------------------------------------------------------------------
+// distances
+// ---------------------------------------------------------------------------
+static int ensure_pairs(ps_population *p, uint64_t P)
+{
+    if (P <= p->pairs_cap) return PS_OK;
+    if (p->d_pairs) HIPCHK(hipFree(p->d_pairs));
+    p->d_pairs = nullptr;
+    p->pairs_cap = 0;
+    HIPCHK(hipMalloc(&p->d_pairs, P * 4 * sizeof(uint32_t)));
+    p->pairs_cap = P;
+    return PS_OK;
+}
+
+static int pair_counts_device(ps_population *p, uint64_t P, const uint32_t *d_r1, const uint32_t *d_r2,
+                              uint32_t *d_a, uint32_t *d_b, hipStream_t st)
+{
+    const uint32_t N = (uint32_t)p->cfg.pop_size;
+    if (p->cfg.core) {
+        HIPCHK(hipMemsetAsync(d_a, 0, P * sizeof(uint32_t), st));
+        const uint32_t rows = (uint32_t)p->cfg.ncols;
+        if (rows == 0) return PS_OK;
+        // tiled kernel: LDS holds N * (W+4) dwords
+        uint32_t W = 0;
+        for (uint32_t w : { 32u, 16u, 8u, 4u })
+            if ((uint64_t)N * (w + 4) * 4 <= p->lds_limit) { W = w; break; }
+        if (p->nibble_safe && W) {
+            constexpr int A = 32;
+            const uint32_t lds = N * (W + 4) * 4;
+            auto kern = core_pair_counts_tiled<A>;
+            if (lds > 64 * 1024)
+                HIPCHK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            const uint32_t n_tiles = (rows + W * 8 - 1) / (W * 8);
+            const uint32_t pair_blocks = (uint32_t)((P + 1024ull * A - 1) / (1024ull * A));
+            // enough site ranges to fill the chip a few times over
+            uint32_t ranges = std::max(1u, std::min(n_tiles, (256u * 4u + pair_blocks - 1) / pair_blocks));
+            const uint32_t tpr = (n_tiles + ranges - 1) / ranges;
+            ranges = (n_tiles + tpr - 1) / tpr;
+            hipLaunchKernelGGL(kern, dim3(ranges, pair_blocks), dim3(1024), lds, st, p->state, N, p->pitch,
+                               rows, d_r1, d_r2, P, d_a, W, tpr);
+        } else {
+            const uint32_t slices = std::max(1u, std::min(rows, 64u));
+            const uint32_t rps = (rows + slices - 1) / slices;
+            dim3 grid((uint32_t)((P + 255) / 256), (rows + rps - 1) / rps);
+            core_pair_counts_simple<<<grid, 256, 0, st>>>(p->state, p->pitch, rows, d_r1, d_r2, P, d_a, rps);
+        }
+    } else {
+        acc_pair_counts_kernel<<<(uint32_t)((P + 255) / 256), 256, 0, st>>>(p->I[p->cur], d_r1, d_r2, P,
+                                                                         d_a, d_b, p->d);
+    }
+    HIPCHK(hipGetLastError());
+    return PS_OK;
+}
+
+extern "C" int ps_pairwise_counts(ps_population *p, uint64_t P, const uint32_t *range1, const uint32_t *range2,
+                                  uint32_t *out_a, uint32_t *out_b, int out_is_device)
+{
+    if (!p || !range1 || !range2 || !out_a) return ps_fail(PS_ERR_INVALID, "null argument");
+    if (!p->cfg.core && !out_b) return ps_fail(PS_ERR_INVALID, "out_b is required for the accessory matrix");
+    if (P == 0) return PS_OK;
+    const uint64_t N = p->cfg.pop_size;
+    for (uint64_t k = 0; k < P; k++)
+        if (range1[k] >= N || range2[k] >= N)
+            return ps_fail(PS_ERR_INVALID, "pair %llu out of range", (unsigned long long)k);
+    PSCHK(use_device(p));
+    PSCHK(ensure_pairs(p, P));
+    uint32_t *d_r1 = (uint32_t *)p->d_pairs, *d_r2 = d_r1 + P, *d_a = d_r2 + P, *d_b = d_a + P;
+    HIPCHK(hipMemcpyAsync(d_r1, range1, P * 4, hipMemcpyHostToDevice, p->stream));
+    HIPCHK(hipMemcpyAsync(d_r2, range2, P * 4, hipMemcpyHostToDevice, p->stream));
+    uint32_t *ka = out_is_device ? out_a : d_a;
+    uint32_t *kb = out_is_device ? out_b : d_b;
+    PSCHK(pair_counts_device(p, P, d_r1, d_r2, ka, kb, p->stream));
+    if (!out_is_device) {
+        HIPCHK(hipMemcpyAsync(out_a, d_a, P * 4, hipMemcpyDeviceToHost, p->stream));
+        if (!p->cfg.core) HIPCHK(hipMemcpyAsync(out_b, d_b, P * 4, hipMemcpyDeviceToHost, p->stream));
+    }
+    HIPCHK(hipStreamSynchronize(p->stream));
+    return PS_OK;
+}
+
+extern "C" int ps_pairwise_distances(ps_population *p, uint64_t P, const uint32_t *range1,
+                                     const uint32_t *range2, double *out)
+{
+    if (!p || !out) return ps_fail(PS_ERR_INVALID, "null argument");
+    std::vector<uint32_t> a(P), b(P);
+    PSCHK(ps_pairwise_counts(p, P, range1, range2, a.data(), b.data(), 0));
+    const double ncols = (double)p->cfg.ncols, cg = (double)p->cfg.core_genes;
+    for (uint64_t k = 0; k < P; k++) {
+        if (p->cfg.core) {
+            const uint32_t distance = a[k] / 2;                      // population.rs:817
+            out[k] = (double)distance / ncols;                       // :822
+        } else {
+            out[k] = 1.0 - (((double)a[k] + cg) / ((double)b[k] + cg)); // :828-830
+        }
+    }
+    return PS_OK;
+}
+
+extern "C" int ps_average_distance(ps_population *p, double *out)
+{
+    if (!p || !out) return ps_fail(PS_ERR_INVALID, "null argument");
+    if (p->cfg.core)
+        return ps_fail(PS_ERR_INVALID, "average_distance is only reached on the accessory matrix (main.rs:439)");
+    if (p->cfg.pop_size < 2) return ps_fail(PS_ERR_INVALID, "average_distance needs pop_size >= 2");
+    PSCHK(use_device(p));
+    double *d_out = nullptr;
+    const uint64_t N = p->cfg.pop_size;
+    HIPCHK(hipMalloc(&d_out, N * sizeof(double)));
+    acc_average_distance_kernel<<<(uint32_t)((N + 63) / 64), 64, 0, p->stream>>>(p->I[p->cur], d_out, p->d,
+                                                                              (double)p->cfg.core_genes);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(out, d_out, N * sizeof(double), hipMemcpyDeviceToHost, p->stream));
+    HIPCHK(hipStreamSynchronize(p->stream));
+    HIPCHK(hipFree(d_out));
+    return PS_OK;
+}
+
+extern "C" int ps_gene_frequencies(ps_population *p, double *out)
+{
+    if (!p || !out) return ps_fail(PS_ERR_INVALID, "null argument");
+    if (p->cfg.core) return ps_fail(PS_ERR_INVALID, "gene_frequencies runs on the accessory matrix (main.rs:492)");
+    PSCHK(use_device(p));
+    const uint64_t G = p->cfg.ncols;
+    if (G) {
+        uint32_t *d_c = nullptr;
+        HIPCHK(hipMalloc(&d_c, G * sizeof(uint32_t)));
+        acc_gene_counts_kernel<<<(uint32_t)((G + 255) / 256), 256, 0, p->stream>>>(p->G[p->cur], d_c, p->d);
+        HIPCHK(hipGetLastError());
+        std::vector<uint32_t> c(G);
+        HIPCHK(hipMemcpyAsync(c.data(), d_c, G * 4, hipMemcpyDeviceToHost, p->stream));
+        HIPCHK(hipStreamSynchronize(p->stream));
+        HIPCHK(hipFree(d_c));
+        const double n_individuals = (double)p->cfg.pop_size;      // population.rs:843
+        for (uint64_t g = 0; g < G; g++) out[g] = (double)c[g] / n_individuals; // :852
+    }
+    for (uint64_t k = 0; k < p->cfg.core_genes; k++) out[G + k] = 1.0;  // :858-860
+    return PS_OK;
+}
+
+extern "C" int ps_calc_gene_freq(ps_population *p, double *out)
+{
+    if (!p || !out) return ps_fail(PS_ERR_INVALID, "null argument");
+    if (p->cfg.core) return ps_fail(PS_ERR_INVALID, "calc_gene_freq runs on the accessory matrix (main.rs:524)");
+    const uint64_t N = p->cfg.pop_size, G = p->cfg.ncols;
+    std::vector<int32_t> ng(N);
+    std::vector<double> lw(N);
+    std::vector<double> zero(G, 0.0);
+    PSCHK(ps_fitness_terms(p, zero.data(), ng.data(), lw.data()));
+    double sum = 0.0;
+    for (uint64_t i = 0; i < N; i++) sum += (double)ng[i] / (double)G;  // population.rs:250-252
+    *out = sum / (double)N;                                             // :265
+    return PS_OK;
+}
+
+// ---------------------------------------------------------------------------
+// free functions
+// ---------------------------------------------------------------------------
+static int slice_counts(const uint8_t *x, const uint8_t *y, size_t n, uint32_t out[3])
+{
+    out[0] = out[1] = out[2] = 0;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return ps_fail(PS_ERR_NO_DEVICE, "no HIP device is visible: libpansim_hip has no CPU path");
+    if (n == 0) return PS_OK;
+    if (!x || !y) return ps_fail(PS_ERR_INVALID, "null slice");
+    uint8_t *d = nullptr;
+    uint32_t *d_out = nullptr;
+    HIPCHK(hipMalloc(&d, 2 * n));
+    HIPCHK(hipMalloc(&d_out, 3 * sizeof(uint32_t)));
+    HIPCHK(hipMemcpy(d, x, n, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(d + n, y, n, hipMemcpyHostToDevice));
+    HIPCHK(hipMemset(d_out, 0, 3 * sizeof(uint32_t)));
+    const uint32_t blocks = (uint32_t)std::min<uint64_t>((n + 255) / 256, 2048);
+    slice_counts_kernel<<<blocks, 256>>>(d, d + n, n, d_out);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpy(out, d_out, 3 * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    HIPCHK(hipFree(d));
+    HIPCHK(hipFree(d_out));
+    return PS_OK;
+}
+
+extern "C" int ps_hamming_bitwise_fast(const uint8_t *x, const uint8_t *y, size_t n, uint32_t *out)
+{
+    if (!out) return ps_fail(PS_ERR_INVALID, "null output");
+    uint32_t c[3];
+    PSCHK(slice_counts(x, y, n, c));
+    *out = c[0];
+    return PS_OK;
+}
+
+extern "C" int ps_jaccard_distance_fast(const uint8_t *x, const uint8_t *y, size_t n, uint32_t *inter,
+                                        uint32_t *uni)
+{
+    if (!inter || !uni) return ps_fail(PS_ERR_INVALID, "null output");
+    uint32_t c[3];
+    PSCHK(slice_counts(x, y, n, c));
+    *inter = c[1];
+    *uni = c[2];
+    return PS_OK;
+}
+
+extern "C" int ps_standard_deviation(const double *v, uint64_t n, double *std_out, double *mean_out)
+{
+    if (!v || !std_out || !mean_out) return ps_fail(PS_ERR_INVALID, "null argument");
+    double s = 0.0;
+    for (uint64_t i = 0; i < n; i++) s += v[i];                     // population.rs:84
+    const double mean = s / (double)n;
+    double ss = 0.0;
+    for (uint64_t i = 0; i < n; i++) { const double dd = v[i] - mean; ss += dd * dd; } // :90
+    *std_out = std::sqrt(ss / (double)n);                           // :92-93
+    *mean_out = mean;
+    return PS_OK;
+}
+
+extern "C" char ps_int_to_base(uint8_t n)
+{
+    switch (n) {                                                    // population.rs:154-162
+    case 1: return 'A';
+    case 2: return 'C';
+    case 4: return 'G';
+    case 8: return 'T';
+    default: return 'N';
+    }
+}
+
+// Rust `{}` for f64: shortest round-trip digits, positional notation, no ".0"
+static std::string fmt_f64(double v)
+{
+    if (std::isnan(v)) return "NaN";
+    if (std::isinf(v)) return v < 0 ? "-inf" : "inf";
+    if (v == 0.0) return std::signbit(v) ? "-0" : "0";
+    char tmp[64];
+    auto r = std::to_chars(tmp, tmp + sizeof tmp, v, std::chars_format::scientific);
+    std::string s(tmp, r.ptr);
+    bool neg = false;
+    size_t pos = 0;
+    if (s[0] == '-') { neg = true; pos = 1; }
+    const size_t epos = s.find('e');
+    std::string digits;
+    for (size_t k = pos; k < epos; k++)
+        if (s[k] != '.') digits.push_back(s[k]);
+    const int e10 = std::atoi(s.c_str() + epos + 1);
+    const int nd = (int)digits.size();
+    std::string out = neg ? "-" : "";
+    if (e10 >= nd - 1) {
+        out += digits;
+        out.append((size_t)(e10 - (nd - 1)), '0');
+    } else if (e10 >= 0) {
+        out += digits.substr(0, (size_t)e10 + 1);
+        out.push_back('.');
+        out += digits.substr((size_t)e10 + 1);
+    } else {
+        out += "0.";
+        out.append((size_t)(-e10 - 1), '0');
+        out += digits;
+    }
+    return out;
+}
+
+extern "C" int ps_fmt_f64(double v, char *buf, size_t cap)
+{
+    if (!buf || cap == 0) return ps_fail(PS_ERR_INVALID, "null buffer");
+    const std::string s = fmt_f64(v);
+    if (s.size() + 1 > cap) return ps_fail(PS_ERR_INVALID, "buffer too small");
+    memcpy(buf, s.c_str(), s.size() + 1);
+    return (int)s.size();
+}
+
+// Population::write (population.rs:865-897)
+extern "C" int ps_write(ps_population *p, const char *outpref)
+{
+    if (!p || !outpref) return ps_fail(PS_ERR_INVALID, "null argument");
+    const uint64_t N = p->cfg.pop_size, C = p->cfg.ncols;
+    std::vector<uint8_t> rows(std::max<uint64_t>(N * C, 1));
+    PSCHK(ps_read_matrix(p, rows.data()));
+    const std::string path = std::string(outpref) + (p->cfg.core ? "_core_genome.csv" : "_pangenome.csv");
+    FILE *f = fopen(path.c_str(), "w");
+    if (!f) return ps_fail(PS_ERR_IO, "cannot create %s", path.c_str());
+    std::string line;
+    for (uint64_t i = 0; i < N; i++) {
+        line.clear();
+        const uint8_t *row = rows.data() + i * C;
+        if (p->cfg.core) {
+            line.reserve(2 * C + 1);
+            for (uint64_t s = 0; s < C; s++) {
+                if (s) line.push_back(',');
+                line.push_back(ps_int_to_base(row[s]));
+            }
+        } else {
+            bool first = true;
+            for (uint64_t k = 0; k < p->cfg.core_genes; k++) {
+                if (!first) line.push_back(',');
+                line.push_back('1');
+                first = false;
+            }
+            for (uint64_t g = 0; g < C; g++) {
+                if (!first) line.push_back(',');
+                line += std::to_string((unsigned)row[g]);
+                first = false;
+            }
+        }
+        line.push_back('\n');
+        if (fwrite(line.data(), 1, line.size(), f) != line.size()) {
+            fclose(f);
+            return ps_fail(PS_ERR_IO, "short write to %s", path.c_str());
+        }
+    }
+    fclose(f);
+    return PS_OK;
+}
+
+// ---------------------------------------------------------------------------
+// main() as a library (main.rs:155-553)
+// ---------------------------------------------------------------------------
+extern "C" void ps_sim_default_params(ps_sim_params *p)
+{
+    memset(p, 0, sizeof(*p));
+    p->pop_size = 1000; p->core_size = 1200000; p->pan_genes = 6000; p->core_genes = 2000;
+    p->avg_gene_freq = 0.5; p->HR_rate = 0.05; p->HGT_rate = 0.05; p->n_gen = 100;
+    p->max_distances = 100000; p->core_mu = 0.05; p->rate_genes1 = 1.0; p->rate_genes2 = 1000.0;
+    p->prop_genes2 = 0.1; p->prop_positive = -0.1; p->pos_lambda = 10.0; p->neg_lambda = 10.0;
+    p->seed = 0; p->genome_size_penalty = 0.99; p->competition_strength = 0.0;
+    p->shard_rank = 0; p->shard_count = 1; p->device = -1;
+}
+
+extern "C" int ps_sim_validate(const ps_sim_params *p, char *msg, size_t cap)
+{
+    std::string m;
+    auto f = [](double v) { return fmt_f64(v); };
+    if (p->core_genes > p->pan_genes) {                              // main.rs:195-198
+        m = "core_genes must be less than or equal to pan_size\n";
+    } else if (p->HR_rate < 0.0 || p->HGT_rate < 0.0) {              // :200-205
+        m = "HR_rate and HGT_rate must be above 0.0\nHR_rate: " + f(p->HR_rate) + "\nHGT_rate: " + f(p->HGT_rate) + "\n";
+    } else if (p->pos_lambda <= 0.0 || p->neg_lambda <= 0.0) {       // :207-212
+        m = "pos_lambda and neg_lambda must be above 0.0\npos_lambda: " + f(p->pos_lambda) + "\nneg_lambda: "
+            + f(p->neg_lambda) + "\n";
+    } else if (p->rate_genes1 < 0.0 || p->rate_genes2 < 0.0) {       // :214-219
+        m = "rate_genes1 and rate_genes2 must be >= 0\nrate_genes1: " + f(p->rate_genes1) + "\nrate_genes2: "
+            + f(p->rate_genes2) + "\n";
+    } else if (p->prop_genes2 < 0.0 || p->prop_genes2 > 1.0) {       // :221-225
+        m = "prop_genes2 must be 0.0 <= prop_genes2 <= 1.0\nprop_genes2: " + f(p->prop_genes2) + "\n";
+    } else if (p->pop_size < 1 || p->core_size < 1 || p->pan_genes < 1 || p->n_gen < 1
+               || p->max_distances < 1) {                            // :227-235
+        m = "pop_size, core_size, pan_genes, n_gen and max_distances must all be above 1\npop_size: "
+            + std::to_string(p->pop_size) + "\ncore_size: " + std::to_string(p->core_size) + "\npan_genes: "
+            + std::to_string(p->pan_genes) + "\nn_gen: " + std::to_string(p->n_gen) + "\nmax_distances: "
+            + std::to_string(p->max_distances) + "\n";
+    } else if (p->core_mu < 0.0 || p->core_mu > 1.0) {               // :237-241
+        m = "core_mu must be between 0.0 and 1.0\ncore_mu: " + f(p->core_mu) + "\n";
+    } else if (p->avg_gene_freq <= 0.0 || p->avg_gene_freq > 1.0) {  // :243-247
+        m = "avg_gene_freq must be above 0.0 and below or equal to 1.0\navg_gene_freq: " + f(p->avg_gene_freq) + "\n";
+    }
+    if (msg && cap) {
+        const size_t n = std::min(cap - 1, m.size());
+        memcpy(msg, m.data(), n);
+        msg[n] = 0;
+    }
+    return m.empty() ? PS_OK : PS_ERR_INVALID;
+}
+
+extern "C" int ps_sim_derive(const ps_sim_params *p, ps_derived *d)
+{
+    if (!p || !d) return ps_fail(PS_ERR_INVALID, "null argument");
+    memset(d, 0, sizeof(*d));
+    if (p->core_genes > p->pan_genes || p->pan_genes == 0) return ps_fail(PS_ERR_INVALID, "core_genes > pan_genes");
+    const uint64_t pan_size = p->pan_genes - p->core_genes;          // main.rs:259
+    d->pan_size = pan_size;
+    const double core_prop = (double)p->core_genes / (double)p->pan_genes; // :263
+    const double acc_prop = 1.0 - core_prop;                         // :264
+    double agf = (p->avg_gene_freq - core_prop) / acc_prop;          // :265
+    if (agf < 0.0) agf = 0.0;                                        // :266-268
+    d->avg_gene_freq_adj = agf;
+    d->avg_gene_num = (int32_t)std::round(agf * (double)pan_size);   // :272
+    d->n_core_mutations = std::ceil((double)p->core_size * p->core_mu); // :275-276
+    d->n_recombinations_core = std::round(d->n_core_mutations * p->HR_rate); // :279
+    d->n_recombinations_pan_total = std::round(d->n_core_mutations * p->HGT_rate); // :280
+    const uint64_t g1 = (uint64_t)std::round((double)pan_size * (1.0 - p->prop_genes2)); // :334
+    const uint64_t g2 = pan_size - g1;                               // :335
+    const double prop1 = (double)g1 / (double)pan_size;              // :336
+    const double prop2 = 1.0 - prop1;                                // :337
+    int c = 0;
+    if (g1 > 0) {                                                    // :341-352
+        d->comp_begin[c] = 0; d->comp_end[c] = g1;
+        d->n_pan_mutations[c] = p->rate_genes1 * (double)g1;
+        d->n_recombinations_pan[c] = d->n_recombinations_pan_total * prop1;
+        c++;
+    }
+    if (g1 < pan_size) {                                             // :355-367
+        d->comp_begin[c] = g1; d->comp_end[c] = pan_size;
+        d->n_pan_mutations[c] = p->rate_genes2 * (double)g2;
+        d->n_recombinations_pan[c] = d->n_recombinations_pan_total * prop2;
+        c++;
+    }
+    d->n_comp = c;
+    return PS_OK;
+}
+
+extern "C" int ps_selection_coefficients(uint64_t seed, uint64_t G, double prop_positive, double pos_lambda,
+                                         double neg_lambda, double *out)
+{
+    if (!out && G) return ps_fail(PS_ERR_INVALID, "null output");
+    for (uint64_t g = 0; g < G; g++) out[g] = 0.0;                   // main.rs:287
+    if (!(prop_positive >= 0.0)) return PS_OK;                       // :292
+    uint64_t n = 0;
+    for (uint64_t g = 0; g < G; g++) {
+        const double weight = hs_f64(seed, PS_STREAM_SELECTION, 0, n++);
+        double s;
+        if (weight <= prop_positive) {                               // :303
+            s = -std::log(1.0 - hs_f64(seed, PS_STREAM_SELECTION, 0, n++)) / pos_lambda;
+        } else {
+            s = -std::log(1.0 - hs_f64(seed, PS_STREAM_SELECTION, 0, n++)) / neg_lambda;
+            while (s > 1.0)                                          // :309-311
+                s = -std::log(1.0 - hs_f64(seed, PS_STREAM_SELECTION, 0, n++)) / neg_lambda;
+            s = -1.0 * s;                                            // :315
+        }
+        out[g] = s;
+    }
+    return PS_OK;
+}
+
+extern "C" int ps_sample_pairs(uint64_t seed, uint64_t N, uint64_t P, uint32_t *range1, uint32_t *range2)
+{
+    if (!range1 || !range2) return ps_fail(PS_ERR_INVALID, "null output");
+    if (N < 2) return ps_fail(PS_ERR_INVALID, "pair sampling needs pop_size >= 2 (main.rs:421 panics)");
+    for (uint64_t k = 0; k < P; k++)                                 // main.rs:413-415
+        range1[k] = ps_mulhi(hs_u32(seed, PS_STREAM_PAIRS, 0, k), (uint32_t)N);
+    for (uint64_t k = 0; k < P; k++) {                               // :420-427
+        uint32_t e = ps_mulhi(hs_u32(seed, PS_STREAM_PAIRS, 1, k), (uint32_t)(N - 1));
+        if (e >= range1[k]) e += 1;
+        range2[k] = e;
+    }
+    return PS_OK;
+}
+
+// ---------------------------------------------------------------------------
+// generation loop (main.rs:429-464)
+// ---------------------------------------------------------------------------
+#define PS_RING 4
+struct ps_sim {
+    ps_sim_params prm{};
+    ps_derived der{};
+    ps_population *core = nullptr, *acc = nullptr;
+    std::vector<double> sel;
+    std::vector<uint32_t> r1, r2, last_idx;
+    // ring of parent-index slots so that the accessory chain (and the host) can run
+    // ahead of the long core sweep
+    uint32_t *d_idx[PS_RING] = {};
+    uint32_t *h_idx[PS_RING] = {};         // pinned
+    hipEvent_t ev_idx[PS_RING] = {}, ev_core[PS_RING] = {};
+    bool slot_used[PS_RING] = {};
+    int32_t *h_num_genes = nullptr;        // pinned
+    double *h_logw = nullptr, *h_avg = nullptr;
+    double *d_avg = nullptr;
+    uint64_t step_count = 0;
+    bool need_logw = false;
+    // sweep timing
+    bool timing = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> tev;
+    std::vector<hipEvent_t> ev_pool;
+};
+
+extern "C" void ps_sim_destroy(ps_sim *s)
+{
+    if (!s) return;
+    if (s->core) (void)hipSetDevice(s->core->device);
+    if (s->core) (void)hipStreamSynchronize(s->core->stream);
+    if (s->acc) (void)hipStreamSynchronize(s->acc->stream);
+    for (int k = 0; k < PS_RING; k++) {
+        if (s->d_idx[k]) (void)hipFree(s->d_idx[k]);
+        if (s->h_idx[k]) (void)hipHostFree(s->h_idx[k]);
+        if (s->ev_idx[k]) (void)hipEventDestroy(s->ev_idx[k]);
+        if (s->ev_core[k]) (void)hipEventDestroy(s->ev_core[k]);
+    }
+    if (s->h_num_genes) (void)hipHostFree(s->h_num_genes);
+    if (s->h_logw) (void)hipHostFree(s->h_logw);
+    if (s->h_avg) (void)hipHostFree(s->h_avg);
+    if (s->d_avg) (void)hipFree(s->d_avg);
+    for (auto &pr : s->tev) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
+    for (auto e : s->ev_pool) (void)hipEventDestroy(e);
+    ps_population_destroy(s->core);
+    ps_population_destroy(s->acc);
+    delete s;
+}
+
+static int sim_create_impl(const ps_sim_params *p, ps_sim *s)
+{
+    char msg[1024];
+    if (ps_sim_validate(p, msg, sizeof msg) != PS_OK) return ps_fail(PS_ERR_INVALID, "%s", msg);
+    if (p->shard_count < 1 || p->shard_rank < 0 || p->shard_rank >= p->shard_count)
+        return ps_fail(PS_ERR_INVALID, "bad shard %d of %d", p->shard_rank, p->shard_count);
+    if (p->pop_size < 2) return ps_fail(PS_ERR_INVALID, "pop_size must be >= 2 (main.rs:421 / population.rs:584 panic)");
+    s->prm = *p;
+    PSCHK(ps_sim_derive(p, &s->der));
+    const ps_derived &d = s->der;
+    const uint64_t N = p->pop_size, L = p->core_size, G = d.pan_size;
+    s->sel.assign(std::max<uint64_t>(G, 1), 0.0);
+    PSCHK(ps_selection_coefficients(p->seed, G, p->prop_positive, p->pos_lambda, p->neg_lambda, s->sel.data()));
+    for (uint64_t g = 0; g < G; g++)
+        if (std::log(1.0 + s->sel[g]) != 0.0) s->need_logw = true;
+    // site shard of this process
+    const uint64_t sb = L * (uint64_t)p->shard_rank / (uint64_t)p->shard_count;
+    const uint64_t se = L * ((uint64_t)p->shard_rank + 1) / (uint64_t)p->shard_count;
+    ps_config cc{};
+    cc.pop_size = N; cc.ncols = se - sb; cc.global_cols = L; cc.col_offset = sb;
+    cc.core_genes = p->core_genes; cc.seed = p->seed; cc.core = 1; cc.device = p->device;
+    {
+        std::vector<uint8_t> v(std::max<uint64_t>(cc.ncols, 1));
+        PSCHK(ps_init_vector(p->seed, 1, sb, cc.ncols, 0.0, v.data()));
+        PSCHK(ps_population_create(&cc, v.data(), &s->core));       // main.rs:372-381
+    }
+    ps_config ca{};
+    ca.pop_size = N; ca.ncols = G; ca.global_cols = G; ca.col_offset = 0;
+    ca.core_genes = p->core_genes; ca.seed = p->seed; ca.core = 0; ca.device = s->core->device;
+    {
+        std::vector<uint8_t> v(std::max<uint64_t>(G, 1));
+        PSCHK(ps_init_vector(p->seed, 0, 0, G, d.avg_gene_freq_adj, v.data()));
+        PSCHK(ps_population_create(&ca, v.data(), &s->acc));        // main.rs:382-391
+    }
+    {
+        const uint64_t b0 = 0, e0 = L;
+        const double lm = d.n_core_mutations;
+        const double lr = (p->HR_rate > 0.0) ? d.n_recombinations_core : 0.0;   // main.rs:459
+        PSCHK(ps_set_rates(s->core, 1, &lm, &lr, &b0, &e0));
+        double lrec[2] = { 0, 0 };
+        for (int c = 0; c < d.n_comp; c++) lrec[c] = (p->HGT_rate > 0.0) ? d.n_recombinations_pan[c] : 0.0; // :462
+        PSCHK(ps_set_rates(s->acc, d.n_comp, d.n_pan_mutations, lrec, d.comp_begin, d.comp_end));
+    }
+    s->r1.resize(p->max_distances);
+    s->r2.resize(p->max_distances);
+    PSCHK(ps_sample_pairs(p->seed, N, p->max_distances, s->r1.data(), s->r2.data())); // main.rs:413-427
+    s->last_idx.assign(N, 0);
+    PSCHK(use_device(s->core));
+    for (int k = 0; k < PS_RING; k++) {
+        HIPCHK(hipMalloc(&s->d_idx[k], N * sizeof(uint32_t)));
+        HIPCHK(hipHostMalloc(&s->h_idx[k], N * sizeof(uint32_t)));
+        HIPCHK(hipEventCreateWithFlags(&s->ev_idx[k], hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&s->ev_core[k], hipEventDisableTiming));
+    }
+    HIPCHK(hipHostMalloc(&s->h_num_genes, N * sizeof(int32_t)));
+    HIPCHK(hipHostMalloc(&s->h_logw, N * sizeof(double)));
+    HIPCHK(hipHostMalloc(&s->h_avg, N * sizeof(double)));
+    HIPCHK(hipMalloc(&s->d_avg, N * sizeof(double)));
+    if (G) {
+        std::vector<double> l1p(G);
+        for (uint64_t g = 0; g < G; g++) l1p[g] = std::log(1.0 + s->sel[g] * 1.0);
+        HIPCHK(hipMemcpy(s->acc->d_log1p, l1p.data(), G * sizeof(double), hipMemcpyHostToDevice));
+    }
+    return PS_OK;
+}
+
+extern "C" int ps_sim_create(const ps_sim_params *p, ps_sim **out)
+{
+    if (!p || !out) return ps_fail(PS_ERR_INVALID, "null argument");
+    *out = nullptr;
+    ps_sim *s = new ps_sim();
+    const int rc = sim_create_impl(p, s);
+    if (rc != PS_OK) {
+        const std::string keep = g_err;
+        ps_sim_destroy(s);
+        g_err = keep;
+        return rc;
+    }
+    *out = s;
+    return PS_OK;
+}
+
+static int sim_one_generation(ps_sim *s, uint32_t gen)
+{
+    ps_population *core = s->core, *acc = s->acc;
+    const ps_sim_params &p = s->prm;
+    const uint64_t N = p.pop_size;
+    hipStream_t sa = acc->stream, sc = core->stream;
+    const int slot = (int)(s->step_count % PS_RING);
+    // main.rs:435-440
+    for (uint64_t i = 0; i < N; i++) s->h_avg[i] = 1.0;
+    if (p.competition_strength > 0.0) {
+        acc_average_distance_kernel<<<(uint32_t)((N + 63) / 64), 64, 0, sa>>>(acc->I[acc->cur], s->d_avg, acc->d,
+                                                                         (double)p.core_genes);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(s->h_avg, s->d_avg, N * sizeof(double), hipMemcpyDeviceToHost, sa));
+    }
+    // main.rs:442-443: device half of sample_indices ...
+    acc_fitness_kernel<<<(uint32_t)((N + 255) / 256), 256, 0, sa>>>(acc->I[acc->cur], acc->d_log1p,
+                                                                 s->need_logw ? 1 : 0, acc->d_num_genes,
+                                                                 acc->d_logw, acc->d);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(s->h_num_genes, acc->d_num_genes, N * sizeof(int32_t), hipMemcpyDeviceToHost, sa));
+    HIPCHK(hipMemcpyAsync(s->h_logw, acc->d_logw, N * sizeof(double), hipMemcpyDeviceToHost, sa));
+    // the slot's previous core sweep must have consumed its indices
+    if (s->slot_used[slot]) HIPCHK(hipEventSynchronize(s->ev_core[slot]));
+    HIPCHK(hipStreamSynchronize(sa));
+    // ... host half: three softmaxes and N seeded draws
+    std::vector<double> w(N);
+    PSCHK(ps_sample_weights(s->h_num_genes, s->h_logw, N, acc->cfg.ncols, s->der.avg_gene_num, s->h_avg,
+                            p.no_control_genome_size, p.genome_size_penalty, p.competition_strength, w.data()));
+    PSCHK(ps_draw_parents(w.data(), N, p.seed, gen, s->h_idx[slot]));
+    memcpy(s->last_idx.data(), s->h_idx[slot], N * sizeof(uint32_t));
+    HIPCHK(hipMemcpyAsync(s->d_idx[slot], s->h_idx[slot], N * sizeof(uint32_t), hipMemcpyHostToDevice, sa));
+    HIPCHK(hipEventRecord(s->ev_idx[slot], sa));
+    // main.rs:447, :455, :462-464 on the accessory stream
+    PSCHK(step_device(acc, s->d_idx[slot], gen, true, true, p.HGT_rate > 0.0, sa));
+    // main.rs:445, :452, :459-461 on the core stream, one fused pass
+    HIPCHK(hipStreamWaitEvent(sc, s->ev_idx[slot], 0));
+    hipEvent_t t0 = nullptr, t1 = nullptr;
+    if (s->timing) {
+        auto take = [&](hipEvent_t *e) -> int {
+            if (!s->ev_pool.empty()) { *e = s->ev_pool.back(); s->ev_pool.pop_back(); return PS_OK; }
+            HIPCHK(hipEventCreate(e));
+            return PS_OK;
+        };
+        PSCHK(take(&t0));
+        PSCHK(take(&t1));
+        HIPCHK(hipEventRecord(t0, sc));
+    }
+    PSCHK(step_device(core, s->d_idx[slot], gen, true, true, p.HR_rate > 0.0, sc));
+    if (s->timing) {
+        HIPCHK(hipEventRecord(t1, sc));
+        s->tev.emplace_back(t0, t1);
+    }
+    HIPCHK(hipEventRecord(s->ev_core[slot], sc));
+    s->slot_used[slot] = true;
+    s->step_count++;
+    return PS_OK;
+}
+
+extern "C" int ps_sim_run(ps_sim *s, uint32_t first_generation, uint32_t count)
+{
+    if (!s) return ps_fail(PS_ERR_INVALID, "null handle");
+    PSCHK(use_device(s->core));
+    for (uint32_t g = 0; g < count; g++) PSCHK(sim_one_generation(s, first_generation + g));
+    return PS_OK;
+}
+
+extern "C" int ps_sim_sync(ps_sim *s)
+{
+    if (!s) return ps_fail(PS_ERR_INVALID, "null handle");
+    PSCHK(use_device(s->core));
+    HIPCHK(hipStreamSynchronize(s->acc->stream));
+    HIPCHK(hipStreamSynchronize(s->core->stream));
+    return PS_OK;
+}
+
+extern "C" ps_population *ps_sim_core(ps_sim *s) { return s ? s->core : nullptr; }
+extern "C" ps_population *ps_sim_acc(ps_sim *s) { return s ? s->acc : nullptr; }
+extern "C" const double *ps_sim_selection(ps_sim *s) { return s ? s->sel.data() : nullptr; }
+extern "C" const uint32_t *ps_sim_range1(ps_sim *s) { return s ? s->r1.data() : nullptr; }
+extern "C" const uint32_t *ps_sim_range2(ps_sim *s) { return s ? s->r2.data() : nullptr; }
+
+extern "C" int ps_sim_last_parents(ps_sim *s, uint32_t *out_idx)
+{
+    if (!s || !out_idx) return ps_fail(PS_ERR_INVALID, "null argument");
+    memcpy(out_idx, s->last_idx.data(), s->last_idx.size() * sizeof(uint32_t));
+    return PS_OK;
+}
+
+extern "C" int ps_sim_enable_timing(ps_sim *s, int on)
+{
+    if (!s) return ps_fail(PS_ERR_INVALID, "null handle");
+    s->timing = on != 0;
+    return PS_OK;
+}
+
+extern "C" int ps_sim_sweep_timing(ps_sim *s, int reset, uint64_t *launches, double *total_ms,
+                                   double *bytes_per_launch)
+{
+    if (!s) return ps_fail(PS_ERR_INVALID, "null handle");
+    PSCHK(use_device(s->core));
+    HIPCHK(hipStreamSynchronize(s->core->stream));
+    double tot = 0.0;
+    for (auto &pr : s->tev) {
+        float ms = 0.f;
+        HIPCHK(hipEventElapsedTime(&ms, pr.first, pr.second));
+        tot += ms;
+    }
+    if (launches) *launches = s->tev.size();
+    if (total_ms) *total_ms = tot;
+    if (bytes_per_launch) *bytes_per_launch = 2.0 * (double)s->prm.pop_size * (double)s->core->cfg.ncols;
+    if (reset) {
+        for (auto &pr : s->tev) { s->ev_pool.push_back(pr.first); s->ev_pool.push_back(pr.second); }
+        s->tev.clear();
+    }
+    return PS_OK;
+}

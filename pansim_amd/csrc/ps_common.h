@@ -1,0 +1,81 @@
+// ps_common.h -- Philox4x32-10, RNG stream ids and the keyed dense plans shared by
+// the host code and the gfx950 kernels of libpansim_hip.so.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define PS_HD __host__ __device__ __forceinline__
+
+// RNG streams (Philox counter word 3; word 2 is the generation)
+enum : uint32_t {
+    PS_STREAM_CORE_L1 = 1,    // ctr = (site, individual/16, gen): 16 level-1 bytes
+    PS_STREAM_CORE_L2 = 2,    // ctr = (site, individual, gen): refine bits + donor
+    PS_STREAM_ACC_MUT = 3,    // ctr = (gene/4, individual, gen): 4 flip words
+    PS_STREAM_HGT = 4,        // ctr = (event lo, event hi, gen), | compartment << 8
+    PS_STREAM_INIT_CORE = 16, // host sequential streams: ctr = (n lo, n hi, gen)
+    PS_STREAM_INIT_ACC = 17,
+    PS_STREAM_SELECTION = 18,
+    PS_STREAM_PAIRS = 19,
+    PS_STREAM_PARENTS = 20,
+    PS_STREAM_HGT_COUNT = 21
+};
+
+struct ps_u4 { uint32_t x, y, z, w; };
+
+PS_HD uint32_t ps_mulhi(uint32_t a, uint32_t b) { return (uint32_t)(((uint64_t)a * (uint64_t)b) >> 32); }
+
+PS_HD ps_u4 ps_philox(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1)
+{
+#pragma unroll
+    for (int r = 0; r < 10; r++) {
+        uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+        uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+        uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+        uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        c1 = (uint32_t)p1;
+        c3 = (uint32_t)p0;
+        c0 = n0;
+        c2 = n2;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    ps_u4 o = { c0, c1, c2, c3 };
+    return o;
+}
+
+// Core cell plan: cumulative 32-bit thresholds over one uniform word u
+//   u < T[0],T[1],T[2] : mutate to 2,4,8            (population.rs:511-540)
+//   u < T[3],T[4],T[5] : mutate to 2,4,8 AND receive a donor allele
+//   u < T[6]           : receive a donor allele only (population.rs:544-751)
+struct ps_core_plan {
+    uint32_t T[7];
+    uint32_t has_events;
+    uint32_t bC;          // largest level-1 byte that can still hold an event
+};
+
+struct ps_cell { uint32_t mut; uint32_t hr; };
+
+// classify a refined word against the plan
+PS_HD ps_cell ps_classify(uint32_t u, const ps_core_plan &pl)
+{
+    ps_cell o = { 0u, 0u };
+    if (u >= pl.T[6]) return o;
+    if (u < pl.T[2]) {
+        o.mut = (u < pl.T[0]) ? 2u : (u < pl.T[1]) ? 4u : 8u;
+    } else if (u < pl.T[5]) {
+        o.mut = (u < pl.T[3]) ? 2u : (u < pl.T[4]) ? 4u : 8u;
+        o.hr = 1u;
+    } else {
+        o.hr = 1u;
+    }
+    return o;
+}
+
+#define PS_MAX_COMP 2
+struct ps_acc_plan {
+    int32_t n_comp;
+    uint32_t comp_begin[PS_MAX_COMP], comp_end[PS_MAX_COMP];
+    uint32_t flip_thr[PS_MAX_COMP];   // M-acc: flip iff word < thr (population.rs:486-510)
+    double lam_rec[PS_MAX_COMP];      // HGT events per donor (population.rs:555)
+};

@@ -1,0 +1,137 @@
+"""The reference's main() as a library (pansim/src/main.rs:155-553) over the C ABI:
+parameter validation/derivation, the seeded host draws and the generation loop.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import Derived, SimParams, check
+from .population import Population, fmt_f64, standard_deviation
+
+# flag names and defaults of main.rs:21-151
+DEFAULTS = dict(pop_size=1000, core_size=1200000, pan_genes=6000, core_genes=2000, avg_gene_freq=0.5,
+                n_gen=100, max_distances=100000, core_mu=0.05, HR_rate=0.05, HGT_rate=0.05,
+                rate_genes1=1.0, rate_genes2=1000.0, prop_genes2=0.1, prop_positive=-0.1,
+                pos_lambda=10.0, neg_lambda=10.0, seed=0, genome_size_penalty=0.99,
+                competition_strength=0.0, print_dist=0, print_matrices=0, print_selection=0,
+                verbose=0, no_control_genome_size=0, shard_rank=0, shard_count=1, device=-1)
+
+
+def make_params(**kw):
+    p = SimParams()
+    _lib.load().ps_sim_default_params(C.byref(p))
+    for k, v in kw.items():
+        if k not in DEFAULTS:
+            raise TypeError("unknown parameter %r" % k)
+        setattr(p, k, v)
+    return p
+
+
+def validate(params):
+    """main.rs:195-247 -> (ok, stdout text the reference prints before `return Ok(())`)"""
+    buf = C.create_string_buffer(2048)
+    rc = _lib.load().ps_sim_validate(C.byref(params), buf, 2048)
+    return rc == 0, buf.value.decode()
+
+
+def derive(params):
+    """main.rs:259-367"""
+    d = Derived()
+    check(_lib.load().ps_sim_derive(C.byref(params), C.byref(d)))
+    return d
+
+
+def selection_coefficients(seed, n_genes, prop_positive, pos_lambda, neg_lambda):
+    out = np.zeros(n_genes, np.float64)
+    check(_lib.load().ps_selection_coefficients(int(seed), int(n_genes), float(prop_positive),
+                                                float(pos_lambda), float(neg_lambda), out))
+    return out
+
+
+def sample_pairs(seed, pop_size, max_distances):
+    r1 = np.zeros(max_distances, np.uint32)
+    r2 = np.zeros(max_distances, np.uint32)
+    check(_lib.load().ps_sample_pairs(int(seed), int(pop_size), int(max_distances), r1, r2))
+    return r1, r2
+
+
+class Simulation:
+    """State of main() between main.rs:259 and :553 for one process (one GPU)."""
+
+    def __init__(self, params=None, **kw):
+        self._lib = _lib.load()
+        self.params = params if params is not None else make_params(**kw)
+        self.derived = derive(self.params)
+        self._h = C.c_void_p()
+        check(self._lib.ps_sim_create(C.byref(self.params), C.byref(self._h)))
+        p, d = self.params, self.derived
+        sb = p.core_size * p.shard_rank // p.shard_count
+        se = p.core_size * (p.shard_rank + 1) // p.shard_count
+        self.core_genome = Population(p.pop_size, se - sb, 4, True, 0.0, p.seed, p.core_genes,
+                                      global_cols=p.core_size, _handle=self._lib.ps_sim_core(self._h),
+                                      _owned=False)
+        self.pan_genome = Population(p.pop_size, d.pan_size, 2, False, d.avg_gene_freq_adj, p.seed,
+                                     p.core_genes, _handle=self._lib.ps_sim_acc(self._h), _owned=False)
+        P = p.max_distances
+        self.range1 = np.ctypeslib.as_array(self._lib.ps_sim_range1(self._h), (P,)).copy()
+        self.range2 = np.ctypeslib.as_array(self._lib.ps_sim_range2(self._h), (P,)).copy()
+        G = d.pan_size
+        self.selection_weights = (np.ctypeslib.as_array(self._lib.ps_sim_selection(self._h), (G,)).copy()
+                                  if G else np.zeros(0))
+        self.generation = 0
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            self._lib.ps_sim_destroy(self._h)
+        self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def run(self, count, first_generation=None):
+        """main.rs:429-464 for `count` generations (asynchronous; call sync())"""
+        g0 = self.generation if first_generation is None else int(first_generation)
+        check(self._lib.ps_sim_run(self._h, g0, int(count)))
+        self.generation = g0 + int(count)
+
+    def sync(self):
+        check(self._lib.ps_sim_sync(self._h))
+
+    def last_parents(self):
+        out = np.zeros(self.params.pop_size, np.uint32)
+        check(self._lib.ps_sim_last_parents(self._h, out))
+        return out
+
+    def enable_timing(self, on=True):
+        check(self._lib.ps_sim_enable_timing(self._h, int(on)))
+
+    def sweep_timing(self, reset=True):
+        n, ms, b = C.c_uint64(), C.c_double(), C.c_double()
+        check(self._lib.ps_sim_sweep_timing(self._h, int(reset), C.byref(n), C.byref(ms), C.byref(b)))
+        return n.value, ms.value, b.value
+
+    # -- outputs of main.rs:467-499 ---------------------------------------------------
+    def final_distances(self):
+        self.sync()
+        P = self.params.max_distances
+        core = self.core_genome.pairwise_distances(P, self.range1, self.range2)
+        acc = self.pan_genome.pairwise_distances(P, self.range1, self.range2)
+        return core, acc
+
+    def write_outputs(self, outpref):
+        core, acc = self.final_distances()
+        with open(outpref + ".tsv", "w") as f:                       # main.rs:474-482
+            f.writelines("%s\t%s\n" % (fmt_f64(c), fmt_f64(a)) for c, a in zip(core, acc))
+        with open(outpref + "_freqs.txt", "w") as f:                 # main.rs:487-497
+            f.writelines("%s\n" % fmt_f64(x) for x in self.pan_genome.gene_frequencies())
+        if self.params.print_matrices:                               # main.rs:550-553
+            self.core_genome.write(outpref)
+            self.pan_genome.write(outpref)
+
+
+__all__ = ["Simulation", "make_params", "validate", "derive", "selection_coefficients", "sample_pairs",
+           "DEFAULTS", "standard_deviation"]

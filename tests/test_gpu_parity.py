@@ -1,0 +1,396 @@
+"""GPU parity: every operator of the C ABI (HIP kernels) against the CPU oracle on the same
+seeded inputs.  Integer / byte / index work must be bit-exact; f64 outputs are produced by
+identical IEEE expression shapes and are compared exactly as well.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _rand_core(rng, N, L):
+    return (1 << rng.integers(0, 4, size=(N, L))).astype(np.uint8)
+
+
+def _rand_acc(rng, N, G, p=0.3):
+    return (rng.random((N, G)) < p).astype(np.uint8)
+
+
+# ----------------------------------------------------------------------------- D-kern
+def test_hamming_jaccard_kat(pa):
+    # SURVEY 8(c) H1, H2, J1 (hand-derived from distances.rs:22-77)
+    x = [1, 2, 4, 8, 1, 2, 4, 8, 1]
+    y = [1, 2, 4, 8, 1, 2, 4, 8, 2]
+    assert pa.hamming_bitwise_fast(x, y) == 2
+    x = [1, 2, 4, 8, 1, 2, 4, 8, 1, 2, 4, 8, 1, 2, 4, 8, 8]
+    y = [2, 2, 4, 1, 1, 2, 8, 8, 1, 2, 4, 8, 1, 4, 4, 8, 1]
+    assert pa.hamming_bitwise_fast(x, y) == 10
+    a = [1, 1, 0, 0, 1, 0, 0, 0, 1]
+    b = [1, 0, 1, 0, 1, 0, 0, 0, 0]
+    assert pa.jaccard_distance_fast(a, b) == (2, 5)
+    assert pa.hamming_bitwise_fast([], []) == 0
+
+
+def test_hamming_jaccard_random(pa, orc):
+    rng = np.random.default_rng(1)
+    for n in (1, 7, 8, 9, 1000, 123457):
+        x = rng.integers(0, 256, n).astype(np.uint8)
+        y = rng.integers(0, 256, n).astype(np.uint8)
+        assert pa.hamming_bitwise_fast(x, y) == orc.hamming(x, y)
+        assert pa.jaccard_distance_fast(x, y) == orc.jaccard(x, y)
+
+
+# ----------------------------------------------------------------------------- S-state
+@pytest.mark.parametrize("N,L", [(2, 1), (100, 777), (1000, 130), (1024, 65), (1500, 200), (4100, 33)])
+def test_core_load_read_roundtrip(pa, N, L):
+    rng = np.random.default_rng(N * 7 + L)
+    m = _rand_core(rng, N, L)
+    pop = pa.Population(N, L, 4, True, 0.0, 0, 0)
+    pop.load_matrix(m)
+    assert np.array_equal(pop.read_matrix(), m)
+    pop.close()
+
+
+@pytest.mark.parametrize("N,G", [(2, 1), (100, 400), (1000, 4000), (130, 64), (65, 129)])
+def test_acc_load_read_roundtrip(pa, N, G):
+    rng = np.random.default_rng(N * 3 + G)
+    m = _rand_acc(rng, N, G)
+    pop = pa.Population(N, G, 2, False, 0.5, 0, 10)
+    pop.load_matrix(m)
+    assert np.array_equal(pop.read_matrix(), m)
+    pop.close()
+
+
+def test_clonal_init_matches_oracle(pa, orc):
+    N, L, G = 100, 5000, 400
+    core = pa.Population(N, L, 4, True, 0.0, 5, 0)
+    assert np.array_equal(core.read_matrix(), np.tile(orc.init_core_vec(5, L), (N, 1)))
+    acc = pa.Population(N, G, 2, False, 0.25, 5, 200)
+    assert np.array_equal(acc.read_matrix(), np.tile(orc.init_acc_vec(5, G, 0.25), (N, 1)))
+    # a site shard draws the same global vector
+    sh = pa.Population(N, 1000, 4, True, 0.0, 5, 0, col_offset=3000, global_cols=L)
+    assert np.array_equal(sh.read_matrix(), np.tile(orc.init_core_vec(5, L)[3000:4000], (N, 1)))
+
+
+# ----------------------------------------------------------------------------- G-gather
+@pytest.mark.parametrize("N,L", [(3, 5), (100, 1200), (1000, 300), (1500, 100)])
+def test_next_generation_core(pa, orc, N, L):
+    rng = np.random.default_rng(N + L)
+    m = _rand_core(rng, N, L)
+    sample = rng.integers(0, N, N).astype(np.uint32)
+    pop = pa.Population(N, L, 4, True, 0.0, 0, 0)
+    pop.load_matrix(m)
+    pop.next_generation(sample)
+    assert np.array_equal(pop.read_matrix(), orc.next_generation(m, sample))
+
+
+def test_next_generation_kat(pa):
+    # sample=[2,2,0]
+    m = np.array([[1, 2, 4], [8, 8, 8], [2, 1, 2]], np.uint8)
+    pop = pa.Population(3, 3, 4, True, 0.0, 0, 0)
+    pop.load_matrix(m)
+    pop.next_generation([2, 2, 0])
+    assert pop.read_matrix().tolist() == [[2, 1, 2], [2, 1, 2], [1, 2, 4]]
+
+
+@pytest.mark.parametrize("N,G", [(100, 400), (1000, 700), (130, 64)])
+def test_next_generation_acc(pa, orc, N, G):
+    rng = np.random.default_rng(N + G)
+    m = _rand_acc(rng, N, G)
+    sample = rng.integers(0, N, N).astype(np.uint32)
+    pop = pa.Population(N, G, 2, False, 0.5, 0, 0)
+    pop.load_matrix(m)
+    pop.next_generation(sample)
+    assert np.array_equal(pop.read_matrix(), orc.next_generation(m, sample))
+
+
+# ----------------------------------------------------------------------------- M-core / R-core
+CORE_CASES = [
+    # N, L_local, L_global, offset, lam_mut, lam_hr
+    (100, 1200, 12000, 0, 600.0, 30.0),
+    (100, 500, 12000, 7000, 600.0, 6000.0),
+    (1000, 400, 1200000, 1000000, 60000.0, 3000.0),
+    (1000, 200, 4000, 0, 2000.0, 2000.0),        # heavy rates: many candidates per chunk
+    (1500, 150, 3000, 100, 150.0, 15.0),         # block-per-row path
+    (17, 64, 64, 0, 64.0, 0.0),
+    (2, 300, 300, 0, 30.0, 30.0),
+]
+
+
+@pytest.mark.parametrize("N,L,LG,off,lm,lh", CORE_CASES)
+def test_core_operators_match_oracle(pa, orc, N, L, LG, off, lm, lh):
+    rng = np.random.default_rng(N * 31 + L)
+    m0 = _rand_core(rng, N, L)
+    plan = orc.core_plan(lm, lh, LG)
+    seed, gen = 1234567890123, 7
+    pop = pa.Population(N, L, 4, True, 0.0, seed, 0, col_offset=off, global_cols=LG)
+    pop.set_rates([lm], [lh])
+    # mutate only
+    pop.load_matrix(m0)
+    pop.mutate_alleles(gen)
+    want_mut = orc.mutate_core(m0.copy(), off, seed, gen, plan)
+    got = pop.read_matrix()
+    assert np.array_equal(got, want_mut)
+    assert (got != m0).any()
+    # recombine only, on the post-mutation state
+    pop.recombine(gen)
+    want_rec = orc.recombine_core(want_mut.copy(), off, seed, gen, plan)
+    assert np.array_equal(pop.read_matrix(), want_rec)
+    # fused == gather, mutate, recombine in order
+    sample = rng.integers(0, N, N).astype(np.uint32)
+    pop.load_matrix(m0)
+    pop.step(gen + 1, sample, True)
+    w = orc.next_generation(m0, sample)
+    orc.mutate_core(w, off, seed, gen + 1, plan)
+    orc.recombine_core(w, off, seed, gen + 1, plan)
+    assert np.array_equal(pop.read_matrix(), w)
+    # fused without recombination
+    pop.load_matrix(m0)
+    pop.step(gen + 2, sample, False)
+    w = orc.next_generation(m0, sample)
+    orc.mutate_core(w, off, seed, gen + 2, plan)
+    assert np.array_equal(pop.read_matrix(), w)
+    pop.close()
+
+
+def test_core_mutation_never_writes_A(pa):
+    # `1 >> value` always selects [2,4,8]
+    N, L = 200, 2000
+    pop = pa.Population(N, L, 4, True, 0.0, 3, 0)
+    pop.load_matrix(np.ones((N, L), np.uint8))
+    pop.set_rates([L * 0.5], [0.0])
+    pop.mutate_alleles(0)
+    m = pop.read_matrix()
+    assert set(np.unique(m)) <= {1, 2, 4, 8}
+    changed = m[m != 1]
+    assert changed.size > 0 and set(np.unique(changed)) == {2, 4, 8}
+
+
+# ----------------------------------------------------------------------------- M-acc / R-acc
+ACC_CASES = [
+    # N, G, comps(begin,end), lam_mut, lam_rec
+    (100, 400, [(0, 360), (360, 400)], [360.0, 40000.0], [27.0, 3.0]),
+    (1000, 4000, [(0, 3600), (3600, 4000)], [3600.0, 400000.0], [2700.0, 299.99999999999994]),
+    (130, 200, [(0, 200)], [20.0], [500.0]),
+    (70, 129, [(0, 64), (64, 129)], [0.0, 10.0], [5.0, 0.0]),
+    (50, 300, [(0, 100), (100, 300)], [1.0, 1.0], [2000.0, 2000.0]),
+]
+
+
+@pytest.mark.parametrize("N,G,comps,lm,lr", ACC_CASES)
+def test_acc_operators_match_oracle(pa, orc, N, G, comps, lm, lr):
+    rng = np.random.default_rng(N * 13 + G)
+    m0 = _rand_acc(rng, N, G, 0.25)
+    m0[0, :] = 0            # a donor with no genes at all (population.rs:672)
+    cb = [c[0] for c in comps]
+    ce = [c[1] for c in comps]
+    seed, gen = 42, 3
+    pop = pa.Population(N, G, 2, False, 0.25, seed, 10)
+    pop.set_rates(lm, lr, cb, ce)
+    pop.load_matrix(m0)
+    pop.mutate_alleles(gen)
+    want = orc.mutate_acc(m0.copy(), seed, gen, cb, ce, lm)
+    assert np.array_equal(pop.read_matrix(), want)
+    pop.recombine(gen)
+    want2 = want.copy()
+    orc.recombine_acc(want2, seed, gen, cb, ce, lr)
+    got2 = pop.read_matrix()
+    assert np.array_equal(got2, want2)
+    assert (got2 >= want).all()          # HGT never clears a gene
+    # gene-major view stayed coherent with the individual-major one
+    assert np.array_equal(pop.gene_frequencies()[:G], want2.sum(0) / N)
+    sample = rng.integers(0, N, N).astype(np.uint32)
+    pop.load_matrix(m0)
+    pop.step(gen + 1, sample, True)
+    w = orc.next_generation(m0, sample)
+    orc.mutate_acc(w, seed, gen + 1, cb, ce, lm)
+    orc.recombine_acc(w, seed, gen + 1, cb, ce, lr)
+    assert np.array_equal(pop.read_matrix(), w)
+    pop.close()
+
+
+# ----------------------------------------------------------------------------- P-*
+def test_fitness_terms_and_sample_indices(pa, orc):
+    N, G = 300, 500
+    rng = np.random.default_rng(5)
+    m = _rand_acc(rng, N, G, 0.4)
+    sel = orc.selection_coefficients(9, G, 0.3, 10.0, 10.0)
+    sel[7] = -1.0                      # the -inf reset rule (population.rs:312-318)
+    pop = pa.Population(N, G, 2, False, 0.4, 11, 20)
+    pop.load_matrix(m)
+    ng, lw = pop.fitness_terms(sel)
+    ong, olw = orc.fitness_terms(m, sel)
+    assert np.array_equal(ng, ong)
+    assert np.array_equal(lw, olw)
+    assert (lw[m[:, 7] == 1] == 0.0).all()
+    for comp, avg in ((0.0, np.ones(N)), (5.0, rng.random(N) + 0.1)):
+        for no_control in (False, True):
+            idx = pop.sample_indices(4, 200, avg, sel, False, no_control, 0.99, comp)
+            rc, oidx = orc.sample_indices(m, 11, 4, 200, avg, sel, no_control, 0.99, comp)
+            assert rc == 0
+            assert np.array_equal(idx, oidx)
+    # neutral coefficients
+    z = np.zeros(G)
+    idx = pop.sample_indices(0, 200, np.ones(N), z)
+    rc, oidx = orc.sample_indices(m, 11, 0, 200, np.ones(N), z)
+    assert np.array_equal(idx, oidx)
+
+
+# ----------------------------------------------------------------------------- D-pairs / D-avg / F-freq
+@pytest.mark.parametrize("N,L,P", [(100, 1203, 5000), (1000, 777, 40000), (1100, 300, 3000),
+                                   (1500, 333, 2000), (6000, 40, 1000)])
+def test_pairwise_core(pa, orc, N, L, P):
+    rng = np.random.default_rng(N + L + P)
+    m = _rand_core(rng, N, L)
+    r1, r2 = orc.sample_pairs(3, N, P)
+    pop = pa.Population(N, L, 4, True, 0.0, 0, 0)
+    pop.load_matrix(m)
+    got = pop.pairwise_distances(P, r1, r2)
+    assert np.array_equal(got, orc.pairwise_distances(m, True, 0, r1, r2))
+    (cnt,) = pop.pairwise_counts(r1, r2)
+    assert np.array_equal(cnt, orc.pairwise_hamming_counts(m, 0, L, r1, r2))
+
+
+def test_pairwise_core_arbitrary_bytes(pa, orc):
+    # not one-hot: the generic kernel must reproduce popcount(x ^ y) / 2 (population.rs:817)
+    N, L, P = 64, 99, 500
+    rng = np.random.default_rng(0)
+    m = rng.integers(0, 256, (N, L)).astype(np.uint8)
+    r1, r2 = orc.sample_pairs(1, N, P)
+    pop = pa.Population(N, L, 4, True, 0.0, 0, 0)
+    pop.load_matrix(m)
+    assert np.array_equal(pop.pairwise_distances(P, r1, r2), orc.pairwise_distances(m, True, 0, r1, r2))
+
+
+def test_pairwise_kat(pa):
+    # SURVEY 8(c) H1 -> 0.1111111111111111 ; J1 -> 0.6 / 0.4285714285714286 / 0.0014962593516208988
+    x = [1, 2, 4, 8, 1, 2, 4, 8, 1]
+    y = [1, 2, 4, 8, 1, 2, 4, 8, 2]
+    pop = pa.Population(2, 9, 4, True, 0.0, 0, 0)
+    pop.load_matrix(np.array([x, y], np.uint8))
+    assert pop.pairwise_distances(1, [0], [1])[0] == 0.1111111111111111
+    a = [1, 1, 0, 0, 1, 0, 0, 0, 1]
+    b = [1, 0, 1, 0, 1, 0, 0, 0, 0]
+    for cg, want in ((0, 0.6), (2, 0.4285714285714286), (2000, 0.0014962593516208988)):
+        acc = pa.Population(2, 9, 2, False, 0.5, 0, cg)
+        acc.load_matrix(np.array([a, b], np.uint8))
+        assert acc.pairwise_distances(1, [0], [1])[0] == want
+    # identical rows -> average distance clamps to f64::MIN_POSITIVE (population.rs:774-776)
+    acc = pa.Population(3, 9, 2, False, 0.5, 0, 5)
+    acc.load_matrix(np.array([a, a, a], np.uint8))
+    assert (acc.average_distance() == 2.2250738585072014e-308).all()
+    # empty union and no core genes -> NaN
+    acc = pa.Population(2, 4, 2, False, 0.5, 0, 0)
+    acc.load_matrix(np.zeros((2, 4), np.uint8))
+    assert np.isnan(acc.pairwise_distances(1, [0], [1])[0])
+
+
+@pytest.mark.parametrize("N,G,cg", [(100, 400, 200), (1000, 4000, 2000), (77, 65, 0)])
+def test_pairwise_average_freq_acc(pa, orc, N, G, cg):
+    rng = np.random.default_rng(N + G)
+    m = _rand_acc(rng, N, G, 0.25)
+    r1, r2 = orc.sample_pairs(8, N, 3000)
+    pop = pa.Population(N, G, 2, False, 0.25, 0, cg)
+    pop.load_matrix(m)
+    assert np.array_equal(pop.pairwise_distances(3000, r1, r2), orc.pairwise_distances(m, False, cg, r1, r2))
+    assert np.array_equal(pop.gene_frequencies(), orc.gene_frequencies(m, cg))
+    if N <= 100:
+        assert np.array_equal(pop.average_distance(), orc.average_distance(m, False, cg))
+    assert pop.calc_gene_freq() == orc.lib().orc_calc_gene_freq(m, N, G)
+
+
+def test_gene_frequencies_kat(pa):
+    m = np.array([[1, 0, 1], [1, 0, 0], [1, 1, 0], [1, 0, 0]], np.uint8)
+    pop = pa.Population(4, 3, 2, False, 0.5, 0, 2)
+    pop.load_matrix(m)
+    assert pop.gene_frequencies().tolist() == [1.0, 0.25, 0.25, 1.0, 1.0]
+
+
+# ----------------------------------------------------------------------------- W-out
+def test_write_matrices(pa, orc, tmp_path):
+    N, L, G = 5, 7, 6
+    rng = np.random.default_rng(2)
+    mc = _rand_core(rng, N, L)
+    mc[0, 0] = 3                       # not an allele -> 'N' (population.rs:160)
+    ma = _rand_acc(rng, N, G)
+    core = pa.Population(N, L, 4, True, 0.0, 0, 2)
+    core.load_matrix(mc)
+    acc = pa.Population(N, G, 2, False, 0.5, 0, 2)
+    acc.load_matrix(ma)
+    core.write(str(tmp_path / "got"))
+    acc.write(str(tmp_path / "got"))
+    orc.lib().orc_write_matrix(mc, N, L, 1, 2, str(tmp_path / "want").encode())
+    orc.lib().orc_write_matrix(ma, N, G, 0, 2, str(tmp_path / "want").encode())
+    for suffix in ("_core_genome.csv", "_pangenome.csv"):
+        assert (tmp_path / ("got" + suffix)).read_text() == (tmp_path / ("want" + suffix)).read_text()
+    first = (tmp_path / "got_core_genome.csv").read_text().splitlines()[0]
+    assert first.startswith("N,") and len(first.split(",")) == L
+    assert (tmp_path / "got_pangenome.csv").read_text().splitlines()[0].startswith("1,1,")
+
+
+# ----------------------------------------------------------------------------- L-loop
+SIM_CASES = [
+    dict(pop_size=100, core_size=12000, pan_genes=600, core_genes=200),                   # config 1'
+    dict(pop_size=100, core_size=3000, pan_genes=600, core_genes=200, HR_rate=0.5, HGT_rate=0.5),
+    dict(pop_size=64, core_size=2000, pan_genes=300, core_genes=100, HR_rate=0.0, HGT_rate=0.0),
+    dict(pop_size=1200, core_size=900, pan_genes=500, core_genes=100),                     # block path
+]
+
+
+@pytest.mark.parametrize("kw", SIM_CASES)
+def test_generation_loop_matches_oracle(pa, orc, kw):
+    from orc_sim import OracleSim
+    sim = pa.Simulation(pa.make_params(seed=3, n_gen=6, max_distances=2000, **kw))
+    ref = OracleSim(seed=3, **kw)
+    r1, r2 = orc.sample_pairs(3, kw["pop_size"], 2000)
+    assert np.array_equal(sim.range1, r1) and np.array_equal(sim.range2, r2)
+    for g in range(6):
+        sim.run(1)
+        sim.sync()
+        ref.generation(g)
+        assert np.array_equal(sim.last_parents(), ref.last_idx)
+    assert np.array_equal(sim.core_genome.read_matrix(), ref.core)
+    assert np.array_equal(sim.pan_genome.read_matrix(), ref.acc)
+    core_d, acc_d = sim.final_distances()
+    cg = kw["core_genes"]
+    assert np.array_equal(core_d, orc.pairwise_distances(ref.core, True, cg, r1, r2))
+    assert np.array_equal(acc_d, orc.pairwise_distances(ref.acc, False, cg, r1, r2))
+    assert np.array_equal(sim.pan_genome.gene_frequencies(), orc.gene_frequencies(ref.acc, cg))
+    sim.close()
+
+
+def test_generation_loop_selection_and_competition(pa, orc):
+    from orc_sim import OracleSim
+    kw = dict(pop_size=80, core_size=1500, pan_genes=400, core_genes=100)
+    extra = dict(prop_positive=0.3, competition_strength=50.0)
+    sim = pa.Simulation(pa.make_params(seed=9, n_gen=5, max_distances=300, **kw, **extra))
+    ref = OracleSim(seed=9, **kw, **extra)
+    assert np.array_equal(sim.selection_weights, ref.sel)
+    # run the 5 generations without host synchronisation in between
+    sim.run(5)
+    sim.sync()
+    for g in range(5):
+        ref.generation(g)
+    assert np.array_equal(sim.last_parents(), ref.last_idx)
+    assert np.array_equal(sim.core_genome.read_matrix(), ref.core)
+    assert np.array_equal(sim.pan_genome.read_matrix(), ref.acc)
+
+
+def test_site_shards_equal_unsharded(pa):
+    # 8(e): a site shard keyed on global site indices reproduces its columns of the full run
+    kw = dict(pop_size=100, core_size=6001, pan_genes=600, core_genes=200, HR_rate=0.3)
+    full = pa.Simulation(pa.make_params(seed=1, n_gen=4, max_distances=1000, **kw))
+    full.run(4)
+    want = full.core_genome.read_matrix()
+    (cnt_full,) = full.core_genome.pairwise_counts(full.range1, full.range2)
+    parts, cnt = [], np.zeros_like(cnt_full)
+    for r in range(3):
+        sh = pa.Simulation(pa.make_params(seed=1, n_gen=4, max_distances=1000, shard_rank=r, shard_count=3, **kw))
+        sh.run(4)
+        parts.append(sh.core_genome.read_matrix())
+        cnt += sh.core_genome.pairwise_counts(sh.range1, sh.range2)[0]
+        assert np.array_equal(sh.pan_genome.read_matrix(), full.pan_genome.read_matrix())
+        sh.close()
+    assert np.array_equal(np.concatenate(parts, axis=1), want)
+    assert np.array_equal(cnt, cnt_full)
+    full.close()
