@@ -1,0 +1,166 @@
+"""CPU-side checks of the product's host code (no GPU compute): parameter derivation,
+validation text, seeded host draws, weight arithmetic and formatting of libpansim_hip.so
+against the oracle and the golden vectors; the C ABI exports every declared symbol.
+"""
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+KAT = json.load(open(os.path.join(ROOT, "tests", "golden", "kat.json")))
+
+
+def test_library_exports_every_declared_symbol(pa):
+    hdr = open(os.path.join(ROOT, "include", "pansim_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(ps_[a-z0-9_]+)\s*\(", hdr))
+    assert len(declared) >= 40
+    import ctypes
+    lib = ctypes.CDLL(pa.LIB_PATH)
+    missing = [n for n in sorted(declared) if not hasattr(lib, n)]
+    assert not missing, "declared in include/pansim_hip.h but not exported: %s" % missing
+    from pansim_amd import _lib
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    assert lib.ps_abi_version() == 1
+
+
+def test_no_cpu_fallback_without_device(pa):
+    # in the CPU container every compute entry point must fail loudly, never fall back
+    if pa.load().ps_device_count() > 0:
+        pytest.skip("a GPU is present")
+    with pytest.raises(pa.PansimError) as e:
+        pa.Population(10, 20, 4, True, 0.0, 0, 0)
+    assert e.value.code == -2
+    with pytest.raises(pa.PansimError):
+        pa.hamming_bitwise_fast([1, 2], [2, 2])
+    with pytest.raises(pa.PansimError):
+        pa.Simulation(pa.make_params(pop_size=10, core_size=100, pan_genes=60, core_genes=20))
+
+
+def test_product_does_not_import_oracle():
+    # the oracle is test infrastructure: nothing under pansim_amd/ may reference it
+    bad = []
+    for dp, _, files in os.walk(os.path.join(ROOT, "pansim_amd")):
+        for f in files:
+            if f.endswith((".py", ".h", ".hip", ".cpp", ".hpp")) or f == "Makefile":
+                txt = open(os.path.join(dp, f), errors="replace").read()
+                if re.search(r"\boracle\b|orc_", txt):
+                    bad.append(os.path.join(dp, f))
+    assert not bad, bad
+
+
+def test_derive_matches_golden_and_oracle(pa, orc):
+    for v in KAT["derived"]:
+        d = pa.derive(pa.make_params(**v["params"]))
+        o = orc.derive(orc.make_params(**v["params"]))
+        for name in ("pan_size", "avg_gene_freq_adj", "avg_gene_num", "n_core_mutations",
+                     "n_recombinations_core", "n_recombinations_pan_total", "n_comp"):
+            assert getattr(d, name) == getattr(o, name)
+        assert d.avg_gene_num == v["avg_gene_num"] and d.pan_size == v["pan_size"]
+        for name in ("comp_begin", "comp_end", "n_pan_mutations", "n_recombinations_pan"):
+            assert list(getattr(d, name)) == list(getattr(o, name))
+        assert list(d.n_recombinations_pan)[:d.n_comp] == v["n_recombinations_pan"]
+    rng = np.random.default_rng(0)
+    for _ in range(50):
+        kw = dict(pop_size=int(rng.integers(2, 5000)), core_size=int(rng.integers(1, 10**7)),
+                  pan_genes=int(rng.integers(100, 10000)), avg_gene_freq=float(rng.random() * 0.99 + 0.01),
+                  HR_rate=float(rng.random()), HGT_rate=float(rng.random()), core_mu=float(rng.random()),
+                  rate_genes1=float(rng.random() * 3), rate_genes2=float(rng.random() * 2000),
+                  prop_genes2=float(rng.random()))
+        kw["core_genes"] = int(rng.integers(0, kw["pan_genes"]))
+        d, o = pa.derive(pa.make_params(**kw)), orc.derive(orc.make_params(**kw))
+        assert (d.pan_size, d.avg_gene_freq_adj, d.avg_gene_num, d.n_core_mutations, d.n_comp) == \
+               (o.pan_size, o.avg_gene_freq_adj, o.avg_gene_num, o.n_core_mutations, o.n_comp)
+        assert list(d.n_recombinations_pan) == list(o.n_recombinations_pan)
+        assert list(d.n_pan_mutations) == list(o.n_pan_mutations)
+
+
+VALIDATION = [
+    (dict(pan_genes=600), "core_genes must be less than or equal to pan_size\n"),               # main.rs:195-198
+    (dict(HR_rate=-0.5), "HR_rate and HGT_rate must be above 0.0\nHR_rate: -0.5\nHGT_rate: 0.05\n"),
+    (dict(pos_lambda=0.0), "pos_lambda and neg_lambda must be above 0.0\npos_lambda: 0\nneg_lambda: 10\n"),
+    (dict(rate_genes2=-1.0), "rate_genes1 and rate_genes2 must be >= 0\nrate_genes1: 1\nrate_genes2: -1\n"),
+    (dict(prop_genes2=1.5), "prop_genes2 must be 0.0 <= prop_genes2 <= 1.0\nprop_genes2: 1.5\n"),
+    (dict(n_gen=0), "pop_size, core_size, pan_genes, n_gen and max_distances must all be above 1\npop_size: 1000\n"
+                    "core_size: 1200000\npan_genes: 6000\nn_gen: 0\nmax_distances: 100000\n"),
+    (dict(core_mu=1.5), "core_mu must be between 0.0 and 1.0\ncore_mu: 1.5\n"),
+    (dict(avg_gene_freq=0.0), "avg_gene_freq must be above 0.0 and below or equal to 1.0\navg_gene_freq: 0\n"),
+]
+
+
+@pytest.mark.parametrize("kw,text", VALIDATION)
+def test_validation_messages(pa, kw, text):
+    ok, msg = pa.validate(pa.make_params(**kw))
+    assert not ok and msg == text
+
+
+def test_validation_order_and_defaults(pa):
+    assert pa.validate(pa.make_params()) == (True, "")
+    # first failing check wins (main.rs:195-247 order)
+    ok, msg = pa.validate(pa.make_params(pan_genes=600, HR_rate=-1.0, core_mu=2.0))
+    assert msg.startswith("core_genes must be")
+    ok, msg = pa.validate(pa.make_params(prop_genes2=2.0, core_mu=2.0))
+    assert msg.startswith("prop_genes2 must be")
+    p = pa.make_params()
+    for k, v in pa.DEFAULTS.items():
+        assert getattr(p, k) == v
+
+
+def test_seeded_host_draws_match_oracle(pa, orc):
+    for seed in (0, 1, 2**40 + 17):
+        assert np.array_equal(pa.init_vector(seed, True, 5000), orc.init_core_vec(seed, 5000))
+        assert np.array_equal(pa.init_vector(seed, True, 100, col_offset=4000), orc.init_core_vec(seed, 5000)[4000:4100])
+        assert np.array_equal(pa.init_vector(seed, False, 4000, 0.25), orc.init_acc_vec(seed, 4000, 0.25))
+        r1, r2 = pa.sample_pairs(seed, 1000, 5000)
+        o1, o2 = orc.sample_pairs(seed, 1000, 5000)
+        assert np.array_equal(r1, o1) and np.array_equal(r2, o2)
+        for pp in (-0.1, 0.0, 0.3, 1.0):
+            assert np.array_equal(pa.selection_coefficients(seed, 3000, pp, 10.0, 4.0),
+                                  orc.selection_coefficients(seed, 3000, pp, 10.0, 4.0))
+    v = pa.init_vector(0, True, 100000)
+    assert set(np.unique(v)) == {1, 2, 4, 8}
+    assert abs(pa.init_vector(0, False, 100000, 0.25).mean() - 0.25) < 0.01
+
+
+def test_sample_weights_and_draws_match_oracle(pa, orc):
+    rng = np.random.default_rng(3)
+    N, G = 500, 300
+    for trial in range(12):
+        ng = rng.integers(50, 150, N).astype(np.int32)
+        lw = rng.normal(0, 2, N) if trial % 2 else np.zeros(N)
+        avg = rng.random(N) + 1e-3 if trial % 3 == 0 else np.ones(N)
+        comp = 10.0 if trial % 3 == 0 else 0.0
+        noc = bool(trial % 4 == 1)
+        w = pa.sample_weights(ng, lw, G, 100, avg, noc, 0.99, comp)
+        rc, ow = orc.sample_weights(ng, lw, G, 100, avg, noc, 0.99, comp)
+        assert rc == 0 and np.array_equal(w, ow)
+        idx = pa.draw_parents(w, 77, trial)
+        rc, oidx = orc.draw_parents(ow, 77, trial)
+        assert np.array_equal(idx, oidx) and idx.max() < N
+    with pytest.raises(pa.PansimError) as e:                 # WeightedIndex::new panic, population.rs:440
+        pa.sample_weights(ng, lw, G, 100, np.ones(N), False, -1.0, 0.0)
+    assert e.value.code == -4
+    # all-zero weights fall back to uniform (population.rs:403, :435-437)
+    lw2 = np.zeros(N)
+    big = np.full(N, 10**6, np.int32)
+    w = pa.sample_weights(big, lw2, G, 0, np.ones(N), False, 1e-300, 0.0)
+    rc, ow = orc.sample_weights(big, lw2, G, 0, np.ones(N), False, 1e-300, 0.0)
+    assert rc == 0 and np.array_equal(w, ow)
+
+
+def test_format_and_small_helpers(pa, orc):
+    for x, want in KAT["rust_display_f64"]:
+        assert pa.fmt_f64(x) == want
+    rng = np.random.default_rng(5)
+    xs = np.concatenate([rng.random(300), rng.random(100) * 1e-12, rng.random(100) * 1e15, -rng.random(20)])
+    for x in xs:
+        assert pa.fmt_f64(x) == orc.fmt_f64(x)
+    for x in (float("nan"), float("inf"), float("-inf"), 5e-324, 1.7976931348623157e308, 2.2250738585072014e-308):
+        assert pa.fmt_f64(x) == orc.fmt_f64(x)
+    for k, v in KAT["int_to_base"].items():
+        assert pa.int_to_base(int(k)) == v
+    v = KAT["standard_deviation"]
+    assert pa.standard_deviation(v["values"]) == (v["std"], v["mean"])
