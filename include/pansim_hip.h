@@ -144,6 +144,11 @@ int ps_calc_gene_freq(ps_population *p, double *out);
 int ps_write(ps_population *p, const char *outpref);
 /* wait for all queued device work of this handle */
 int ps_sync(ps_population *p);
+/* Launch tuning / test hooks (no reference counterpart).  Keys: "sweep_blocks_per_cu"
+ * (resident 256-thread blocks per CU of the wave-per-row sweep, 1..8),
+ * "force_block_sweep" (0/1: use the block-per-row sweep even when a row fits one
+ * wavefront), "lds_limit" (bytes of LDS a workgroup may use). */
+int ps_set_tuning(ps_population *p, const char *key, int64_t value);
 
 /* ------------------------------------------------------------------------ */
 /* free functions of the seam                                                */

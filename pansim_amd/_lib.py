@@ -9,7 +9,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libpansim_hip.so")
+LIB_PATH = os.environ.get("PANSIM_HIP_LIBRARY") or os.path.join(_HERE, "libpansim_hip.so")
 
 PS_OK = 0
 PS_ERR_INVALID, PS_ERR_NO_DEVICE, PS_ERR_OOM, PS_ERR_WEIGHTS, PS_ERR_IO, PS_ERR_STATE = -1, -2, -3, -4, -5, -6
@@ -82,6 +82,7 @@ SIGNATURES = {
     "ps_calc_gene_freq": (_int, [_vp, C.POINTER(_f64)]),
     "ps_write": (_int, [_vp, C.c_char_p]),
     "ps_sync": (_int, [_vp]),
+    "ps_set_tuning": (_int, [_vp, C.c_char_p, C.c_int64]),
     "ps_hamming_bitwise_fast": (_int, [_u8p, _u8p, C.c_size_t, C.POINTER(_u32)]),
     "ps_jaccard_distance_fast": (_int, [_u8p, _u8p, C.c_size_t, C.POINTER(_u32), C.POINTER(_u32)]),
     "ps_standard_deviation": (_int, [_f64p, _u64, C.POINTER(_f64), C.POINTER(_f64)]),

@@ -120,40 +120,54 @@ __global__ void __launch_bounds__(64) acc_step_kernel(acc_step_args a)
     if (valid) a.dstI[(uint64_t)i * d.GW + gw] = rowword;
 }
 
-// number of present genes of every individual inside each compartment
-__global__ void acc_comp_counts_kernel(const uint64_t *accI, uint32_t *cnt /* [n_comp][N] */,
-                                       acc_dims d, ps_acc_plan plan)
+// Rank/select tables for HGT donors (population.rs:636-680 builds a per-donor
+// WeightedIndex over the donor's present genes; this is its bitset form).  One wave
+// per (individual, compartment): lane = row word, popcount, wave prefix sum, then
+// every lane writes the positions of its set bits.  list[i*G + comp_begin + j] is
+// the j-th present gene of individual i inside the compartment; cnt[c*N + i] their
+// number.
+__global__ void __launch_bounds__(64) acc_gene_lists_kernel(const uint64_t *accI, uint16_t *list,
+                                                            uint32_t *cnt, acc_dims d, ps_acc_plan plan)
 {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= d.N) return;
-    for (int c = 0; c < plan.n_comp; c++) {
-        const uint32_t gb = plan.comp_begin[c], ge = plan.comp_end[c];
-        uint32_t n = 0;
-        for (uint32_t gw = gb >> 6; gw * 64u < ge; gw++) {
-            uint64_t word = accI[(uint64_t)i * d.GW + gw];
+    const uint32_t i = blockIdx.x, c = blockIdx.y, lane = threadIdx.x;
+    const uint32_t gb = plan.comp_begin[c], ge = plan.comp_end[c];
+    uint32_t base = 0;
+    for (uint32_t gw0 = gb >> 6; gw0 * 64u < ge; gw0 += 64u) {
+        const uint32_t gw = gw0 + lane;
+        uint64_t word = 0;
+        if (gw * 64u < ge && gw < d.GW) {
+            word = accI[(uint64_t)i * d.GW + gw];
             const uint32_t lo = gw * 64u;
             if (lo < gb) word &= ~0ull << (gb - lo);
             if (lo + 64u > ge) word &= (ge - lo >= 64u) ? ~0ull : ((1ull << (ge - lo)) - 1ull);
-            n += __popcll(word);
         }
-        cnt[(uint64_t)c * d.N + i] = n;
+        const uint32_t pc = __popcll(word);
+        uint32_t incl = pc;                      // inclusive wave prefix sum
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t t = __shfl_up(incl, off, 64);
+            if ((int)lane >= off) incl += t;
+        }
+        uint32_t pos = base + incl - pc;
+        while (word) {
+            const uint32_t b = (uint32_t)__builtin_ctzll(word);
+            word &= word - 1ull;
+            list[(uint64_t)i * d.G + gb + pos] = (uint16_t)(gw * 64u + b);
+            pos++;
+        }
+        base += __shfl(incl, 63, 64);
     }
-}
-
-__device__ __forceinline__ uint32_t ps_select64(uint64_t word, uint32_t j)
-{
-    for (uint32_t t = 0; t < j; t++) word &= word - 1ull;   // drop the j lowest set bits
-    return (uint32_t)__builtin_ctzll(word);
+    if (lane == 0) cnt[(uint64_t)c * d.N + i] = base;
 }
 
 // HGT events of one compartment (population.rs:544-751 accessory path): event e
 // picks a uniform donor, a uniform other recipient and a uniform gene among the
-// donor's present genes of the compartment IN THE SNAPSHOT; the recipient gains
-// the gene (value always 1, :632) -- an idempotent OR, so order does not matter.
-__global__ void __launch_bounds__(256) acc_hgt_kernel(const uint64_t *snapI, const uint32_t *cnt,
+// donor's present genes of the compartment IN THE SNAPSHOT (the gene lists); the
+// recipient gains the gene (value always 1, :632) -- an idempotent OR, so the order
+// of events does not matter.
+__global__ void __launch_bounds__(256) acc_hgt_kernel(const uint16_t *list, const uint32_t *cnt,
                                                       uint64_t *dstG, uint64_t *dstI, acc_dims d,
-                                                      uint32_t gb, uint32_t ge, uint32_t comp,
-                                                      uint64_t K, uint32_t gen, uint32_t k0, uint32_t k1)
+                                                      uint32_t gb, uint32_t comp, uint64_t K,
+                                                      uint32_t gen, uint32_t k0, uint32_t k1)
 {
     const uint32_t stream = PS_STREAM_HGT | (comp << 8);
     for (uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; e < K;
@@ -164,17 +178,8 @@ __global__ void __launch_bounds__(256) acc_hgt_kernel(const uint64_t *snapI, con
         rc += (rc >= dn) ? 1u : 0u;                         // population.rs:618
         const uint32_t n = cnt[(uint64_t)comp * d.N + dn];
         if (n == 0) continue;                               // population.rs:672
-        uint32_t j = ps_mulhi(r.z, n);
-        uint32_t gene = 0;
-        for (uint32_t gw = gb >> 6; gw * 64u < ge; gw++) {
-            uint64_t word = snapI[(uint64_t)dn * d.GW + gw];
-            const uint32_t lo = gw * 64u;
-            if (lo < gb) word &= ~0ull << (gb - lo);
-            if (lo + 64u > ge) word &= (ge - lo >= 64u) ? ~0ull : ((1ull << (ge - lo)) - 1ull);
-            const uint32_t pc = __popcll(word);
-            if (j < pc) { gene = lo + ps_select64(word, j); break; }
-            j -= pc;
-        }
+        const uint32_t j = ps_mulhi(r.z, n);
+        const uint32_t gene = list[(uint64_t)dn * d.G + gb + j];
         atomicOr((unsigned long long *)&dstG[(uint64_t)gene * d.W + (rc >> 6)], 1ull << (rc & 63u));
         atomicOr((unsigned long long *)&dstI[(uint64_t)rc * d.GW + (gene >> 6)], 1ull << (gene & 63u));
     }

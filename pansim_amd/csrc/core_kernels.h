@@ -20,6 +20,7 @@ struct core_sweep_args {
     uint32_t site_offset;  // global site index of local row 0 (Philox counter)
     uint32_t gen, k0, k1;
     ps_core_plan plan;
+    uint32_t *overflow_flag;   // host-mapped sticky error word
 };
 
 __device__ __forceinline__ void ps_set_byte(uint32_t (&w)[4], uint32_t k, uint32_t v)
@@ -181,6 +182,243 @@ __global__ void __launch_bounds__(1024) core_sweep_kernel(core_sweep_args a)
     }
 }
 
+// ---------------------------------------------------------------------------
+// Wave-per-row sweep (pitch <= 1024: one wavefront holds a whole site row, 16 cells
+// per lane).  No workgroup barriers: the four waves of a block work on their own
+// rows and synchronise only through the in-order LDS queue of their own wave.
+//
+// A wave takes PS_ROWS consecutive site rows per iteration (their loads are in
+// flight together and the 16 parent indices of a lane are shared by all rows).
+// Events are sparse (about 5 % of the cells at the default rates), so per row:
+//   1. one Philox call per lane gives the 16 level-1 bytes; a SWAR compare finds
+//      the candidate bytes (<= bC);
+//   2. a candidate whose byte lies strictly inside one "mutate only" interval of the
+//      plan is decided by the byte alone (the 24 refinement bits cannot change the
+//      outcome) and its allele is written straight into the LDS row;
+//   3. the remaining candidates (byte holds a threshold, or may receive a donor
+//      allele) are compacted into a wave-private LDS queue with ballot/mbcnt.
+// The queue is drained once per PS_ROWS rows, 64 entries at a time with every lane
+// busy: level-2 Philox, exact classification, mutation bytes into the LDS rows, HR
+// donors read from the post-mutation rows and written back after all reads.
+// The host only selects this kernel when the queue cannot overflow in practice
+// (mean + 12 sigma of the entry count fits); an overflow raises a sticky error flag.
+// ---------------------------------------------------------------------------
+#define PS_ROWS 4u
+#define PS_QCAP 640u
+
+__device__ __forceinline__ void ps_wave_sync()
+{
+    // LDS operations of one wave complete in issue order; this only stops the
+    // compiler from moving LDS accesses across the phase boundary.
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+__device__ __forceinline__ uint32_t ps_lane_prefix(uint64_t bal)
+{
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
+}
+
+// flags (0x80 per byte) of the bytes of w that are < c, for 1 <= c <= 128
+__device__ __forceinline__ uint32_t ps_bytes_lt(uint32_t w, uint32_t c4 /* c * 0x01010101 */)
+{
+    const uint32_t H = 0x80808080u;
+    return ~(((w | H) - c4) | w) & H;
+}
+
+// candidate cells of a lane in "permuted" order: cell k = 4*j + b (dword j, byte b)
+// is bit 8*b + 7 - j
+__device__ __forceinline__ uint32_t ps_candidates_swar(const ps_u4 &l1, uint32_t c4)
+{
+    return ps_bytes_lt(l1.x, c4) | (ps_bytes_lt(l1.y, c4) >> 1) | (ps_bytes_lt(l1.z, c4) >> 2)
+           | (ps_bytes_lt(l1.w, c4) >> 3);
+}
+
+template <bool DO_GATHER, bool DO_MUT, bool DO_HR>
+__global__ void __launch_bounds__(256) core_sweep_wave_kernel(core_sweep_args a)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    uint8_t *rowbuf = lds + wave * (PS_ROWS * a.pitch + PS_QCAP * 4u);
+    uint32_t *q = (uint32_t *)(rowbuf + PS_ROWS * a.pitch);
+    const ps_core_plan pl = a.plan;
+    const bool events = pl.has_events && (DO_MUT || DO_HR);
+    const bool has_chunk = lane < a.cpr;
+    const uint32_t i0 = lane * 16u;
+    const uint32_t nvalid = (i0 >= a.N) ? 0u : min(16u, a.N - i0);
+    uint32_t vperm = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < 16; k++)
+        if (k < nvalid) vperm |= 1u << (8u * (k & 3u) + 7u - (k >> 2));
+    const uint32_t c4 = (pl.bC + 1u) * 0x01010101u;
+    // byte-level intervals that decide a mutation without refinement
+    const uint32_t t0b = pl.T[0] >> 24, t1b = pl.T[1] >> 24, t2b = pl.T[2] >> 24;
+
+    uint32_t pidx[16];
+    if (DO_GATHER) {
+        // cells beyond N gather the first padding byte of the row, which is always 0
+#pragma unroll
+        for (uint32_t k = 0; k < 16; k++) pidx[k] = (k < nvalid) ? a.idx[i0 + k] : min(a.N, a.pitch - 1u);
+    }
+
+    const uint32_t wpb = blockDim.x >> 6;
+    const uint32_t nwaves = gridDim.x * wpb;
+    for (uint32_t r0 = (blockIdx.x * wpb + wave) * PS_ROWS; r0 < a.rows; r0 += nwaves * PS_ROWS) {
+        const uint32_t nr = min(PS_ROWS, a.rows - r0);
+        uint4 v[PS_ROWS];
+#pragma unroll
+        for (uint32_t rr = 0; rr < PS_ROWS; rr++) {
+            v[rr] = make_uint4(0, 0, 0, 0);
+            if (rr < nr && has_chunk) v[rr] = *(const uint4 *)(a.state + (size_t)(r0 + rr) * a.pitch + i0);
+        }
+        if (DO_GATHER) {
+#pragma unroll
+            for (uint32_t rr = 0; rr < PS_ROWS; rr++)
+                if (rr < nr && has_chunk) *(uint4 *)(rowbuf + rr * a.pitch + i0) = v[rr];
+            ps_wave_sync();
+        }
+
+        uint32_t qn = 0;        // wave-uniform number of queued candidate cells
+#pragma unroll
+        for (uint32_t rr = 0; rr < PS_ROWS; rr++) {
+            if (rr < nr) {
+                uint8_t *row = rowbuf + rr * a.pitch;
+                const uint32_t site = a.site_offset + r0 + rr;
+                uint4 d = v[rr];
+                if (DO_GATHER) {
+                    uint32_t w[4];
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        uint32_t x = 0;
+#pragma unroll
+                        for (int b = 0; b < 4; b++) x |= (uint32_t)row[pidx[4 * j + b]] << (8 * b);
+                        w[j] = x;
+                    }
+                    d = make_uint4(w[0], w[1], w[2], w[3]);
+                }
+                uint32_t cm = 0;
+                ps_u4 l1 = { 0, 0, 0, 0 };
+                if (events) {
+                    l1 = ps_philox(site, lane, a.gen, PS_STREAM_CORE_L1, a.k0, a.k1);
+                    cm = ps_candidates_swar(l1, c4) & vperm;
+                }
+                // the LDS row becomes the child row; every gather read precedes this store
+                if (DO_GATHER) ps_wave_sync();
+                if (has_chunk && (DO_GATHER || events)) *(uint4 *)(row + i0) = d;
+#if !defined(PS_ABLATE) || PS_ABLATE > 1
+                if (events) {
+                    // compact every candidate cell of the row into the wave queue
+                    for (;;) {
+                        const bool act = cm != 0u;
+                        const uint64_t bal = __ballot(act);
+                        if (bal == 0ull) break;
+                        if (act) {
+                            const uint32_t p = __builtin_ctz(cm);
+                            cm &= cm - 1u;
+                            const uint32_t b = p >> 3, j = 7u - (p & 7u);
+                            const uint32_t sel = ((j & 1u) * 4u + b) | 0x0c0c0c00u;
+                            const uint32_t byte = (j & 2u) ? __builtin_amdgcn_perm(l1.w, l1.z, sel)
+                                                           : __builtin_amdgcn_perm(l1.y, l1.x, sel);
+                            const uint32_t pos = qn + ps_lane_prefix(bal);
+                            if (pos < PS_QCAP) q[pos] = (i0 + 4u * j + b) | (rr << 10) | (byte << 12);
+                        }
+                        qn += (uint32_t)__popcll(bal);
+                    }
+                }
+#else
+                if (cm == 0xFFFFFFFFu) qn = 1;   // keep the detection alive
+#endif
+            }
+        }
+        ps_wave_sync();
+
+#if defined(PS_ABLATE) && PS_ABLATE < 3
+        if (qn == 12345u) q[lane] = qn;
+#else
+        if (events) {
+            if (qn > PS_QCAP) {
+                if (lane == 0) atomicOr(a.overflow_flag, 1u);
+                qn = PS_QCAP;
+            }
+            // dense pass: a candidate whose byte lies strictly inside one "mutate only"
+            // interval is decided by the byte; the others are compacted in place to the
+            // front of the queue (the write index never passes the read index)
+            uint32_t n2 = 0;
+            for (uint32_t base = 0; base < qn; base += 64u) {
+                const uint32_t e = base + lane;
+                const bool valid = e < qn;
+                const uint32_t ent = valid ? q[e] : 0u;
+                const uint32_t byte = (ent >> 12) & 0xFFu;
+                uint32_t allele = 0;
+                if (byte < t0b) allele = 2u;
+                else if (byte > t0b && byte < t1b) allele = 4u;
+                else if (byte > t1b && byte < t2b) allele = 8u;
+                const bool amb = valid && allele == 0u;
+                if (DO_MUT && valid && allele) rowbuf[((ent >> 10) & 3u) * a.pitch + (ent & 1023u)] = (uint8_t)allele;
+                const uint64_t bal = __ballot(amb);
+                if (amb) q[n2 + ps_lane_prefix(bal)] = ent;
+                n2 += (uint32_t)__popcll(bal);
+            }
+            ps_wave_sync();
+            // exact pass over the undecided cells: level-2 Philox, 32-bit thresholds
+            for (uint32_t base = 0; base < n2; base += 64u) {
+                const uint32_t e = base + lane;
+                if (e < n2) {
+                    const uint32_t ent = q[e];
+                    const uint32_t cellidx = ent & 1023u, rr = (ent >> 10) & 3u, byte = (ent >> 12) & 0xFFu;
+                    const ps_u4 l2 = ps_philox(a.site_offset + r0 + rr, cellidx, a.gen, PS_STREAM_CORE_L2, a.k0, a.k1);
+                    const ps_cell cell = ps_classify((byte << 24) | (l2.x >> 8), pl);
+                    if (DO_MUT && cell.mut) rowbuf[rr * a.pitch + cellidx] = (uint8_t)cell.mut;
+                    if (DO_HR) {
+                        uint32_t out = 0;
+                        if (cell.hr) {
+                            uint32_t donor = ps_mulhi(l2.y, a.N - 1u);
+                            donor += (donor >= cellidx) ? 1u : 0u;       // population.rs:618
+                            out = (ent & 4095u) | (donor << 12) | 0x80000000u;
+                        }
+                        q[e] = out;
+                    }
+                }
+            }
+            if (DO_HR) {
+                ps_wave_sync();   // the LDS rows are now the post-mutation snapshot (population.rs:693-695)
+                for (uint32_t base = 0; base < n2; base += 64u) {
+                    const uint32_t e = base + lane;
+                    if (e < n2) {
+                        const uint32_t ent = q[e];
+                        if (ent >> 31) {
+                            const uint32_t rr = (ent >> 10) & 3u, donor = (ent >> 12) & 1023u;
+                            q[e] = (ent & 4095u) | ((uint32_t)rowbuf[rr * a.pitch + donor] << 12) | 0x80000000u;
+                        }
+                    }
+                }
+                ps_wave_sync();   // all donor reads are done; now apply the copies
+                for (uint32_t base = 0; base < n2; base += 64u) {
+                    const uint32_t e = base + lane;
+                    if (e < n2) {
+                        const uint32_t ent = q[e];
+                        if (ent >> 31) rowbuf[((ent >> 10) & 3u) * a.pitch + (ent & 1023u)] = (uint8_t)((ent >> 12) & 0xFFu);
+                    }
+                }
+            }
+            ps_wave_sync();
+        }
+#endif
+
+        if (has_chunk) {
+#pragma unroll
+            for (uint32_t rr = 0; rr < PS_ROWS; rr++) {
+                if (rr < nr) {
+                    const uint4 o = (DO_GATHER || events) ? *(const uint4 *)(rowbuf + rr * a.pitch + i0) : v[rr];
+                    *(uint4 *)(a.state + (size_t)(r0 + rr) * a.pitch + i0) = o;
+                }
+            }
+        }
+        ps_wave_sync();   // the next iteration overwrites the LDS rows and the queue
+    }
+}
+
 // clonal start: every individual gets allele_vec[site] (population.rs:206-212)
 __global__ void core_init_kernel(uint8_t *state, const uint8_t *allele_vec, uint32_t N,
                                  uint32_t pitch, uint32_t rows)
@@ -260,30 +498,43 @@ __global__ void __launch_bounds__(1024) core_pair_counts_tiled(
     const uint32_t RS = W + 4u;
     const uint32_t tid = threadIdx.x;
     const uint32_t sites_per_tile = W * 8u;
+    const uint64_t kbase = (uint64_t)blockIdx.y * A * blockDim.x + tid;
     uint32_t pi[A], pj[A], acc[A];
-    uint64_t pk[A];
 #pragma unroll
     for (int q = 0; q < A; q++) {
-        const uint64_t k = ((uint64_t)blockIdx.y * A + q) * blockDim.x + tid;
-        pk[q] = k;
+        const uint64_t k = kbase + (uint64_t)q * blockDim.x;
         acc[q] = 0;
         if (k < P) { pi[q] = r1[k] * RS; pj[q] = r2[k] * RS; }
-        else { pi[q] = 0; pj[q] = 0; }
+        else { pi[q] = 0; pj[q] = 0; }     // same row twice: contributes nothing
     }
     for (uint32_t t = 0; t < tiles_per_range; t++) {
         const uint32_t s0 = (blockIdx.x * tiles_per_range + t) * sites_per_tile;
         if (s0 >= rows) break;
         __syncthreads();
-        for (uint32_t e = tid; e < N * W; e += blockDim.x) {
-            const uint32_t w = e / N, i = e % N;   // consecutive lanes -> consecutive individuals
-            uint32_t packed = 0;
+        // work item = (4 consecutive individuals, 32 consecutive sites): 32 independent dword
+        // loads (a wave reads 256 contiguous bytes of a site row), repacked into one
+        // 16-byte nibble string per individual
+        const uint32_t quads = (N + 3u) >> 2, sgs = W >> 2;
+        for (uint32_t it = tid; it < quads * sgs; it += blockDim.x) {
+            const uint32_t qd = it % quads, sg = it / quads;
+            const uint32_t sb = s0 + 32u * sg;
+            const uint8_t *base = state + (size_t)sb * pitch + 4u * qd;
+            uint32_t v[32];
 #pragma unroll
-            for (int b = 0; b < 8; b++) {
-                const uint32_t s = s0 + w * 8u + b;
-                const uint32_t v = (s < rows) ? (uint32_t)state[(size_t)s * pitch + i] : 0u;
-                packed |= (v & 0xFu) << (4 * b);
+            for (int b = 0; b < 32; b++)
+                v[b] = (sb + b < rows) ? *(const uint32_t *)(base + (size_t)b * pitch) : 0u;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                uint32_t o[4];
+#pragma unroll
+                for (int m = 0; m < 4; m++) {
+                    uint32_t x = 0;
+#pragma unroll
+                    for (int b = 0; b < 8; b++) x |= ((v[8 * m + b] >> (8 * j)) & 0xFu) << (4 * b);
+                    o[m] = x;
+                }
+                if (4u * qd + j < N) *(uint4 *)&T[(4u * qd + j) * RS + 4u * sg] = make_uint4(o[0], o[1], o[2], o[3]);
             }
-            T[i * RS + w] = packed;
         }
         __syncthreads();
 #pragma unroll
@@ -298,8 +549,10 @@ __global__ void __launch_bounds__(1024) core_pair_counts_tiled(
         }
     }
 #pragma unroll
-    for (int q = 0; q < A; q++)
-        if (pk[q] < P && acc[q]) atomicAdd(&out[pk[q]], acc[q]);
+    for (int q = 0; q < A; q++) {
+        const uint64_t k = kbase + (uint64_t)q * blockDim.x;
+        if (k < P && acc[q]) atomicAdd(&out[k], acc[q]);
+    }
 }
 
 // generic form (any N, any byte values): one thread per pair, blockIdx.y splits the sites

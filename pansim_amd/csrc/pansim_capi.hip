@@ -179,7 +179,7 @@ struct ps_population {
     acc_dims d{};
     uint64_t *G[2] = { nullptr, nullptr };
     uint64_t *I[2] = { nullptr, nullptr };
-    uint64_t *Isnap = nullptr;
+    uint16_t *glist = nullptr;           // rank/select tables of HGT donors, N x G
     uint32_t *cnt = nullptr;
     int cur = 0;
     ps_acc_plan aplan{};
@@ -191,6 +191,9 @@ struct ps_population {
     void *d_pairs = nullptr;         // r1|r2|outA|outB
     uint64_t pairs_cap = 0;
     uint32_t lds_limit = 160 * 1024;
+    uint32_t sweep_blocks_per_cu = 6;   // wave-per-row sweep: resident 256-thread blocks per CU
+    bool force_block_sweep = false;     // tests: run the block-per-row sweep on small populations
+    uint32_t *h_flag = nullptr, *d_flag = nullptr;   // host-mapped sticky device error word
 };
 
 static int use_device(const ps_population *p)
@@ -204,10 +207,11 @@ extern "C" void ps_population_destroy(ps_population *p)
     if (!p) return;
     (void)hipSetDevice(p->device);
     if (p->stream) (void)hipStreamSynchronize(p->stream);
-    void *ptrs[] = { p->state, p->G[0], p->G[1], p->I[0], p->I[1], p->Isnap, p->cnt, p->d_idx,
+    void *ptrs[] = { p->state, p->G[0], p->G[1], p->I[0], p->I[1], p->glist, p->cnt, p->d_idx,
                      p->d_log1p, p->d_num_genes, p->d_logw, p->d_pairs };
     for (void *q : ptrs)
         if (q) (void)hipFree(q);
+    if (p->h_flag) (void)hipHostFree(p->h_flag);
     if (p->stream) (void)hipStreamDestroy(p->stream);
     delete p;
 }
@@ -225,8 +229,15 @@ static int pop_create_impl(const ps_config *cfg, const uint8_t *init_vec, ps_pop
     }
     PSCHK(use_device(p));
     HIPCHK(hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking));
+    if (const char *e = getenv("PANSIM_SWEEP_BLOCKS_PER_CU")) {
+        const int v = atoi(e);
+        if (v >= 1 && v <= 8) p->sweep_blocks_per_cu = (uint32_t)v;
+    }
     const uint64_t N = cfg->pop_size, C = cfg->ncols;
     HIPCHK(hipMalloc(&p->d_idx, std::max<uint64_t>(N, 1) * sizeof(uint32_t)));
+    HIPCHK(hipHostMalloc(&p->h_flag, sizeof(uint32_t), hipHostMallocMapped));
+    *p->h_flag = 0;
+    HIPCHK(hipHostGetDevicePointer((void **)&p->d_flag, p->h_flag, 0));
     uint8_t *d_vec = nullptr;
     HIPCHK(hipMalloc(&d_vec, std::max<uint64_t>(C, 1)));
     if (C) HIPCHK(hipMemcpyAsync(d_vec, init_vec, C, hipMemcpyHostToDevice, p->stream));
@@ -251,7 +262,8 @@ static int pop_create_impl(const ps_config *cfg, const uint8_t *init_vec, ps_pop
             HIPCHK(hipMalloc(&p->G[k], nG));
             HIPCHK(hipMalloc(&p->I[k], nI));
         }
-        HIPCHK(hipMalloc(&p->Isnap, nI));
+        if (C > 65536) return ps_fail(PS_ERR_INVALID, "at most 65536 accessory genes are supported");
+        HIPCHK(hipMalloc(&p->glist, std::max<uint64_t>(N * C, 1) * sizeof(uint16_t)));
         HIPCHK(hipMalloc(&p->cnt, std::max<uint64_t>(N, 1) * PS_MAX_COMP * sizeof(uint32_t)));
         HIPCHK(hipMalloc(&p->d_log1p, std::max<uint64_t>(C, 1) * sizeof(double)));
         HIPCHK(hipMalloc(&p->d_num_genes, std::max<uint64_t>(N, 1) * sizeof(int32_t)));
@@ -310,11 +322,43 @@ extern "C" int ps_init_vector(uint64_t seed, int core, uint64_t col_offset, uint
     return PS_OK;
 }
 
+// device-side sticky errors become loud host errors at every synchronisation point
+static int check_device_flag(ps_population *p)
+{
+    if (p->h_flag && *p->h_flag != 0)
+        return ps_fail(PS_ERR_STATE, "core sweep candidate queue overflowed (flag %u): results are invalid",
+                       *p->h_flag);
+    return PS_OK;
+}
+
+static int sync_checked(ps_population *p)
+{
+    HIPCHK(hipStreamSynchronize(p->stream));
+    return check_device_flag(p);
+}
+
 extern "C" int ps_sync(ps_population *p)
 {
     if (!p) return ps_fail(PS_ERR_INVALID, "null handle");
     PSCHK(use_device(p));
-    HIPCHK(hipStreamSynchronize(p->stream));
+    return sync_checked(p);
+}
+
+extern "C" int ps_set_tuning(ps_population *p, const char *key, int64_t value)
+{
+    if (!p || !key) return ps_fail(PS_ERR_INVALID, "null argument");
+    const std::string k(key);
+    if (k == "sweep_blocks_per_cu") {
+        if (value < 1 || value > 8) return ps_fail(PS_ERR_INVALID, "sweep_blocks_per_cu must be 1..8");
+        p->sweep_blocks_per_cu = (uint32_t)value;
+    } else if (k == "force_block_sweep") {
+        p->force_block_sweep = value != 0;
+    } else if (k == "lds_limit") {
+        if (value < 1024 || value > 160 * 1024) return ps_fail(PS_ERR_INVALID, "lds_limit must be 1 KiB..160 KiB");
+        p->lds_limit = (uint32_t)value;
+    } else {
+        return ps_fail(PS_ERR_INVALID, "unknown tuning key %s", key);
+    }
     return PS_OK;
 }
 
@@ -414,22 +458,45 @@ extern "C" int ps_set_rates(ps_population *p, int n_comp, const double *lam_mut,
 // ---------------------------------------------------------------------------
 // core sweep launch
 // ---------------------------------------------------------------------------
-template <bool WAVE, bool GA, bool MU, bool HR>
-static int launch_core_sweep_t(ps_population *p, const core_sweep_args &a, hipStream_t st)
+template <bool GA, bool MU, bool HR>
+static int launch_core_sweep_wave(ps_population *p, const core_sweep_args &a, hipStream_t st)
 {
-    const uint32_t block = WAVE ? 256u : 1024u;
-    const uint32_t rpb = WAVE ? block / 64u : 1u;
+    const uint32_t block = 256u, wpb = block / 64u;
+    const uint32_t lds = wpb * (PS_ROWS * a.pitch + PS_QCAP * 4u);
+    const uint32_t want = (a.rows + wpb * PS_ROWS - 1) / (wpb * PS_ROWS);
+    const uint32_t grid = std::max(1u, std::min(want, 256u * p->sweep_blocks_per_cu));
+    hipLaunchKernelGGL((core_sweep_wave_kernel<GA, MU, HR>), dim3(grid), dim3(block), lds, st, a);
+    HIPCHK(hipGetLastError());
+    return PS_OK;
+}
+
+// The wave-per-row sweep queues every candidate cell (level-1 byte <= bC) of PS_ROWS
+// rows.  It is selected only when that many cells fit the queue with 10 standard
+// deviations to spare (and the SWAR byte compare applies: bC < 127).
+static bool wave_sweep_eligible(const ps_population *p, bool mu, bool hr)
+{
+    if (p->pitch > 1024 || p->force_block_sweep) return false;
+    const ps_core_plan &pl = p->cplan;
+    if (!pl.has_events || (!mu && !hr)) return true;
+    if (pl.bC > 126) return false;
+    const double m = (double)PS_ROWS * (double)p->cfg.pop_size * (double)(pl.bC + 1u) / 256.0;
+    return m + 10.0 * std::sqrt(m) + 16.0 <= (double)PS_QCAP;
+}
+
+template <bool GA, bool MU, bool HR>
+static int launch_core_sweep_block(ps_population *p, const core_sweep_args &a, hipStream_t st)
+{
+    const uint32_t block = 1024u;
     const uint32_t hrm_bytes = (a.cpr * 2u + 15u) & ~15u;
-    const uint32_t lds = rpb * (2u * a.pitch + hrm_bytes);
+    const uint32_t lds = 2u * a.pitch + hrm_bytes;
     if (lds > p->lds_limit)
         return ps_fail(PS_ERR_INVALID, "pop_size %u needs %u bytes of LDS per row (limit %u)", a.N, lds,
                        p->lds_limit);
-    auto kern = core_sweep_kernel<WAVE, GA, MU, HR>;
+    auto kern = core_sweep_kernel<false, GA, MU, HR>;
     if (lds > 64 * 1024)
         HIPCHK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    const uint32_t want = (a.rows + rpb - 1) / rpb;
-    const uint32_t cap = WAVE ? 256u * 8u : 256u * (lds > 80 * 1024 ? 1u : 2u);
-    const uint32_t grid = std::max(1u, std::min(want, cap));
+    const uint32_t cap = 256u * (lds > 80 * 1024 ? 1u : 2u);
+    const uint32_t grid = std::max(1u, std::min(a.rows, cap));
     hipLaunchKernelGGL(kern, dim3(grid), dim3(block), lds, st, a);
     HIPCHK(hipGetLastError());
     return PS_OK;
@@ -452,19 +519,17 @@ static int launch_core_sweep(ps_population *p, const uint32_t *d_idx, uint32_t g
     a.k1 = (uint32_t)(p->cfg.seed >> 32);
     a.plan = p->cplan;
     if (!mu && !hr) a.plan.has_events = 0;
-    const bool wave = p->pitch <= 1024;
-#define PS_DISPATCH(W, G_, M_, H_) \
-    if (wave == W && ga == G_ && mu == M_ && hr == H_) return launch_core_sweep_t<W, G_, M_, H_>(p, a, st);
-    PS_DISPATCH(true, true, false, false)
-    PS_DISPATCH(true, false, true, false)
-    PS_DISPATCH(true, false, false, true)
-    PS_DISPATCH(true, true, true, false)
-    PS_DISPATCH(true, true, true, true)
-    PS_DISPATCH(false, true, false, false)
-    PS_DISPATCH(false, false, true, false)
-    PS_DISPATCH(false, false, false, true)
-    PS_DISPATCH(false, true, true, false)
-    PS_DISPATCH(false, true, true, true)
+    const bool wave = wave_sweep_eligible(p, mu, hr);
+    a.overflow_flag = p->d_flag;
+#define PS_DISPATCH(G_, M_, H_)                                              \
+    if (ga == G_ && mu == M_ && hr == H_)                                    \
+        return wave ? launch_core_sweep_wave<G_, M_, H_>(p, a, st)           \
+                    : launch_core_sweep_block<G_, M_, H_>(p, a, st);
+    PS_DISPATCH(true, false, false)
+    PS_DISPATCH(false, true, false)
+    PS_DISPATCH(false, false, true)
+    PS_DISPATCH(true, true, false)
+    PS_DISPATCH(true, true, true)
 #undef PS_DISPATCH
     return ps_fail(PS_ERR_INVALID, "unsupported operator combination");
 }
@@ -501,18 +566,18 @@ static int launch_acc_hgt(ps_population *p, uint32_t gen, hipStream_t st)
     bool any = false;
     for (int c = 0; c < p->aplan.n_comp; c++) any |= p->aplan.lam_rec[c] != 0.0;
     if (!any) return PS_OK;
-    const uint64_t nI = (uint64_t)p->d.N * p->d.GW * 8;
-    HIPCHK(hipMemcpyAsync(p->Isnap, p->I[p->cur], nI, hipMemcpyDeviceToDevice, st));
-    acc_comp_counts_kernel<<<(p->d.N + 255) / 256, 256, 0, st>>>(p->Isnap, p->cnt, p->d, p->aplan);
+    // the gene lists ARE the pre-recombination snapshot the donors are read from
+    acc_gene_lists_kernel<<<dim3(p->d.N, p->aplan.n_comp), 64, 0, st>>>(p->I[p->cur], p->glist, p->cnt,
+                                                                         p->d, p->aplan);
     for (int c = 0; c < p->aplan.n_comp; c++) {
         if (p->aplan.lam_rec[c] == 0.0) continue;      // population.rs:558
         const uint64_t K = hs_poisson((double)p->d.N * p->aplan.lam_rec[c], p->cfg.seed,
                                       PS_STREAM_HGT_COUNT | ((uint32_t)c << 8), gen);
         if (K == 0) continue;
         const uint32_t blocks = (uint32_t)std::min<uint64_t>((K + 255) / 256, 256 * 16);
-        acc_hgt_kernel<<<blocks, 256, 0, st>>>(p->Isnap, p->cnt, p->G[p->cur], p->I[p->cur], p->d,
-                                               p->aplan.comp_begin[c], p->aplan.comp_end[c], (uint32_t)c,
-                                               K, gen, (uint32_t)p->cfg.seed, (uint32_t)(p->cfg.seed >> 32));
+        acc_hgt_kernel<<<blocks, 256, 0, st>>>(p->glist, p->cnt, p->G[p->cur], p->I[p->cur], p->d,
+                                               p->aplan.comp_begin[c], (uint32_t)c, K, gen,
+                                               (uint32_t)p->cfg.seed, (uint32_t)(p->cfg.seed >> 32));
     }
     HIPCHK(hipGetLastError());
     return PS_OK;
@@ -542,8 +607,7 @@ extern "C" int ps_next_generation(ps_population *p, const uint32_t *sample)
     PSCHK(use_device(p));
     PSCHK(upload_idx(p, sample));
     PSCHK(step_device(p, p->d_idx, 0, true, false, false, p->stream));
-    HIPCHK(hipStreamSynchronize(p->stream));
-    return PS_OK;
+    return sync_checked(p);
 }
 
 extern "C" int ps_mutate_alleles(ps_population *p, uint32_t generation)
@@ -552,8 +616,7 @@ extern "C" int ps_mutate_alleles(ps_population *p, uint32_t generation)
     if (!p->rates_set) return ps_fail(PS_ERR_STATE, "ps_set_rates has not been called");
     PSCHK(use_device(p));
     PSCHK(step_device(p, nullptr, generation, false, true, false, p->stream));
-    HIPCHK(hipStreamSynchronize(p->stream));
-    return PS_OK;
+    return sync_checked(p);
 }
 
 extern "C" int ps_recombine(ps_population *p, uint32_t generation)
@@ -562,8 +625,7 @@ extern "C" int ps_recombine(ps_population *p, uint32_t generation)
     if (!p->rates_set) return ps_fail(PS_ERR_STATE, "ps_set_rates has not been called");
     PSCHK(use_device(p));
     PSCHK(step_device(p, nullptr, generation, false, false, true, p->stream));
-    HIPCHK(hipStreamSynchronize(p->stream));
-    return PS_OK;
+    return sync_checked(p);
 }
 
 extern "C" int ps_step(ps_population *p, uint32_t generation, const uint32_t *sample, int do_recombine)
@@ -573,8 +635,7 @@ extern "C" int ps_step(ps_population *p, uint32_t generation, const uint32_t *sa
     PSCHK(use_device(p));
     PSCHK(upload_idx(p, sample));
     PSCHK(step_device(p, p->d_idx, generation, true, true, do_recombine != 0, p->stream));
-    HIPCHK(hipStreamSynchronize(p->stream));
-    return PS_OK;
+    return sync_checked(p);
 }
 
 // ---------------------------------------------------------------------------
@@ -730,7 +791,7 @@ static int pair_counts_device(ps_population *p, uint64_t P, const uint32_t *d_r1
         for (uint32_t w : { 32u, 16u, 8u, 4u })
             if ((uint64_t)N * (w + 4) * 4 <= p->lds_limit) { W = w; break; }
         if (p->nibble_safe && W) {
-            constexpr int A = 32;
+            constexpr int A = 16;
             const uint32_t lds = N * (W + 4) * 4;
             auto kern = core_pair_counts_tiled<A>;
             if (lds > 64 * 1024)
@@ -1342,7 +1403,7 @@ extern "C" int ps_sim_sync(ps_sim *s)
     PSCHK(use_device(s->core));
     HIPCHK(hipStreamSynchronize(s->acc->stream));
     HIPCHK(hipStreamSynchronize(s->core->stream));
-    return PS_OK;
+    return check_device_flag(s->core);
 }
 
 extern "C" ps_population *ps_sim_core(ps_sim *s) { return s ? s->core : nullptr; }

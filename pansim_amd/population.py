@@ -247,3 +247,7 @@ class Population:
 
     def sync(self):
         check(self._lib.ps_sync(self._h))
+
+    def set_tuning(self, key, value):
+        """launch tuning / test hooks of ps_set_tuning (no reference counterpart)"""
+        check(self._lib.ps_set_tuning(self._h, key.encode(), int(value)))

@@ -394,3 +394,27 @@ def test_site_shards_equal_unsharded(pa):
     assert np.array_equal(np.concatenate(parts, axis=1), want)
     assert np.array_equal(cnt, cnt_full)
     full.close()
+
+
+# ----------------------------------------------------------------------------- kernel variants
+@pytest.mark.parametrize("N,L,lm,lh", [(1000, 300, 20000.0, 20000.0), (1000, 200, 150.0, 15.0), (100, 700, 300.0, 300.0)])
+def test_block_sweep_equals_wave_sweep(pa, orc, N, L, lm, lh):
+    # the block-per-row sweep (large populations) and the wave-per-row sweep (with its queue
+    # overflowing at the heavy rates) implement the same keyed arithmetic
+    rng = np.random.default_rng(N + L)
+    m0 = _rand_core(rng, N, L)
+    sample = rng.integers(0, N, N).astype(np.uint32)
+    plan = orc.core_plan(lm, lh, 1000)
+    want = orc.next_generation(m0, sample)
+    orc.mutate_core(want, 0, 5, 2, plan)
+    orc.recombine_core(want, 0, 5, 2, plan)
+    for force in (0, 1):
+        for bpc in (1, 8):
+            pop = pa.Population(N, L, 4, True, 0.0, 5, 0, global_cols=1000)
+            pop.set_tuning("force_block_sweep", force)
+            pop.set_tuning("sweep_blocks_per_cu", bpc)
+            pop.set_rates([lm], [lh])
+            pop.load_matrix(m0)
+            pop.step(2, sample, True)
+            assert np.array_equal(pop.read_matrix(), want)
+            pop.close()
