@@ -23,10 +23,22 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s
 
 
+def host_cores():
+    """CPU threads this process may actually use: affinity mask capped by the cgroup CPU quota."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
+
+
 def cpu_baseline(kw, seed, budget_s=20.0):
     """Reference algorithm (event-driven, rows in parallel like rayon) timed on the host cores."""
     from oracle import oracle as o
-    threads = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    threads = host_cores()
     sim = o.RefSim(o.make_params(**kw), seed=seed, threads=threads)
     t0 = time.perf_counter()
     sim.generation(0)                      # warm-up generation (page faults, first touch)
