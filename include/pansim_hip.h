@@ -145,7 +145,8 @@ int ps_write(ps_population *p, const char *outpref);
 /* wait for all queued device work of this handle */
 int ps_sync(ps_population *p);
 /* Launch tuning / test hooks (no reference counterpart).  Keys: "sweep_blocks_per_cu"
- * (resident 256-thread blocks per CU of the wave-per-row sweep, 1..8),
+ * (resident 256-thread blocks per CU of the wave-per-row sweep, 1..8), "sweep_rows"
+ * (site rows a wave of that sweep takes per iteration, 2..4),
  * "force_block_sweep" (0/1: use the block-per-row sweep even when a row fits one
  * wavefront), "lds_limit" (bytes of LDS a workgroup may use). */
 int ps_set_tuning(ps_population *p, const char *key, int64_t value);

@@ -159,29 +159,44 @@ __global__ void __launch_bounds__(64) acc_gene_lists_kernel(const uint64_t *accI
     if (lane == 0) cnt[(uint64_t)c * d.N + i] = base;
 }
 
-// HGT events of one compartment (population.rs:544-751 accessory path): event e
-// picks a uniform donor, a uniform other recipient and a uniform gene among the
-// donor's present genes of the compartment IN THE SNAPSHOT (the gene lists); the
-// recipient gains the gene (value always 1, :632) -- an idempotent OR, so the order
-// of events does not matter.
-__global__ void __launch_bounds__(256) acc_hgt_kernel(const uint16_t *list, const uint32_t *cnt,
-                                                      uint64_t *dstG, uint64_t *dstI, acc_dims d,
-                                                      uint32_t gb, uint32_t comp, uint64_t K,
-                                                      uint32_t gen, uint32_t k0, uint32_t k1)
+// HGT events (population.rs:544-751 accessory path), all compartments in one launch:
+// event e of compartment c picks a uniform donor, a uniform other recipient and a
+// uniform gene among the donor's present genes of the compartment IN THE SNAPSHOT
+// (the gene lists); the recipient gains the gene (value always 1, :632) -- an
+// idempotent OR, so the order of events does not matter.  Only the individual-major
+// view is edited here; acc_i_to_g_kernel rebuilds the gene-major view afterwards.
+struct acc_hgt_args {
+    const uint16_t *list;
+    const uint32_t *cnt;
+    uint64_t *dstI;
+    acc_dims d;
+    uint32_t n_comp;
+    uint32_t gb[PS_MAX_COMP];
+    uint64_t K[PS_MAX_COMP];      // events per compartment (0 = skipped)
+    uint32_t gen, k0, k1;
+};
+
+__global__ void __launch_bounds__(256) acc_hgt_kernel(acc_hgt_args a)
 {
-    const uint32_t stream = PS_STREAM_HGT | (comp << 8);
-    for (uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; e < K;
-         e += (uint64_t)gridDim.x * blockDim.x) {
-        const ps_u4 r = ps_philox((uint32_t)e, (uint32_t)(e >> 32), gen, stream, k0, k1);
+    const acc_dims d = a.d;
+    uint64_t total = 0;
+    for (uint32_t c = 0; c < a.n_comp; c++) total += a.K[c];
+    for (uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total;
+         t += (uint64_t)gridDim.x * blockDim.x) {
+        uint32_t comp = 0;
+        uint64_t e = t;
+        while (comp + 1 < a.n_comp && e >= a.K[comp]) { e -= a.K[comp]; comp++; }
+        const ps_u4 r = ps_philox((uint32_t)e, (uint32_t)(e >> 32), a.gen, PS_STREAM_HGT | (comp << 8), a.k0, a.k1);
         const uint32_t dn = ps_mulhi(r.x, d.N);
         uint32_t rc = ps_mulhi(r.y, d.N - 1u);
         rc += (rc >= dn) ? 1u : 0u;                         // population.rs:618
-        const uint32_t n = cnt[(uint64_t)comp * d.N + dn];
+        const uint32_t n = a.cnt[(uint64_t)comp * d.N + dn];
         if (n == 0) continue;                               // population.rs:672
         const uint32_t j = ps_mulhi(r.z, n);
-        const uint32_t gene = list[(uint64_t)dn * d.G + gb + j];
-        atomicOr((unsigned long long *)&dstG[(uint64_t)gene * d.W + (rc >> 6)], 1ull << (rc & 63u));
-        atomicOr((unsigned long long *)&dstI[(uint64_t)rc * d.GW + (gene >> 6)], 1ull << (gene & 63u));
+        const uint32_t gene = a.list[(uint64_t)dn * d.G + a.gb[comp] + j];
+        // 32-bit atomic on the half word that holds the bit
+        uint32_t *w32 = (uint32_t *)&a.dstI[(uint64_t)rc * d.GW + (gene >> 6)] + ((gene >> 5) & 1u);
+        atomicOr(w32, 1u << (gene & 31u));
     }
 }
 
@@ -225,7 +240,8 @@ __global__ void acc_gene_counts_kernel(const uint64_t *accG, uint32_t *counts, a
 
 // distances.rs:55-77 numerators for sampled pairs
 __global__ void acc_pair_counts_kernel(const uint64_t *accI, const uint32_t *r1, const uint32_t *r2,
-                                       uint64_t P, uint32_t *inter, uint32_t *uni, acc_dims d)
+                                       const uint32_t *perm, uint64_t P, uint32_t *inter, uint32_t *uni,
+                                       acc_dims d)
 {
     const uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= P) return;
@@ -236,8 +252,9 @@ __global__ void acc_pair_counts_kernel(const uint64_t *accI, const uint32_t *r1,
         in += __popcll(a & b);
         un += __popcll(a | b);
     }
-    inter[k] = in;
-    uni[k] = un;
+    const uint64_t o = perm ? perm[k] : k;
+    inter[o] = in;
+    uni[o] = un;
 }
 
 // population.rs:753-784 on the accessory matrix: mean Jaccard distance of i to all

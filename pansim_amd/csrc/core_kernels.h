@@ -203,8 +203,8 @@ __global__ void __launch_bounds__(1024) core_sweep_kernel(core_sweep_args a)
 // The host only selects this kernel when the queue cannot overflow in practice
 // (mean + 12 sigma of the entry count fits); an overflow raises a sticky error flag.
 // ---------------------------------------------------------------------------
-#define PS_ROWS 4u
-#define PS_QCAP 640u
+// rows per wave iteration (template parameter ROWS) and queue capacity per wave
+__host__ __device__ constexpr uint32_t ps_qcap(uint32_t rows) { return rows >= 4 ? 640u : rows == 3 ? 512u : 384u; }
 
 __device__ __forceinline__ void ps_wave_sync()
 {
@@ -235,9 +235,10 @@ __device__ __forceinline__ uint32_t ps_candidates_swar(const ps_u4 &l1, uint32_t
            | (ps_bytes_lt(l1.w, c4) >> 3);
 }
 
-template <bool DO_GATHER, bool DO_MUT, bool DO_HR>
-__global__ void __launch_bounds__(256) core_sweep_wave_kernel(core_sweep_args a)
+template <uint32_t PS_ROWS, bool DO_GATHER, bool DO_MUT, bool DO_HR>
+__global__ void __launch_bounds__(256, PS_ROWS >= 4 ? 6 : 8) core_sweep_wave_kernel(core_sweep_args a)
 {
+    constexpr uint32_t PS_QCAP = ps_qcap(PS_ROWS);
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     uint8_t *rowbuf = lds + wave * (PS_ROWS * a.pitch + PS_QCAP * 4u);
@@ -491,8 +492,8 @@ __global__ void __launch_bounds__(256) core_transpose_kernel(uint8_t *state, uin
 template <int A>
 __global__ void __launch_bounds__(1024) core_pair_counts_tiled(
     const uint8_t *state, uint32_t N, uint32_t pitch, uint32_t rows, const uint32_t *r1,
-    const uint32_t *r2, uint64_t P, uint32_t *out, uint32_t W /* dwords per individual per tile */,
-    uint32_t tiles_per_range)
+    const uint32_t *r2, const uint32_t *perm /* output slot of pair k, or null */, uint64_t P,
+    uint32_t *out, uint32_t W /* dwords per individual per tile */, uint32_t tiles_per_range)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t T[];
     const uint32_t RS = W + 4u;
@@ -504,7 +505,8 @@ __global__ void __launch_bounds__(1024) core_pair_counts_tiled(
     for (int q = 0; q < A; q++) {
         const uint64_t k = kbase + (uint64_t)q * blockDim.x;
         acc[q] = 0;
-        if (k < P) { pi[q] = r1[k] * RS; pj[q] = r2[k] * RS; }
+        // row offsets in 16-byte units so that the tile reads are provably aligned (ds_read_b128)
+        if (k < P) { pi[q] = r1[k] * (RS >> 2); pj[q] = r2[k] * (RS >> 2); }
         else { pi[q] = 0; pj[q] = 0; }     // same row twice: contributes nothing
     }
     for (uint32_t t = 0; t < tiles_per_range; t++) {
@@ -515,6 +517,9 @@ __global__ void __launch_bounds__(1024) core_pair_counts_tiled(
         // loads (a wave reads 256 contiguous bytes of a site row), repacked into one
         // 16-byte nibble string per individual
         const uint32_t quads = (N + 3u) >> 2, sgs = W >> 2;
+#if defined(PS_PAIR_ABLATE) && PS_PAIR_ABLATE == 1
+        if (t == 0)
+#endif
         for (uint32_t it = tid; it < quads * sgs; it += blockDim.x) {
             const uint32_t qd = it % quads, sg = it / quads;
             const uint32_t sb = s0 + 32u * sg;
@@ -533,16 +538,20 @@ __global__ void __launch_bounds__(1024) core_pair_counts_tiled(
                     for (int b = 0; b < 8; b++) x |= ((v[8 * m + b] >> (8 * j)) & 0xFu) << (4 * b);
                     o[m] = x;
                 }
-                if (4u * qd + j < N) *(uint4 *)&T[(4u * qd + j) * RS + 4u * sg] = make_uint4(o[0], o[1], o[2], o[3]);
+                if (4u * qd + j < N) ((uint4 *)T)[(4u * qd + j) * (RS >> 2) + sg] = make_uint4(o[0], o[1], o[2], o[3]);
             }
         }
         __syncthreads();
+#if defined(PS_PAIR_ABLATE) && PS_PAIR_ABLATE == 2
+        if (t == 0)
+#endif
 #pragma unroll
         for (int q = 0; q < A; q++) {
             uint32_t s = 0;
-            for (uint32_t w = 0; w < W; w += 4) {
-                const uint4 x = *(const uint4 *)&T[pi[q] + w];
-                const uint4 y = *(const uint4 *)&T[pj[q] + w];
+            const uint4 *T4 = (const uint4 *)T;
+            for (uint32_t w4 = 0; w4 < (W >> 2); w4++) {
+                const uint4 x = T4[pi[q] + w4];
+                const uint4 y = T4[pj[q] + w4];
                 s += __popc(x.x ^ y.x) + __popc(x.y ^ y.y) + __popc(x.z ^ y.z) + __popc(x.w ^ y.w);
             }
             acc[q] += s;
@@ -551,14 +560,14 @@ __global__ void __launch_bounds__(1024) core_pair_counts_tiled(
 #pragma unroll
     for (int q = 0; q < A; q++) {
         const uint64_t k = kbase + (uint64_t)q * blockDim.x;
-        if (k < P && acc[q]) atomicAdd(&out[k], acc[q]);
+        if (k < P && acc[q]) atomicAdd(&out[perm ? perm[k] : k], acc[q]);
     }
 }
 
 // generic form (any N, any byte values): one thread per pair, blockIdx.y splits the sites
 __global__ void __launch_bounds__(256) core_pair_counts_simple(
     const uint8_t *state, uint32_t pitch, uint32_t rows, const uint32_t *r1, const uint32_t *r2,
-    uint64_t P, uint32_t *out, uint32_t rows_per_slice)
+    const uint32_t *perm, uint64_t P, uint32_t *out, uint32_t rows_per_slice)
 {
     const uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= P) return;
@@ -570,7 +579,7 @@ __global__ void __launch_bounds__(256) core_pair_counts_simple(
         const uint8_t *row = state + (size_t)s * pitch;
         acc += __popc((uint32_t)(row[i] ^ row[j]));
     }
-    if (acc) atomicAdd(&out[k], acc);
+    if (acc) atomicAdd(&out[perm ? perm[k] : k], acc);
 }
 
 // distances.rs:22-52 / :55-77 on two byte slices already in device memory

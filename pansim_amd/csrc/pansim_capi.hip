@@ -188,10 +188,12 @@ struct ps_population {
     double *d_log1p = nullptr;       // G
     int32_t *d_num_genes = nullptr;  // N
     double *d_logw = nullptr;        // N
-    void *d_pairs = nullptr;         // r1|r2|outA|outB
-    uint64_t pairs_cap = 0;
+    void *d_pairs = nullptr;         // sorted r1 | r2 | perm | outA | outB
+    uint64_t pairs_cap = 0, pairs_cached = 0;
+    std::vector<uint32_t> h_r1, h_r2; // the caller's list the device copy was built from
     uint32_t lds_limit = 160 * 1024;
-    uint32_t sweep_blocks_per_cu = 6;   // wave-per-row sweep: resident 256-thread blocks per CU
+    uint32_t sweep_blocks_per_cu = 8;   // wave-per-row sweep: resident 256-thread blocks per CU (capped by LDS)
+    uint32_t sweep_rows = 3;            // wave-per-row sweep: site rows per wave iteration (2..4)
     bool force_block_sweep = false;     // tests: run the block-per-row sweep on small populations
     uint32_t *h_flag = nullptr, *d_flag = nullptr;   // host-mapped sticky device error word
 };
@@ -232,6 +234,10 @@ static int pop_create_impl(const ps_config *cfg, const uint8_t *init_vec, ps_pop
     if (const char *e = getenv("PANSIM_SWEEP_BLOCKS_PER_CU")) {
         const int v = atoi(e);
         if (v >= 1 && v <= 8) p->sweep_blocks_per_cu = (uint32_t)v;
+    }
+    if (const char *e = getenv("PANSIM_SWEEP_ROWS")) {
+        const int v = atoi(e);
+        if (v >= 2 && v <= 4) p->sweep_rows = (uint32_t)v;
     }
     const uint64_t N = cfg->pop_size, C = cfg->ncols;
     HIPCHK(hipMalloc(&p->d_idx, std::max<uint64_t>(N, 1) * sizeof(uint32_t)));
@@ -351,6 +357,9 @@ extern "C" int ps_set_tuning(ps_population *p, const char *key, int64_t value)
     if (k == "sweep_blocks_per_cu") {
         if (value < 1 || value > 8) return ps_fail(PS_ERR_INVALID, "sweep_blocks_per_cu must be 1..8");
         p->sweep_blocks_per_cu = (uint32_t)value;
+    } else if (k == "sweep_rows") {
+        if (value < 2 || value > 4) return ps_fail(PS_ERR_INVALID, "sweep_rows must be 2..4");
+        p->sweep_rows = (uint32_t)value;
     } else if (k == "force_block_sweep") {
         p->force_block_sweep = value != 0;
     } else if (k == "lds_limit") {
@@ -458,29 +467,49 @@ extern "C" int ps_set_rates(ps_population *p, int n_comp, const double *lam_mut,
 // ---------------------------------------------------------------------------
 // core sweep launch
 // ---------------------------------------------------------------------------
-template <bool GA, bool MU, bool HR>
-static int launch_core_sweep_wave(ps_population *p, const core_sweep_args &a, hipStream_t st)
+template <uint32_t ROWS, bool GA, bool MU, bool HR>
+static int launch_core_sweep_wave_r(ps_population *p, const core_sweep_args &a, hipStream_t st)
 {
     const uint32_t block = 256u, wpb = block / 64u;
-    const uint32_t lds = wpb * (PS_ROWS * a.pitch + PS_QCAP * 4u);
-    const uint32_t want = (a.rows + wpb * PS_ROWS - 1) / (wpb * PS_ROWS);
-    const uint32_t grid = std::max(1u, std::min(want, 256u * p->sweep_blocks_per_cu));
-    hipLaunchKernelGGL((core_sweep_wave_kernel<GA, MU, HR>), dim3(grid), dim3(block), lds, st, a);
+    const uint32_t lds = wpb * (ROWS * a.pitch + ps_qcap(ROWS) * 4u);
+    const uint32_t want = (a.rows + wpb * ROWS - 1) / (wpb * ROWS);
+    const uint32_t fit = std::max(1u, std::min(8u, p->lds_limit / lds));
+    const uint32_t bpc = std::min(p->sweep_blocks_per_cu, fit);
+    const uint32_t grid = std::max(1u, std::min(want, 256u * bpc));
+    hipLaunchKernelGGL((core_sweep_wave_kernel<ROWS, GA, MU, HR>), dim3(grid), dim3(block), lds, st, a);
     HIPCHK(hipGetLastError());
     return PS_OK;
 }
 
-// The wave-per-row sweep queues every candidate cell (level-1 byte <= bC) of PS_ROWS
-// rows.  It is selected only when that many cells fit the queue with 10 standard
+template <bool GA, bool MU, bool HR>
+static int launch_core_sweep_wave(ps_population *p, const core_sweep_args &a, hipStream_t st)
+{
+    switch (p->sweep_rows) {
+    case 2: return launch_core_sweep_wave_r<2, GA, MU, HR>(p, a, st);
+    case 3: return launch_core_sweep_wave_r<3, GA, MU, HR>(p, a, st);
+    default: return launch_core_sweep_wave_r<4, GA, MU, HR>(p, a, st);
+    }
+}
+
+// The wave-per-row sweep queues every candidate cell (level-1 byte <= bC) of `rows`
+// site rows.  It is selected only when that many cells fit the queue with 10 standard
 // deviations to spare (and the SWAR byte compare applies: bC < 127).
-static bool wave_sweep_eligible(const ps_population *p, bool mu, bool hr)
+static bool wave_sweep_fits(const ps_population *p, uint32_t rows)
+{
+    const ps_core_plan &pl = p->cplan;
+    const double m = (double)rows * (double)p->cfg.pop_size * (double)(pl.bC + 1u) / 256.0;
+    return m + 10.0 * std::sqrt(m) + 16.0 <= (double)ps_qcap(rows);
+}
+
+static bool wave_sweep_eligible(ps_population *p, bool mu, bool hr)
 {
     if (p->pitch > 1024 || p->force_block_sweep) return false;
     const ps_core_plan &pl = p->cplan;
+    if (p->sweep_rows < 2 || p->sweep_rows > 4) p->sweep_rows = 3;
     if (!pl.has_events || (!mu && !hr)) return true;
     if (pl.bC > 126) return false;
-    const double m = (double)PS_ROWS * (double)p->cfg.pop_size * (double)(pl.bC + 1u) / 256.0;
-    return m + 10.0 * std::sqrt(m) + 16.0 <= (double)PS_QCAP;
+    while (p->sweep_rows > 2 && !wave_sweep_fits(p, p->sweep_rows)) p->sweep_rows--;
+    return wave_sweep_fits(p, p->sweep_rows);
 }
 
 template <bool GA, bool MU, bool HR>
@@ -563,22 +592,32 @@ static int launch_acc_step(ps_population *p, const uint32_t *d_idx, uint32_t gen
 static int launch_acc_hgt(ps_population *p, uint32_t gen, hipStream_t st)
 {
     if (p->d.G == 0 || p->d.N < 2) return PS_OK;
-    bool any = false;
-    for (int c = 0; c < p->aplan.n_comp; c++) any |= p->aplan.lam_rec[c] != 0.0;
-    if (!any) return PS_OK;
+    acc_hgt_args a{};
+    a.n_comp = (uint32_t)p->aplan.n_comp;
+    uint64_t total = 0;
+    for (int c = 0; c < p->aplan.n_comp; c++) {
+        a.gb[c] = p->aplan.comp_begin[c];
+        a.K[c] = 0;
+        if (p->aplan.lam_rec[c] == 0.0) continue;      // population.rs:558
+        a.K[c] = hs_poisson((double)p->d.N * p->aplan.lam_rec[c], p->cfg.seed,
+                            PS_STREAM_HGT_COUNT | ((uint32_t)c << 8), gen);
+        total += a.K[c];
+    }
+    if (total == 0) return PS_OK;
     // the gene lists ARE the pre-recombination snapshot the donors are read from
     acc_gene_lists_kernel<<<dim3(p->d.N, p->aplan.n_comp), 64, 0, st>>>(p->I[p->cur], p->glist, p->cnt,
                                                                          p->d, p->aplan);
-    for (int c = 0; c < p->aplan.n_comp; c++) {
-        if (p->aplan.lam_rec[c] == 0.0) continue;      // population.rs:558
-        const uint64_t K = hs_poisson((double)p->d.N * p->aplan.lam_rec[c], p->cfg.seed,
-                                      PS_STREAM_HGT_COUNT | ((uint32_t)c << 8), gen);
-        if (K == 0) continue;
-        const uint32_t blocks = (uint32_t)std::min<uint64_t>((K + 255) / 256, 256 * 16);
-        acc_hgt_kernel<<<blocks, 256, 0, st>>>(p->glist, p->cnt, p->G[p->cur], p->I[p->cur], p->d,
-                                               p->aplan.comp_begin[c], (uint32_t)c, K, gen,
-                                               (uint32_t)p->cfg.seed, (uint32_t)(p->cfg.seed >> 32));
-    }
+    a.list = p->glist;
+    a.cnt = p->cnt;
+    a.dstI = p->I[p->cur];
+    a.d = p->d;
+    a.gen = gen;
+    a.k0 = (uint32_t)p->cfg.seed;
+    a.k1 = (uint32_t)(p->cfg.seed >> 32);
+    const uint32_t blocks = (uint32_t)std::min<uint64_t>((total + 255) / 256, 256 * 8);
+    acc_hgt_kernel<<<blocks, 256, 0, st>>>(a);
+    // rebuild the gene-major view from the individual-major one (one ballot per gene word)
+    acc_i_to_g_kernel<<<dim3(p->d.W, p->d.GW), 64, 0, st>>>(p->I[p->cur], p->G[p->cur], p->d);
     HIPCHK(hipGetLastError());
     return PS_OK;
 }
@@ -773,45 +812,79 @@ static int ensure_pairs(ps_population *p, uint64_t P)
     if (p->d_pairs) HIPCHK(hipFree(p->d_pairs));
     p->d_pairs = nullptr;
     p->pairs_cap = 0;
-    HIPCHK(hipMalloc(&p->d_pairs, P * 4 * sizeof(uint32_t)));
+    p->pairs_cached = 0;
+    HIPCHK(hipMalloc(&p->d_pairs, P * 5 * sizeof(uint32_t)));
     p->pairs_cap = P;
     return PS_OK;
 }
 
+// Upload the pair list sorted by its first individual (consecutive lanes then read the same
+// LDS row: a broadcast instead of a bank conflict) together with the permutation that
+// restores the caller's order.  The list is fixed for a whole run (main.rs:413-427), so the
+// device copy is reused while the caller keeps passing the same list.
+static int upload_pairs(ps_population *p, uint64_t P, const uint32_t *r1, const uint32_t *r2)
+{
+    PSCHK(ensure_pairs(p, P));
+    if (p->pairs_cached == P && p->h_r1.size() == P && memcmp(p->h_r1.data(), r1, P * 4) == 0
+        && memcmp(p->h_r2.data(), r2, P * 4) == 0)
+        return PS_OK;
+    const uint64_t N = p->cfg.pop_size;
+    p->h_r1.assign(r1, r1 + P);
+    p->h_r2.assign(r2, r2 + P);
+    std::vector<uint32_t> start(N + 1, 0), s1(P), s2(P), perm(P);
+    for (uint64_t k = 0; k < P; k++) start[r1[k] + 1]++;
+    for (uint64_t i = 0; i < N; i++) start[i + 1] += start[i];
+    for (uint64_t k = 0; k < P; k++) {
+        const uint32_t pos = start[r1[k]]++;
+        s1[pos] = r1[k];
+        s2[pos] = r2[k];
+        perm[pos] = (uint32_t)k;
+    }
+    uint32_t *d = (uint32_t *)p->d_pairs;
+    HIPCHK(hipMemcpyAsync(d, s1.data(), P * 4, hipMemcpyHostToDevice, p->stream));
+    HIPCHK(hipMemcpyAsync(d + P, s2.data(), P * 4, hipMemcpyHostToDevice, p->stream));
+    HIPCHK(hipMemcpyAsync(d + 2 * P, perm.data(), P * 4, hipMemcpyHostToDevice, p->stream));
+    HIPCHK(hipStreamSynchronize(p->stream));   // the staging vectors die here
+    p->pairs_cached = P;
+    return PS_OK;
+}
+
 static int pair_counts_device(ps_population *p, uint64_t P, const uint32_t *d_r1, const uint32_t *d_r2,
-                              uint32_t *d_a, uint32_t *d_b, hipStream_t st)
+                              const uint32_t *d_perm, uint32_t *d_a, uint32_t *d_b, hipStream_t st)
 {
     const uint32_t N = (uint32_t)p->cfg.pop_size;
     if (p->cfg.core) {
         HIPCHK(hipMemsetAsync(d_a, 0, P * sizeof(uint32_t), st));
         const uint32_t rows = (uint32_t)p->cfg.ncols;
         if (rows == 0) return PS_OK;
-        // tiled kernel: LDS holds N * (W+4) dwords
+        // tiled kernel: LDS holds N * (W+4) dwords; prefer a tile that lets two workgroups share
+        // a CU so that one packs its next tile (HBM) while the other compares (LDS)
         uint32_t W = 0;
         for (uint32_t w : { 32u, 16u, 8u, 4u })
             if ((uint64_t)N * (w + 4) * 4 <= p->lds_limit) { W = w; break; }
         if (p->nibble_safe && W) {
             constexpr int A = 16;
+            constexpr uint32_t PT = 1024;
             const uint32_t lds = N * (W + 4) * 4;
             auto kern = core_pair_counts_tiled<A>;
             if (lds > 64 * 1024)
                 HIPCHK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             const uint32_t n_tiles = (rows + W * 8 - 1) / (W * 8);
-            const uint32_t pair_blocks = (uint32_t)((P + 1024ull * A - 1) / (1024ull * A));
+            const uint32_t pair_blocks = (uint32_t)((P + (uint64_t)PT * A - 1) / ((uint64_t)PT * A));
             // enough site ranges to fill the chip a few times over
             uint32_t ranges = std::max(1u, std::min(n_tiles, (256u * 4u + pair_blocks - 1) / pair_blocks));
             const uint32_t tpr = (n_tiles + ranges - 1) / ranges;
             ranges = (n_tiles + tpr - 1) / tpr;
-            hipLaunchKernelGGL(kern, dim3(ranges, pair_blocks), dim3(1024), lds, st, p->state, N, p->pitch,
-                               rows, d_r1, d_r2, P, d_a, W, tpr);
+            hipLaunchKernelGGL(kern, dim3(ranges, pair_blocks), dim3(PT), lds, st, p->state, N, p->pitch,
+                               rows, d_r1, d_r2, d_perm, P, d_a, W, tpr);
         } else {
             const uint32_t slices = std::max(1u, std::min(rows, 64u));
             const uint32_t rps = (rows + slices - 1) / slices;
             dim3 grid((uint32_t)((P + 255) / 256), (rows + rps - 1) / rps);
-            core_pair_counts_simple<<<grid, 256, 0, st>>>(p->state, p->pitch, rows, d_r1, d_r2, P, d_a, rps);
+            core_pair_counts_simple<<<grid, 256, 0, st>>>(p->state, p->pitch, rows, d_r1, d_r2, d_perm, P, d_a, rps);
         }
     } else {
-        acc_pair_counts_kernel<<<(uint32_t)((P + 255) / 256), 256, 0, st>>>(p->I[p->cur], d_r1, d_r2, P,
+        acc_pair_counts_kernel<<<(uint32_t)((P + 255) / 256), 256, 0, st>>>(p->I[p->cur], d_r1, d_r2, d_perm, P,
                                                                          d_a, d_b, p->d);
     }
     HIPCHK(hipGetLastError());
@@ -829,13 +902,11 @@ extern "C" int ps_pairwise_counts(ps_population *p, uint64_t P, const uint32_t *
         if (range1[k] >= N || range2[k] >= N)
             return ps_fail(PS_ERR_INVALID, "pair %llu out of range", (unsigned long long)k);
     PSCHK(use_device(p));
-    PSCHK(ensure_pairs(p, P));
-    uint32_t *d_r1 = (uint32_t *)p->d_pairs, *d_r2 = d_r1 + P, *d_a = d_r2 + P, *d_b = d_a + P;
-    HIPCHK(hipMemcpyAsync(d_r1, range1, P * 4, hipMemcpyHostToDevice, p->stream));
-    HIPCHK(hipMemcpyAsync(d_r2, range2, P * 4, hipMemcpyHostToDevice, p->stream));
+    PSCHK(upload_pairs(p, P, range1, range2));
+    uint32_t *d_r1 = (uint32_t *)p->d_pairs, *d_r2 = d_r1 + P, *d_perm = d_r2 + P, *d_a = d_perm + P, *d_b = d_a + P;
     uint32_t *ka = out_is_device ? out_a : d_a;
     uint32_t *kb = out_is_device ? out_b : d_b;
-    PSCHK(pair_counts_device(p, P, d_r1, d_r2, ka, kb, p->stream));
+    PSCHK(pair_counts_device(p, P, d_r1, d_r2, d_perm, ka, kb, p->stream));
     if (!out_is_device) {
         HIPCHK(hipMemcpyAsync(out_a, d_a, P * 4, hipMemcpyDeviceToHost, p->stream));
         if (!p->cfg.core) HIPCHK(hipMemcpyAsync(out_b, d_b, P * 4, hipMemcpyDeviceToHost, p->stream));
@@ -1214,8 +1285,8 @@ struct ps_sim {
     uint32_t *h_idx[PS_RING] = {};         // pinned
     hipEvent_t ev_idx[PS_RING] = {}, ev_core[PS_RING] = {};
     bool slot_used[PS_RING] = {};
-    int32_t *h_num_genes = nullptr;        // pinned
-    double *h_logw = nullptr, *h_avg = nullptr;
+    int32_t *h_num_genes = nullptr, *m_num_genes = nullptr;   // pinned + its device alias
+    double *h_logw = nullptr, *m_logw = nullptr, *h_avg = nullptr;
     double *d_avg = nullptr;
     uint64_t step_count = 0;
     bool need_logw = false;
@@ -1302,8 +1373,10 @@ static int sim_create_impl(const ps_sim_params *p, ps_sim *s)
         HIPCHK(hipEventCreateWithFlags(&s->ev_idx[k], hipEventDisableTiming));
         HIPCHK(hipEventCreateWithFlags(&s->ev_core[k], hipEventDisableTiming));
     }
-    HIPCHK(hipHostMalloc(&s->h_num_genes, N * sizeof(int32_t)));
-    HIPCHK(hipHostMalloc(&s->h_logw, N * sizeof(double)));
+    HIPCHK(hipHostMalloc(&s->h_num_genes, N * sizeof(int32_t), hipHostMallocMapped));
+    HIPCHK(hipHostMalloc(&s->h_logw, N * sizeof(double), hipHostMallocMapped));
+    HIPCHK(hipHostGetDevicePointer((void **)&s->m_num_genes, s->h_num_genes, 0));
+    HIPCHK(hipHostGetDevicePointer((void **)&s->m_logw, s->h_logw, 0));
     HIPCHK(hipHostMalloc(&s->h_avg, N * sizeof(double)));
     HIPCHK(hipMalloc(&s->d_avg, N * sizeof(double)));
     if (G) {
@@ -1346,12 +1419,11 @@ static int sim_one_generation(ps_sim *s, uint32_t gen)
         HIPCHK(hipMemcpyAsync(s->h_avg, s->d_avg, N * sizeof(double), hipMemcpyDeviceToHost, sa));
     }
     // main.rs:442-443: device half of sample_indices ...
+    // the kernel writes its 12*N bytes straight into host-mapped pinned memory (no copy kernels)
     acc_fitness_kernel<<<(uint32_t)((N + 255) / 256), 256, 0, sa>>>(acc->I[acc->cur], acc->d_log1p,
-                                                                 s->need_logw ? 1 : 0, acc->d_num_genes,
-                                                                 acc->d_logw, acc->d);
+                                                                 s->need_logw ? 1 : 0, s->m_num_genes,
+                                                                 s->m_logw, acc->d);
     HIPCHK(hipGetLastError());
-    HIPCHK(hipMemcpyAsync(s->h_num_genes, acc->d_num_genes, N * sizeof(int32_t), hipMemcpyDeviceToHost, sa));
-    HIPCHK(hipMemcpyAsync(s->h_logw, acc->d_logw, N * sizeof(double), hipMemcpyDeviceToHost, sa));
     // the slot's previous core sweep must have consumed its indices
     if (s->slot_used[slot]) HIPCHK(hipEventSynchronize(s->ev_core[slot]));
     HIPCHK(hipStreamSynchronize(sa));

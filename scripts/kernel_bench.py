@@ -83,6 +83,23 @@ def main():
             dt = timeit(lambda: core.pairwise_counts(r1, r2), core.sync, n=3, warm=1)
             print(json.dumps({"op": "core.pairwise_counts", "P": P, "ms": dt * 1e3, "Mpairs_per_s": P / dt / 1e6}), flush=True)
         core.close()
+    if "rows" in what:
+        for hr in (3000.0, 30000.0):
+            for rows in (2, 3, 4):
+                for bpc in (5, 6, 7, 8):
+                    core = pa.Population(N, L, 4, True, 0.0, 0, 2000)
+                    core.set_tuning("sweep_blocks_per_cu", bpc)
+                    core.set_tuning("sweep_rows", rows)
+                    core.set_rates([60000.0], [hr])
+                    gen = [0]
+
+                    def f():
+                        gen[0] += 1
+                        core.step(gen[0], idx, True)
+                    dt = timeit(f, core.sync, n=10)
+                    print(json.dumps({"op": "core.step", "lam_hr": hr, "rows": rows, "blocks_per_cu": bpc,
+                                      "ms": dt * 1e3, "GBps": 2.0 * N * L / dt / 1e9}), flush=True)
+                    core.close()
     if "loop" in what:
         for bpc in ("5", "6", "7", "8"):
             os.environ["PANSIM_SWEEP_BLOCKS_PER_CU"] = bpc
