@@ -23,6 +23,17 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s
 
 
+def pmc_traffic():
+    """HBM bytes per launch of the fused sweep from the committed rocprofv3 --pmc passes
+    (profiles/r01_pmc_sweep.json, written by scripts/collect_pmc.py; FETCH_SIZE doubled per the
+    gfx950 correction of MI355X_MICROARCH.md).  None if that file is absent."""
+    try:
+        d = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_sweep.json")))
+        return d["hbm_bytes_per_launch"], d["source"]
+    except (OSError, KeyError, ValueError):
+        return None, None
+
+
 def host_cores():
     """CPU threads this process may actually use: affinity mask capped by the cgroup CPU quota."""
     n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
@@ -82,10 +93,19 @@ def main():
                          % (args.gpus, world, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: pansim_amd has no CPU path")
+    # PANSIM_BENCH_BACKEND=gloo lets several ranks share one GPU (debugging the N>1 path on a
+    # 1-GPU box); the driver's multi-GPU runs use nccl (= RCCL over xGMI), one rank per GPU
+    backend = os.environ.get("PANSIM_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
+    coll_dev = "cuda" if backend == "nccl" else "cpu"
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
 
     def barrier():
         if world > 1:
@@ -109,7 +129,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        t = torch.tensor([dt], device=coll_dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     launches, sweep_ms, bytes_per_launch = sim.sweep_timing(reset=True)
@@ -123,7 +143,12 @@ def main():
     t1 = time.perf_counter()
     sim.core_genome.pairwise_counts_device(sim.range1, sim.range2, cnt.data_ptr())
     if world > 1:
-        dist.all_reduce(cnt)
+        if backend == "nccl":
+            dist.all_reduce(cnt)
+        else:
+            c = cnt.cpu()
+            dist.all_reduce(c)
+            cnt = c
     acc_d = sim.pan_genome.pairwise_distances(P, sim.range1, sim.range2)
     core_d = (cnt.cpu().numpy().astype("uint32") // 2) / float(kw["core_size"])
     barrier()
@@ -133,6 +158,7 @@ def main():
     if rank == 0:
         avg_ms = sweep_ms / max(launches, 1)
         achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if launches else 0.0
+        traffic, traffic_src = pmc_traffic() if (args.pop_size, args.core_size) == (1000, 1200000) else (None, None)
         out = {
             "metric": "generations/sec", "value": world * args.steps / dt,
             "unit": "generations/s (pop=%d, %d core sites per GPU, pan=%d)" % (args.pop_size, args.core_size, args.pan_genes),
@@ -147,8 +173,8 @@ def main():
             "mpairs_per_s": P / dist_dt / 1e6,
             "distance_ms": 1e3 * dist_dt,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": "core_sweep_kernel<gather,mutate,HR>", "avg_launch_ms": avg_ms,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                         "kernel": "core_sweep_wave_kernel<gather,mutate,HR>", "avg_launch_ms": avg_ms,
                          "algorithmic_bytes_per_launch": bytes_per_launch},
         }
         if world == 1 and not args.no_cpu_baseline:
