@@ -147,8 +147,9 @@ int ps_sync(ps_population *p);
 /* Launch tuning / test hooks (no reference counterpart).  Keys: "sweep_blocks_per_cu"
  * (resident 256-thread blocks per CU of the wave-per-row sweep, 1..8), "sweep_rows"
  * (site rows a wave of that sweep takes per iteration, 2..4),
- * "force_block_sweep" (0/1: use the block-per-row sweep even when a row fits one
- * wavefront), "lds_limit" (bytes of LDS a workgroup may use). */
+ * "force_block_sweep" (0/1: use the block sweep even when a row fits one wavefront),
+ * "force_inline_sweep" (0/1: use the queue-free inline block sweep), "pair_mode" (core
+ * distances: 0 = choose by cost, 1 = sampled-pair kernel, 2 = all-pairs tiles + lookup), "lds_limit" (bytes of LDS a workgroup may use). */
 int ps_set_tuning(ps_population *p, const char *key, int64_t value);
 
 /* ------------------------------------------------------------------------ */

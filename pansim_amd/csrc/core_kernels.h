@@ -16,6 +16,7 @@
 struct core_sweep_args {
     uint8_t *state;
     const uint32_t *idx;   // parents (device), DO_GATHER only
+    const uint32_t *idxT;  // idxT[k * cpr + chunk] = idx[16 * chunk + k] (block sweep)
     uint32_t N, pitch, cpr, rows;
     uint32_t site_offset;  // global site index of local row 0 (Philox counter)
     uint32_t gen, k0, k1;
@@ -420,6 +421,179 @@ __global__ void __launch_bounds__(256, PS_ROWS >= 4 ? 6 : 8) core_sweep_wave_ker
     }
 }
 
+// ---------------------------------------------------------------------------
+// Block sweep for rows wider than one wavefront (pitch > 1024: cfg4/cfg5 populations).
+// A 1024-thread workgroup stages R whole site rows in LDS (parent rows and child rows);
+// its 16 waves split the rows into 1024-cell segments and treat each segment exactly like
+// the wave-per-row sweep treats a row (level-1 Philox, SWAR detection, wave-private
+// candidate queue, dense byte classification, exact level-2 pass).  A mutation only
+// touches the cells of the segment's own wave, so it needs no block barrier; cells that
+// receive a donor allele are collected in a per-wave HR list, and the donor reads /
+// writes happen between block barriers once every segment of the row has been mutated.
+// ---------------------------------------------------------------------------
+struct core_block_geom {
+    uint32_t R;        // rows per workgroup iteration
+    uint32_t segs;     // 1024-cell segments per row
+    uint32_t QW;       // candidate queue entries per wave
+    uint32_t HW;       // HR list entries per wave
+};
+
+template <bool DO_GATHER, bool DO_MUT, bool DO_HR>
+__global__ void __launch_bounds__(1024) core_sweep_block_kernel(core_sweep_args a, core_block_geom g)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63u, nw = blockDim.x >> 6;
+    uint8_t *rowS = lds;                                   // child rows [R][pitch]
+    uint8_t *rowA = lds + (DO_GATHER ? g.R * a.pitch : 0); // parent rows [R][pitch] (gather only)
+    uint32_t *wbase = (uint32_t *)(lds + (DO_GATHER ? 2u : 1u) * g.R * a.pitch) + wave * (g.QW + 2u * g.HW);
+    uint32_t *q = wbase, *hr_a = wbase + g.QW, *hr_b = hr_a + g.HW;
+    const ps_core_plan pl = a.plan;
+    const bool events = pl.has_events && (DO_MUT || DO_HR);
+    const uint32_t c4 = (pl.bC + 1u) * 0x01010101u;
+    const uint32_t t0b = pl.T[0] >> 24, t1b = pl.T[1] >> 24, t2b = pl.T[2] >> 24;
+
+    for (uint32_t r0 = blockIdx.x * g.R; r0 < a.rows; r0 += gridDim.x * g.R) {
+        const uint32_t nr = min(g.R, a.rows - r0);
+        // cooperative, coalesced load of the row group
+        for (uint32_t c = tid; c < nr * a.cpr; c += blockDim.x) {
+            const uint32_t rr = c / a.cpr, ch = c % a.cpr;
+            const uint4 v = *(const uint4 *)(a.state + (size_t)(r0 + rr) * a.pitch + 16u * ch);
+            *(uint4 *)((DO_GATHER ? rowA : rowS) + rr * a.pitch + 16u * ch) = v;
+        }
+        __syncthreads();
+
+        uint32_t nhr = 0;       // wave-uniform length of this wave's HR list
+        for (uint32_t item = wave; item < nr * g.segs; item += nw) {
+            const uint32_t rr = item / g.segs, sg = item % g.segs;
+            const uint32_t chunk = sg * 64u + lane;
+            const bool has_chunk = chunk < a.cpr;
+            const uint32_t i0 = chunk * 16u;
+            const uint32_t nvalid = (i0 >= a.N) ? 0u : min(16u, a.N - i0);
+            const uint32_t site = a.site_offset + r0 + rr;
+            uint8_t *row = rowS + rr * a.pitch;
+            if (DO_GATHER) {
+                const uint8_t *par = rowA + rr * a.pitch;
+                uint32_t w[4] = { 0, 0, 0, 0 };
+                if (has_chunk) {
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        uint32_t x = 0;
+#pragma unroll
+                        for (int b = 0; b < 4; b++) {
+                            const uint32_t k = 4 * j + b;
+                            // idxT[k][chunk]: consecutive lanes read consecutive words
+                            const uint32_t v = (k < nvalid) ? (uint32_t)par[a.idxT[k * a.cpr + chunk]] : 0u;
+                            x |= v << (8 * b);
+                        }
+                        w[j] = x;
+                    }
+                    *(uint4 *)(row + i0) = make_uint4(w[0], w[1], w[2], w[3]);
+                }
+            }
+            if (!events) continue;
+            uint32_t vperm = 0;
+#pragma unroll
+            for (uint32_t k = 0; k < 16; k++)
+                if (k < nvalid) vperm |= 1u << (8u * (k & 3u) + 7u - (k >> 2));
+            const ps_u4 l1 = ps_philox(site, chunk, a.gen, PS_STREAM_CORE_L1, a.k0, a.k1);
+            uint32_t cm = ps_candidates_swar(l1, c4) & vperm;
+            uint32_t qn = 0;
+            for (;;) {
+                const bool act = cm != 0u;
+                const uint64_t bal = __ballot(act);
+                if (bal == 0ull) break;
+                if (act) {
+                    const uint32_t p = __builtin_ctz(cm);
+                    cm &= cm - 1u;
+                    const uint32_t b = p >> 3, j = 7u - (p & 7u);
+                    const uint32_t sel = ((j & 1u) * 4u + b) | 0x0c0c0c00u;
+                    const uint32_t byte = (j & 2u) ? __builtin_amdgcn_perm(l1.w, l1.z, sel)
+                                                   : __builtin_amdgcn_perm(l1.y, l1.x, sel);
+                    const uint32_t pos = qn + ps_lane_prefix(bal);
+                    if (pos < g.QW) q[pos] = (i0 + 4u * j + b) | (byte << 20);
+                }
+                qn += (uint32_t)__popcll(bal);
+            }
+            ps_wave_sync();
+            if (qn > g.QW) {
+                if (lane == 0) atomicOr(a.overflow_flag, 2u);
+                qn = g.QW;
+            }
+            // dense pass: byte-decided mutations; the others compacted in place
+            uint32_t n2 = 0;
+            for (uint32_t base = 0; base < qn; base += 64u) {
+                const uint32_t e = base + lane;
+                const bool valid = e < qn;
+                const uint32_t ent = valid ? q[e] : 0u;
+                const uint32_t byte = ent >> 20;
+                uint32_t allele = 0;
+                if (byte < t0b) allele = 2u;
+                else if (byte > t0b && byte < t1b) allele = 4u;
+                else if (byte > t1b && byte < t2b) allele = 8u;
+                const bool amb = valid && allele == 0u;
+                if (DO_MUT && valid && allele) row[ent & 0xFFFFFu] = (uint8_t)allele;
+                const uint64_t bal = __ballot(amb);
+                if (amb) q[n2 + ps_lane_prefix(bal)] = ent;
+                n2 += (uint32_t)__popcll(bal);
+            }
+            ps_wave_sync();
+            // exact pass
+            for (uint32_t base = 0; base < n2; base += 64u) {
+                const uint32_t e = base + lane;
+                bool hr = false;
+                uint32_t cellidx = 0, donor = 0;
+                if (e < n2) {
+                    const uint32_t ent = q[e];
+                    cellidx = ent & 0xFFFFFu;
+                    const uint32_t byte = ent >> 20;
+                    const ps_u4 l2 = ps_philox(site, cellidx, a.gen, PS_STREAM_CORE_L2, a.k0, a.k1);
+                    const ps_cell cell = ps_classify((byte << 24) | (l2.x >> 8), pl);
+                    if (DO_MUT && cell.mut) row[cellidx] = (uint8_t)cell.mut;
+                    if (DO_HR && cell.hr) {
+                        hr = true;
+                        donor = ps_mulhi(l2.y, a.N - 1u);
+                        donor += (donor >= cellidx) ? 1u : 0u;           // population.rs:618
+                    }
+                }
+                if (DO_HR) {
+                    const uint64_t bal = __ballot(hr);
+                    if (hr) {
+                        const uint32_t pos = nhr + ps_lane_prefix(bal);
+                        if (pos < g.HW) { hr_a[pos] = rr * a.pitch + cellidx; hr_b[pos] = rr * a.pitch + donor; }
+                    }
+                    nhr += (uint32_t)__popcll(bal);
+                }
+            }
+            ps_wave_sync();
+        }
+        if (DO_HR && events) {
+            if (nhr > g.HW) {
+                if (lane == 0) atomicOr(a.overflow_flag, 4u);
+                nhr = g.HW;
+            }
+            __syncthreads();    // every segment is mutated: rowS is the snapshot (population.rs:693-695)
+            for (uint32_t e = lane; e < nhr; e += 64u) hr_b[e] = (uint32_t)rowS[hr_b[e]];
+            __syncthreads();    // all donor reads done
+            for (uint32_t e = lane; e < nhr; e += 64u) rowS[hr_a[e]] = (uint8_t)hr_b[e];
+        }
+        __syncthreads();
+        for (uint32_t c = tid; c < nr * a.cpr; c += blockDim.x) {
+            const uint32_t rr = c / a.cpr, ch = c % a.cpr;
+            *(uint4 *)(a.state + (size_t)(r0 + rr) * a.pitch + 16u * ch) = *(const uint4 *)(rowS + rr * a.pitch + 16u * ch);
+        }
+        __syncthreads();        // the next row group overwrites the LDS rows
+    }
+}
+
+// idxT[k][chunk] = idx[16*chunk + k] (0 beyond N): coalesced parent indices for the block sweep
+__global__ void idx_transpose_kernel(const uint32_t *idx, uint32_t *idxT, uint32_t N, uint32_t cpr)
+{
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= 16u * cpr) return;
+    const uint32_t k = t / cpr, chunk = t % cpr, i = chunk * 16u + k;
+    idxT[t] = (i < N) ? idx[i] : 0u;
+}
+
 // clonal start: every individual gets allele_vec[site] (population.rs:206-212)
 __global__ void core_init_kernel(uint8_t *state, const uint8_t *allele_vec, uint32_t N,
                                  uint32_t pitch, uint32_t rows)
@@ -562,6 +736,105 @@ __global__ void __launch_bounds__(1024) core_pair_counts_tiled(
         const uint64_t k = kbase + (uint64_t)q * blockDim.x;
         if (k < P && acc[q]) atomicAdd(&out[perm ? perm[k] : k], acc[q]);
     }
+}
+
+// ---------------------------------------------------------------------------
+// All-pairs Hamming numerators, register tiled: H[i][j] += sum_s popcount(x[s][i] ^ x[s][j])
+// for every pair of a 128 x 128 tile of individuals (tiles with ti <= tj only).  Cost is
+// independent of the number of requested pairs, so it serves P close to N^2/2 (cfg5) and
+// per-generation statistics; core_pair_lookup_kernel then picks the sampled pairs.
+// A workgroup packs the two individual tiles of a 256-site chunk into LDS as nibble
+// strings (same packing as the sampled kernel); thread (ty,tx) owns the 8 x 8 pairs
+// (ti*128 + a*16 + ty, tj*128 + b*16 + tx): the 16 lanes that share ty read the same A
+// rows (broadcast) and rows tx + 16 b of B, 16 bytes apart by an odd stride (no conflict).
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void ps_pack_tile(uint4 *T, const uint8_t *state, uint32_t N, uint32_t pitch,
+                                             uint32_t rows, uint32_t ibase, uint32_t s0, uint32_t W)
+{
+    const uint32_t RS4 = (W >> 2) + 1u, sgs = W >> 2;
+    for (uint32_t it = threadIdx.x; it < 32u * sgs; it += blockDim.x) {
+        const uint32_t qd = it & 31u, sg = it >> 5;
+        const uint32_t sb = s0 + 32u * sg;
+        const uint32_t icol = ibase + 4u * qd;
+        uint32_t v[32];
+#pragma unroll
+        for (int b = 0; b < 32; b++)
+            v[b] = (sb + b < rows && icol < pitch) ? *(const uint32_t *)(state + (size_t)(sb + b) * pitch + icol) : 0u;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            uint32_t o[4];
+#pragma unroll
+            for (int m = 0; m < 4; m++) {
+                uint32_t x = 0;
+#pragma unroll
+                for (int b = 0; b < 8; b++) x |= ((v[8 * m + b] >> (8 * j)) & 0xFu) << (4 * b);
+                o[m] = x;
+            }
+            T[(4u * qd + j) * RS4 + sg] = make_uint4(o[0], o[1], o[2], o[3]);
+        }
+    }
+    (void)N;
+}
+
+__global__ void __launch_bounds__(256) core_allpairs_kernel(const uint8_t *state, uint32_t N, uint32_t pitch,
+                                                            uint32_t rows, uint32_t *H, uint32_t W,
+                                                            uint32_t chunks_per_range, uint32_t ntile)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t T[];
+    const uint32_t RS4 = (W >> 2) + 1u;
+    uint4 *TA = (uint4 *)T, *TB = TA + 128u * RS4;
+    // blockIdx.x enumerates tile pairs ti <= tj row by row
+    uint32_t ti = 0, rem = blockIdx.x;
+    while (rem >= ntile - ti) { rem -= ntile - ti; ti++; }
+    const uint32_t tj = ti + rem;
+    const uint32_t tx = threadIdx.x & 15u, ty = threadIdx.x >> 4;
+    uint32_t acc[8][8];
+#pragma unroll
+    for (int a = 0; a < 8; a++)
+#pragma unroll
+        for (int b = 0; b < 8; b++) acc[a][b] = 0;
+    const uint32_t sites_per_chunk = W * 8u;
+    for (uint32_t c = 0; c < chunks_per_range; c++) {
+        const uint32_t s0 = (blockIdx.y * chunks_per_range + c) * sites_per_chunk;
+        if (s0 >= rows) break;
+        __syncthreads();
+        ps_pack_tile(TA, state, N, pitch, rows, ti * 128u, s0, W);
+        ps_pack_tile(TB, state, N, pitch, rows, tj * 128u, s0, W);
+        __syncthreads();
+        for (uint32_t w4 = 0; w4 < (W >> 2); w4++) {
+            uint4 xb[8];
+#pragma unroll
+            for (int b = 0; b < 8; b++) xb[b] = TB[(tx + 16u * b) * RS4 + w4];
+#pragma unroll
+            for (int a = 0; a < 8; a++) {
+                const uint4 xa = TA[(ty + 16u * a) * RS4 + w4];
+#pragma unroll
+                for (int b = 0; b < 8; b++)
+                    acc[a][b] += __popc(xa.x ^ xb[b].x) + __popc(xa.y ^ xb[b].y) + __popc(xa.z ^ xb[b].z)
+                                 + __popc(xa.w ^ xb[b].w);
+            }
+        }
+    }
+#pragma unroll
+    for (int a = 0; a < 8; a++) {
+        const uint32_t i = ti * 128u + ty + 16u * a;
+#pragma unroll
+        for (int b = 0; b < 8; b++) {
+            const uint32_t j = tj * 128u + tx + 16u * b;
+            if (i < N && j < N && acc[a][b]) atomicAdd(&H[(size_t)i * N + j], acc[a][b]);
+        }
+    }
+}
+
+// out[slot] = H[i][j] with the tile-ordered lookup (only tiles ti <= tj were computed)
+__global__ void core_pair_lookup_kernel(const uint32_t *H, uint32_t N, const uint32_t *r1, const uint32_t *r2,
+                                        const uint32_t *perm, uint64_t P, uint32_t *out)
+{
+    const uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= P) return;
+    const uint32_t i = r1[k], j = r2[k];
+    const bool fwd = (i >> 7) <= (j >> 7);
+    out[perm ? perm[k] : k] = fwd ? H[(size_t)i * N + j] : H[(size_t)j * N + i];
 }
 
 // generic form (any N, any byte values): one thread per pair, blockIdx.y splits the sites

@@ -185,16 +185,21 @@ struct ps_population {
     ps_acc_plan aplan{};
     // scratch
     uint32_t *d_idx = nullptr;       // N parents
+    uint32_t *d_idxT = nullptr;      // transposed parents for the block sweep (16 x cpr)
     double *d_log1p = nullptr;       // G
     int32_t *d_num_genes = nullptr;  // N
     double *d_logw = nullptr;        // N
+    uint32_t *d_H = nullptr;         // all-pairs Hamming numerators N x N
+    uint64_t H_cap = 0;
+    int pair_mode = 0;               // 0 auto, 1 sampled kernel, 2 all-pairs kernel (tuning/tests)
     void *d_pairs = nullptr;         // sorted r1 | r2 | perm | outA | outB
     uint64_t pairs_cap = 0, pairs_cached = 0;
     std::vector<uint32_t> h_r1, h_r2; // the caller's list the device copy was built from
     uint32_t lds_limit = 160 * 1024;
     uint32_t sweep_blocks_per_cu = 8;   // wave-per-row sweep: resident 256-thread blocks per CU (capped by LDS)
     uint32_t sweep_rows = 3;            // wave-per-row sweep: site rows per wave iteration (2..4)
-    bool force_block_sweep = false;     // tests: run the block-per-row sweep on small populations
+    bool force_block_sweep = false;     // tests: run the block sweep on small populations
+    bool force_inline_sweep = false;    // tests: run the inline (queue-free) block sweep
     uint32_t *h_flag = nullptr, *d_flag = nullptr;   // host-mapped sticky device error word
 };
 
@@ -209,8 +214,8 @@ extern "C" void ps_population_destroy(ps_population *p)
     if (!p) return;
     (void)hipSetDevice(p->device);
     if (p->stream) (void)hipStreamSynchronize(p->stream);
-    void *ptrs[] = { p->state, p->G[0], p->G[1], p->I[0], p->I[1], p->glist, p->cnt, p->d_idx,
-                     p->d_log1p, p->d_num_genes, p->d_logw, p->d_pairs };
+    void *ptrs[] = { p->state, p->G[0], p->G[1], p->I[0], p->I[1], p->glist, p->cnt, p->d_idx, p->d_idxT,
+                     p->d_log1p, p->d_num_genes, p->d_logw, p->d_pairs, p->d_H };
     for (void *q : ptrs)
         if (q) (void)hipFree(q);
     if (p->h_flag) (void)hipHostFree(p->h_flag);
@@ -251,6 +256,7 @@ static int pop_create_impl(const ps_config *cfg, const uint8_t *init_vec, ps_pop
         p->pitch = (uint32_t)((N + 127) / 128 * 128);
         p->cpr = p->pitch / 16;
         HIPCHK(hipMalloc(&p->state, std::max<uint64_t>(C, 1) * p->pitch));
+        HIPCHK(hipMalloc(&p->d_idxT, 16ull * p->cpr * sizeof(uint32_t)));
         if (C) {
             const uint64_t total = C * p->cpr;
             const uint32_t blocks = (uint32_t)std::min<uint64_t>((total + 255) / 256, 65536);
@@ -332,7 +338,7 @@ extern "C" int ps_init_vector(uint64_t seed, int core, uint64_t col_offset, uint
 static int check_device_flag(ps_population *p)
 {
     if (p->h_flag && *p->h_flag != 0)
-        return ps_fail(PS_ERR_STATE, "core sweep candidate queue overflowed (flag %u): results are invalid",
+        return ps_fail(PS_ERR_STATE, "core sweep queue overflowed (flag %u: 1 wave queue, 2 block queue, 4 HR list): results are invalid",
                        *p->h_flag);
     return PS_OK;
 }
@@ -360,8 +366,13 @@ extern "C" int ps_set_tuning(ps_population *p, const char *key, int64_t value)
     } else if (k == "sweep_rows") {
         if (value < 2 || value > 4) return ps_fail(PS_ERR_INVALID, "sweep_rows must be 2..4");
         p->sweep_rows = (uint32_t)value;
+    } else if (k == "pair_mode") {
+        if (value < 0 || value > 2) return ps_fail(PS_ERR_INVALID, "pair_mode must be 0 (auto), 1 (sampled) or 2 (all pairs)");
+        p->pair_mode = (int)value;
     } else if (k == "force_block_sweep") {
         p->force_block_sweep = value != 0;
+    } else if (k == "force_inline_sweep") {
+        p->force_inline_sweep = value != 0;
     } else if (k == "lds_limit") {
         if (value < 1024 || value > 160 * 1024) return ps_fail(PS_ERR_INVALID, "lds_limit must be 1 KiB..160 KiB");
         p->lds_limit = (uint32_t)value;
@@ -512,12 +523,50 @@ static bool wave_sweep_eligible(ps_population *p, bool mu, bool hr)
     return wave_sweep_fits(p, p->sweep_rows);
 }
 
+// geometry of the block sweep for this population and these rates; false if its queues cannot
+// be sized safely (then the inline block kernel, correct for any rates, is used)
+static bool block_sweep_geometry(const ps_population *p, bool ga, bool mu, bool hr, core_block_geom *g, uint32_t *lds)
+{
+    const ps_core_plan &pl = p->cplan;
+    const bool events = pl.has_events && (mu || hr);
+    if (events && pl.bC > 126) return false;
+    g->segs = (p->cpr + 63u) / 64u;
+    auto up16 = [](double x) { return (uint32_t)(((uint64_t)std::ceil(x) + 15u) & ~15ull); };
+    const double mq = events ? 1024.0 * (double)(pl.bC + 1u) / 256.0 : 0.0;
+    g->QW = std::max(64u, up16(mq + 10.0 * std::sqrt(mq) + 16.0));
+    const double hr_frac = (events && hr) ? (double)(pl.T[6] - pl.T[2]) / 4294967296.0 : 0.0;
+    for (uint32_t R = std::max(1u, 16u / std::max(1u, g->segs)); R >= 1; R >>= 1) {
+        const uint32_t items_per_wave = (R * g->segs + 15u) / 16u;
+        const double mh = (double)items_per_wave * 1024.0 * hr_frac;
+        g->R = R;
+        g->HW = std::max(16u, up16(mh + 10.0 * std::sqrt(mh) + 16.0));
+        *lds = (ga ? 2u : 1u) * R * p->pitch + 16u * (g->QW + 2u * g->HW) * 4u;
+        if (*lds <= p->lds_limit) return true;
+        if (R == 1) break;
+    }
+    return false;
+}
+
 template <bool GA, bool MU, bool HR>
 static int launch_core_sweep_block(ps_population *p, const core_sweep_args &a, hipStream_t st)
 {
+    core_block_geom g{};
+    uint32_t lds = 0;
+    if (!p->force_inline_sweep && block_sweep_geometry(p, GA, MU, HR, &g, &lds)) {
+        auto kern = core_sweep_block_kernel<GA, MU, HR>;
+        if (lds > 64 * 1024)
+            HIPCHK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        const uint32_t groups = (a.rows + g.R - 1) / g.R;
+        const uint32_t bpc = std::max(1u, std::min(2u, p->lds_limit / lds));
+        const uint32_t grid = std::max(1u, std::min(groups, 256u * bpc));
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(1024), lds, st, a, g);
+        HIPCHK(hipGetLastError());
+        return PS_OK;
+    }
+    // inline kernel: every candidate handled by its owner lane, no queues to overflow
     const uint32_t block = 1024u;
     const uint32_t hrm_bytes = (a.cpr * 2u + 15u) & ~15u;
-    const uint32_t lds = 2u * a.pitch + hrm_bytes;
+    lds = 2u * a.pitch + hrm_bytes;
     if (lds > p->lds_limit)
         return ps_fail(PS_ERR_INVALID, "pop_size %u needs %u bytes of LDS per row (limit %u)", a.N, lds,
                        p->lds_limit);
@@ -550,6 +599,11 @@ static int launch_core_sweep(ps_population *p, const uint32_t *d_idx, uint32_t g
     if (!mu && !hr) a.plan.has_events = 0;
     const bool wave = wave_sweep_eligible(p, mu, hr);
     a.overflow_flag = p->d_flag;
+    a.idxT = p->d_idxT;
+    if (!wave && ga) {
+        const uint32_t n = 16u * p->cpr;
+        idx_transpose_kernel<<<(n + 255) / 256, 256, 0, st>>>(d_idx, p->d_idxT, a.N, p->cpr);
+    }
 #define PS_DISPATCH(G_, M_, H_)                                              \
     if (ga == G_ && mu == M_ && hr == H_)                                    \
         return wave ? launch_core_sweep_wave<G_, M_, H_>(p, a, st)           \
@@ -862,7 +916,31 @@ static int pair_counts_device(ps_population *p, uint64_t P, const uint32_t *d_r1
         uint32_t W = 0;
         for (uint32_t w : { 32u, 16u, 8u, 4u })
             if ((uint64_t)N * (w + 4) * 4 <= p->lds_limit) { W = w; break; }
-        if (p->nibble_safe && W) {
+        // all-pairs tiles cost ~N^2/2 * L regardless of P; the sampled kernel ~P * L with a
+        // worse constant (it re-packs the matrix once per 16384 pairs)
+        const double all_pairs = 0.5 * (double)N * (double)N;
+        const bool use_all = p->nibble_safe && p->pair_mode != 1 && (uint64_t)N * N * 4 <= (8ull << 30)
+                             && (p->pair_mode == 2 || (double)P * 2.5 > all_pairs || !W);
+        if (use_all) {
+            const uint32_t WA = 32u, ntile = (N + 127u) / 128u;
+            const uint32_t lds = 2u * 128u * ((WA >> 2) + 1u) * 16u;
+            if (p->H_cap < (uint64_t)N * N) {
+                if (p->d_H) HIPCHK(hipFree(p->d_H));
+                p->d_H = nullptr;
+                p->H_cap = 0;
+                HIPCHK(hipMalloc(&p->d_H, (uint64_t)N * N * sizeof(uint32_t)));
+                p->H_cap = (uint64_t)N * N;
+            }
+            HIPCHK(hipMemsetAsync(p->d_H, 0, (uint64_t)N * N * sizeof(uint32_t), st));
+            const uint32_t tile_pairs = ntile * (ntile + 1u) / 2u;
+            const uint32_t n_chunks = (rows + WA * 8u - 1u) / (WA * 8u);
+            uint32_t ranges = std::max(1u, std::min(n_chunks, (256u * 16u + tile_pairs - 1u) / tile_pairs));
+            const uint32_t cpr = (n_chunks + ranges - 1u) / ranges;
+            ranges = (n_chunks + cpr - 1u) / cpr;
+            core_allpairs_kernel<<<dim3(tile_pairs, ranges), 256, lds, st>>>(p->state, N, p->pitch, rows, p->d_H, WA,
+                                                                          cpr, ntile);
+            core_pair_lookup_kernel<<<(uint32_t)((P + 255) / 256), 256, 0, st>>>(p->d_H, N, d_r1, d_r2, d_perm, P, d_a);
+        } else if (p->nibble_safe && W) {
             constexpr int A = 16;
             constexpr uint32_t PT = 1024;
             const uint32_t lds = N * (W + 4) * 4;

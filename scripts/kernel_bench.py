@@ -78,10 +78,13 @@ def main():
         acc.close()
     if "pairs" in what:
         core = pa.Population(N, L, 4, True, 0.0, 0, 2000)
-        for P in (100000, 1000000):
-            r1, r2 = pa.sample_pairs(0, N, P)
-            dt = timeit(lambda: core.pairwise_counts(r1, r2), core.sync, n=3, warm=1)
-            print(json.dumps({"op": "core.pairwise_counts", "P": P, "ms": dt * 1e3, "Mpairs_per_s": P / dt / 1e6}), flush=True)
+        for mode in (1, 2):
+            core.set_tuning("pair_mode", mode)
+            for P in (100000, 1000000):
+                r1, r2 = pa.sample_pairs(0, N, P)
+                dt = timeit(lambda: core.pairwise_counts(r1, r2), core.sync, n=3, warm=1)
+                print(json.dumps({"op": "core.pairwise_counts", "mode": mode, "P": P, "ms": dt * 1e3,
+                                  "Mpairs_per_s": P / dt / 1e6}), flush=True)
         core.close()
     if "rows" in what:
         for hr in (3000.0, 30000.0):

@@ -111,7 +111,9 @@ CORE_CASES = [
     (100, 500, 12000, 7000, 600.0, 6000.0),
     (1000, 400, 1200000, 1000000, 60000.0, 3000.0),
     (1000, 200, 4000, 0, 2000.0, 2000.0),        # heavy rates: many candidates per chunk
-    (1500, 150, 3000, 100, 150.0, 15.0),         # block-per-row path
+    (1500, 150, 3000, 100, 150.0, 15.0),         # block sweep, two segments per row
+    (5000, 60, 60000, 0, 3000.0, 3000.0),        # block sweep, five segments, partial last one
+    (20000, 9, 900, 0, 45.0, 200.0),             # block sweep, one row per workgroup iteration
     (17, 64, 64, 0, 64.0, 0.0),
     (2, 300, 300, 0, 30.0, 30.0),
 ]
@@ -249,6 +251,21 @@ def test_pairwise_core(pa, orc, N, L, P):
     assert np.array_equal(got, orc.pairwise_distances(m, True, 0, r1, r2))
     (cnt,) = pop.pairwise_counts(r1, r2)
     assert np.array_equal(cnt, orc.pairwise_hamming_counts(m, 0, L, r1, r2))
+
+
+@pytest.mark.parametrize("N,L,P", [(100, 1203, 5000), (1000, 777, 40000), (300, 5000, 1000), (1500, 333, 2000)])
+def test_pairwise_core_kernels_agree(pa, orc, N, L, P):
+    # sampled-pair kernel and all-pairs tiles + lookup give the same integers
+    rng = np.random.default_rng(N + L)
+    m = _rand_core(rng, N, L)
+    r1, r2 = orc.sample_pairs(5, N, P)
+    want = orc.pairwise_hamming_counts(m, 0, L, r1, r2)
+    for mode in (1, 2):
+        pop = pa.Population(N, L, 4, True, 0.0, 0, 0)
+        pop.set_tuning("pair_mode", mode)
+        pop.load_matrix(m)
+        assert np.array_equal(pop.pairwise_counts(r1, r2)[0], want)
+        pop.close()
 
 
 def test_pairwise_core_arbitrary_bytes(pa, orc):
@@ -408,11 +425,13 @@ def test_block_sweep_equals_wave_sweep(pa, orc, N, L, lm, lh):
     want = orc.next_generation(m0, sample)
     orc.mutate_core(want, 0, 5, 2, plan)
     orc.recombine_core(want, 0, 5, 2, plan)
-    for force in (0, 1):
-        for bpc in (1, 8):
+    for force, inline in ((0, 0), (1, 0), (1, 1)):
+        for bpc, rows in ((1, 2), (8, 3), (6, 4)):
             pop = pa.Population(N, L, 4, True, 0.0, 5, 0, global_cols=1000)
             pop.set_tuning("force_block_sweep", force)
+            pop.set_tuning("force_inline_sweep", inline)
             pop.set_tuning("sweep_blocks_per_cu", bpc)
+            pop.set_tuning("sweep_rows", rows)
             pop.set_rates([lm], [lh])
             pop.load_matrix(m0)
             pop.step(2, sample, True)
