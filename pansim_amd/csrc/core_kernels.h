@@ -22,6 +22,7 @@ struct core_sweep_args {
     uint32_t gen, k0, k1;
     ps_core_plan plan;
     uint32_t *overflow_flag;   // host-mapped sticky error word
+    unsigned long long *stamps; // diagnostic builds (PS_STAMP) only
 };
 
 __device__ __forceinline__ void ps_set_byte(uint32_t (&w)[4], uint32_t k, uint32_t v)
@@ -236,14 +237,25 @@ __device__ __forceinline__ uint32_t ps_candidates_swar(const ps_u4 &l1, uint32_t
            | (ps_bytes_lt(l1.w, c4) >> 3);
 }
 
+#ifdef PS_STAMP
+#define PS_T(k) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); st_acc[k] += t_ - st_last; st_last = t_; } while (0)
+#else
+#define PS_T(k) do { } while (0)
+#endif
 template <uint32_t PS_ROWS, bool DO_GATHER, bool DO_MUT, bool DO_HR>
 __global__ void __launch_bounds__(256, PS_ROWS >= 4 ? 6 : 8) core_sweep_wave_kernel(core_sweep_args a)
 {
+#ifdef PS_STAMP
+    unsigned long long st_acc[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+    unsigned long long st_last = __builtin_amdgcn_s_memtime();
+#endif
     constexpr uint32_t PS_QCAP = ps_qcap(PS_ROWS);
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
-    uint8_t *rowbuf = lds + wave * (PS_ROWS * a.pitch + PS_QCAP * 4u);
-    uint32_t *q = (uint32_t *)(rowbuf + PS_ROWS * a.pitch);
+    // LDS rows have a fixed 1024-byte stride, so the low 12 bits of a queue entry
+    // (cell | row << 10) are the byte address of the cell inside rowbuf
+    uint8_t *rowbuf = lds + wave * (PS_ROWS * 1024u + PS_QCAP * 4u);
+    uint32_t *q = (uint32_t *)(rowbuf + PS_ROWS * 1024u);
     const ps_core_plan pl = a.plan;
     const bool events = pl.has_events && (DO_MUT || DO_HR);
     const bool has_chunk = lane < a.cpr;
@@ -256,6 +268,14 @@ __global__ void __launch_bounds__(256, PS_ROWS >= 4 ? 6 : 8) core_sweep_wave_ker
     const uint32_t c4 = (pl.bC + 1u) * 0x01010101u;
     // byte-level intervals that decide a mutation without refinement
     const uint32_t t0b = pl.T[0] >> 24, t1b = pl.T[1] >> 24, t2b = pl.T[2] >> 24;
+    // the same intervals as a 2-bit code per byte value (0 undecided, 1/2/3 = allele 2/4/8),
+    // usable when every candidate byte is below 32
+    unsigned long long lut = 0;
+    for (uint32_t bb = 0; bb < 32u; bb++) {
+        const unsigned long long code = (bb < t0b) ? 1ull : (bb > t0b && bb < t1b) ? 2ull : (bb > t1b && bb < t2b) ? 3ull : 0ull;
+        lut |= code << (2u * bb);
+    }
+    const bool use_lut = pl.bC < 32u;
 
     uint32_t pidx[16];
     if (DO_GATHER) {
@@ -277,15 +297,16 @@ __global__ void __launch_bounds__(256, PS_ROWS >= 4 ? 6 : 8) core_sweep_wave_ker
         if (DO_GATHER) {
 #pragma unroll
             for (uint32_t rr = 0; rr < PS_ROWS; rr++)
-                if (rr < nr && has_chunk) *(uint4 *)(rowbuf + rr * a.pitch + i0) = v[rr];
+                if (rr < nr && has_chunk) *(uint4 *)(rowbuf + rr * 1024u + i0) = v[rr];
             ps_wave_sync();
         }
+        PS_T(0);   // global load + LDS stage
 
         uint32_t qn = 0;        // wave-uniform number of queued candidate cells
 #pragma unroll
         for (uint32_t rr = 0; rr < PS_ROWS; rr++) {
             if (rr < nr) {
-                uint8_t *row = rowbuf + rr * a.pitch;
+                uint8_t *row = rowbuf + rr * 1024u;
                 const uint32_t site = a.site_offset + r0 + rr;
                 uint4 d = v[rr];
                 if (DO_GATHER) {
@@ -299,12 +320,14 @@ __global__ void __launch_bounds__(256, PS_ROWS >= 4 ? 6 : 8) core_sweep_wave_ker
                     }
                     d = make_uint4(w[0], w[1], w[2], w[3]);
                 }
+                PS_T(1);   // gather
                 uint32_t cm = 0;
                 ps_u4 l1 = { 0, 0, 0, 0 };
                 if (events) {
                     l1 = ps_philox(site, lane, a.gen, PS_STREAM_CORE_L1, a.k0, a.k1);
                     cm = ps_candidates_swar(l1, c4) & vperm;
                 }
+                PS_T(2);   // level-1 Philox + detection
                 // the LDS row becomes the child row; every gather read precedes this store
                 if (DO_GATHER) ps_wave_sync();
                 if (has_chunk && (DO_GATHER || events)) *(uint4 *)(row + i0) = d;
@@ -328,6 +351,7 @@ __global__ void __launch_bounds__(256, PS_ROWS >= 4 ? 6 : 8) core_sweep_wave_ker
                         qn += (uint32_t)__popcll(bal);
                     }
                 }
+                PS_T(3);   // queue push
 #else
                 if (cm == 0xFFFFFFFFu) qn = 1;   // keep the detection alive
 #endif
@@ -353,16 +377,22 @@ __global__ void __launch_bounds__(256, PS_ROWS >= 4 ? 6 : 8) core_sweep_wave_ker
                 const uint32_t ent = valid ? q[e] : 0u;
                 const uint32_t byte = (ent >> 12) & 0xFFu;
                 uint32_t allele = 0;
-                if (byte < t0b) allele = 2u;
-                else if (byte > t0b && byte < t1b) allele = 4u;
-                else if (byte > t1b && byte < t2b) allele = 8u;
+                if (use_lut) {
+                    const uint32_t code = (uint32_t)(lut >> (2u * (byte & 31u))) & 3u;
+                    allele = code ? (1u << code) : 0u;
+                } else {
+                    if (byte < t0b) allele = 2u;
+                    else if (byte > t0b && byte < t1b) allele = 4u;
+                    else if (byte > t1b && byte < t2b) allele = 8u;
+                }
                 const bool amb = valid && allele == 0u;
-                if (DO_MUT && valid && allele) rowbuf[((ent >> 10) & 3u) * a.pitch + (ent & 1023u)] = (uint8_t)allele;
+                if (DO_MUT && valid && allele) rowbuf[ent & 4095u] = (uint8_t)allele;
                 const uint64_t bal = __ballot(amb);
                 if (amb) q[n2 + ps_lane_prefix(bal)] = ent;
                 n2 += (uint32_t)__popcll(bal);
             }
             ps_wave_sync();
+            PS_T(4);   // dense byte classification
             // exact pass over the undecided cells: level-2 Philox, 32-bit thresholds
             for (uint32_t base = 0; base < n2; base += 64u) {
                 const uint32_t e = base + lane;
@@ -371,7 +401,7 @@ __global__ void __launch_bounds__(256, PS_ROWS >= 4 ? 6 : 8) core_sweep_wave_ker
                     const uint32_t cellidx = ent & 1023u, rr = (ent >> 10) & 3u, byte = (ent >> 12) & 0xFFu;
                     const ps_u4 l2 = ps_philox(a.site_offset + r0 + rr, cellidx, a.gen, PS_STREAM_CORE_L2, a.k0, a.k1);
                     const ps_cell cell = ps_classify((byte << 24) | (l2.x >> 8), pl);
-                    if (DO_MUT && cell.mut) rowbuf[rr * a.pitch + cellidx] = (uint8_t)cell.mut;
+                    if (DO_MUT && cell.mut) rowbuf[ent & 4095u] = (uint8_t)cell.mut;
                     if (DO_HR) {
                         uint32_t out = 0;
                         if (cell.hr) {
@@ -390,8 +420,8 @@ __global__ void __launch_bounds__(256, PS_ROWS >= 4 ? 6 : 8) core_sweep_wave_ker
                     if (e < n2) {
                         const uint32_t ent = q[e];
                         if (ent >> 31) {
-                            const uint32_t rr = (ent >> 10) & 3u, donor = (ent >> 12) & 1023u;
-                            q[e] = (ent & 4095u) | ((uint32_t)rowbuf[rr * a.pitch + donor] << 12) | 0x80000000u;
+                            const uint32_t donor = (ent >> 12) & 1023u;
+                            q[e] = (ent & 4095u) | ((uint32_t)rowbuf[(ent & 3072u) | donor] << 12) | 0x80000000u;
                         }
                     }
                 }
@@ -400,25 +430,31 @@ __global__ void __launch_bounds__(256, PS_ROWS >= 4 ? 6 : 8) core_sweep_wave_ker
                     const uint32_t e = base + lane;
                     if (e < n2) {
                         const uint32_t ent = q[e];
-                        if (ent >> 31) rowbuf[((ent >> 10) & 3u) * a.pitch + (ent & 1023u)] = (uint8_t)((ent >> 12) & 0xFFu);
+                        if (ent >> 31) rowbuf[ent & 4095u] = (uint8_t)((ent >> 12) & 0xFFu);
                     }
                 }
             }
             ps_wave_sync();
         }
 #endif
+        PS_T(5);   // exact pass + HR
 
         if (has_chunk) {
 #pragma unroll
             for (uint32_t rr = 0; rr < PS_ROWS; rr++) {
                 if (rr < nr) {
-                    const uint4 o = (DO_GATHER || events) ? *(const uint4 *)(rowbuf + rr * a.pitch + i0) : v[rr];
+                    const uint4 o = (DO_GATHER || events) ? *(const uint4 *)(rowbuf + rr * 1024u + i0) : v[rr];
                     *(uint4 *)(a.state + (size_t)(r0 + rr) * a.pitch + i0) = o;
                 }
             }
         }
         ps_wave_sync();   // the next iteration overwrites the LDS rows and the queue
+        PS_T(6);   // LDS read-back + global store
     }
+#ifdef PS_STAMP
+    if (lane == 0)
+        for (int k = 0; k < 8; k++) atomicAdd((unsigned long long *)a.stamps + k, st_acc[k]);
+#endif
 }
 
 // ---------------------------------------------------------------------------

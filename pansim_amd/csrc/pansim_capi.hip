@@ -201,6 +201,7 @@ struct ps_population {
     bool force_block_sweep = false;     // tests: run the block sweep on small populations
     bool force_inline_sweep = false;    // tests: run the inline (queue-free) block sweep
     uint32_t *h_flag = nullptr, *d_flag = nullptr;   // host-mapped sticky device error word
+    unsigned long long *h_stamps = nullptr, *d_stamps = nullptr;   // diagnostic phase stamps
 };
 
 static int use_device(const ps_population *p)
@@ -219,6 +220,11 @@ extern "C" void ps_population_destroy(ps_population *p)
     for (void *q : ptrs)
         if (q) (void)hipFree(q);
     if (p->h_flag) (void)hipHostFree(p->h_flag);
+    if (p->h_stamps) {
+        if (getenv("PANSIM_PRINT_STAMPS"))
+            for (int k = 0; k < 8; k++) fprintf(stderr, "stamp[%d] = %llu\n", k, p->h_stamps[k]);
+        (void)hipHostFree(p->h_stamps);
+    }
     if (p->stream) (void)hipStreamDestroy(p->stream);
     delete p;
 }
@@ -248,6 +254,9 @@ static int pop_create_impl(const ps_config *cfg, const uint8_t *init_vec, ps_pop
     HIPCHK(hipMalloc(&p->d_idx, std::max<uint64_t>(N, 1) * sizeof(uint32_t)));
     HIPCHK(hipHostMalloc(&p->h_flag, sizeof(uint32_t), hipHostMallocMapped));
     *p->h_flag = 0;
+    HIPCHK(hipHostMalloc(&p->h_stamps, 8 * sizeof(unsigned long long), hipHostMallocMapped));
+    memset(p->h_stamps, 0, 8 * sizeof(unsigned long long));
+    HIPCHK(hipHostGetDevicePointer((void **)&p->d_stamps, p->h_stamps, 0));
     HIPCHK(hipHostGetDevicePointer((void **)&p->d_flag, p->h_flag, 0));
     uint8_t *d_vec = nullptr;
     HIPCHK(hipMalloc(&d_vec, std::max<uint64_t>(C, 1)));
@@ -482,7 +491,7 @@ template <uint32_t ROWS, bool GA, bool MU, bool HR>
 static int launch_core_sweep_wave_r(ps_population *p, const core_sweep_args &a, hipStream_t st)
 {
     const uint32_t block = 256u, wpb = block / 64u;
-    const uint32_t lds = wpb * (ROWS * a.pitch + ps_qcap(ROWS) * 4u);
+    const uint32_t lds = wpb * (ROWS * 1024u + ps_qcap(ROWS) * 4u);
     const uint32_t want = (a.rows + wpb * ROWS - 1) / (wpb * ROWS);
     const uint32_t fit = std::max(1u, std::min(8u, p->lds_limit / lds));
     const uint32_t bpc = std::min(p->sweep_blocks_per_cu, fit);
@@ -599,6 +608,7 @@ static int launch_core_sweep(ps_population *p, const uint32_t *d_idx, uint32_t g
     if (!mu && !hr) a.plan.has_events = 0;
     const bool wave = wave_sweep_eligible(p, mu, hr);
     a.overflow_flag = p->d_flag;
+    a.stamps = p->d_stamps;
     a.idxT = p->d_idxT;
     if (!wave && ga) {
         const uint32_t n = 16u * p->cpr;
