@@ -281,3 +281,35 @@ __global__ void acc_average_distance_kernel(const uint64_t *accI, double *out, a
     if (fd == 0.0) fd = 2.2250738585072014e-308;   // f64::MIN_POSITIVE, population.rs:774-776
     out[i] = fd;
 }
+
+// D-avg in two steps for populations whose N x N distance matrix fits in memory:
+// (1) every pair's Jaccard distance, written transposed (the distance is symmetric bit for bit),
+// (2) one thread per individual sums its column in ascending j -- the reference's left-to-right
+//     fold (population.rs:770) -- with coalesced reads.
+__global__ void __launch_bounds__(256) acc_pair_matrix_kernel(const uint64_t *accI, double *Dt, acc_dims d,
+                                                              double core_genes)
+{
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x, i = blockIdx.y;
+    if (j >= d.N) return;
+    const uint64_t *x = accI + (uint64_t)i * d.GW, *y = accI + (uint64_t)j * d.GW;
+    uint32_t in = 0, un = 0;
+    for (uint32_t gw = 0; gw < d.GW; gw++) {
+        in += __popcll(x[gw] & y[gw]);
+        un += __popcll(x[gw] | y[gw]);
+    }
+    Dt[(uint64_t)i * d.N + j] = 1.0 - (((double)in + 0.0 + core_genes) / ((double)un + 0.0 + core_genes));
+}
+
+__global__ void __launch_bounds__(64) acc_average_from_matrix_kernel(const double *Dt, double *out, acc_dims d)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= d.N) return;
+    double sum = 0.0;
+    for (uint32_t j = 0; j < d.N; j++) {
+        if (j == i) continue;
+        sum = sum + Dt[(uint64_t)j * d.N + i];      // = distance(i, j)
+    }
+    double fd = sum / (double)(d.N - 1u);
+    if (fd == 0.0) fd = 2.2250738585072014e-308;    // f64::MIN_POSITIVE, population.rs:774-776
+    out[i] = fd;
+}

@@ -190,6 +190,7 @@ struct ps_population {
     int32_t *d_num_genes = nullptr;  // N
     double *d_logw = nullptr;        // N
     uint32_t *d_H = nullptr;         // all-pairs Hamming numerators N x N
+    double *d_Dt = nullptr;          // all-pairs Jaccard distances (D-avg), N x N
     uint64_t H_cap = 0;
     int pair_mode = 0;               // 0 auto, 1 sampled kernel, 2 all-pairs kernel (tuning/tests)
     void *d_pairs = nullptr;         // sorted r1 | r2 | perm | outA | outB
@@ -216,7 +217,7 @@ extern "C" void ps_population_destroy(ps_population *p)
     (void)hipSetDevice(p->device);
     if (p->stream) (void)hipStreamSynchronize(p->stream);
     void *ptrs[] = { p->state, p->G[0], p->G[1], p->I[0], p->I[1], p->glist, p->cnt, p->d_idx, p->d_idxT,
-                     p->d_log1p, p->d_num_genes, p->d_logw, p->d_pairs, p->d_H };
+                     p->d_log1p, p->d_num_genes, p->d_logw, p->d_pairs, p->d_H, p->d_Dt };
     for (void *q : ptrs)
         if (q) (void)hipFree(q);
     if (p->h_flag) (void)hipHostFree(p->h_flag);
@@ -870,6 +871,23 @@ extern "C" int ps_sample_indices(ps_population *acc, uint32_t generation, int32_
 // ---------------------------------------------------------------------------
 // distances
 // ---------------------------------------------------------------------------
+// D-avg (population.rs:753-784) into a device buffer of N doubles
+static int average_distance_device(ps_population *p, double *d_out, hipStream_t st)
+{
+    const uint64_t N = p->cfg.pop_size;
+    if (N <= 8192) {
+        if (!p->d_Dt) HIPCHK(hipMalloc(&p->d_Dt, N * N * sizeof(double)));
+        dim3 grid((uint32_t)((N + 255) / 256), (uint32_t)N);
+        acc_pair_matrix_kernel<<<grid, 256, 0, st>>>(p->I[p->cur], p->d_Dt, p->d, (double)p->cfg.core_genes);
+        acc_average_from_matrix_kernel<<<(uint32_t)((N + 63) / 64), 64, 0, st>>>(p->d_Dt, d_out, p->d);
+    } else {
+        acc_average_distance_kernel<<<(uint32_t)((N + 63) / 64), 64, 0, st>>>(p->I[p->cur], d_out, p->d,
+                                                                         (double)p->cfg.core_genes);
+    }
+    HIPCHK(hipGetLastError());
+    return PS_OK;
+}
+
 static int ensure_pairs(ps_population *p, uint64_t P)
 {
     if (P <= p->pairs_cap) return PS_OK;
@@ -1031,9 +1049,7 @@ extern "C" int ps_average_distance(ps_population *p, double *out)
     double *d_out = nullptr;
     const uint64_t N = p->cfg.pop_size;
     HIPCHK(hipMalloc(&d_out, N * sizeof(double)));
-    acc_average_distance_kernel<<<(uint32_t)((N + 63) / 64), 64, 0, p->stream>>>(p->I[p->cur], d_out, p->d,
-                                                                              (double)p->cfg.core_genes);
-    HIPCHK(hipGetLastError());
+    PSCHK(average_distance_device(p, d_out, p->stream));
     HIPCHK(hipMemcpyAsync(out, d_out, N * sizeof(double), hipMemcpyDeviceToHost, p->stream));
     HIPCHK(hipStreamSynchronize(p->stream));
     HIPCHK(hipFree(d_out));
@@ -1501,9 +1517,7 @@ static int sim_one_generation(ps_sim *s, uint32_t gen)
     // main.rs:435-440
     for (uint64_t i = 0; i < N; i++) s->h_avg[i] = 1.0;
     if (p.competition_strength > 0.0) {
-        acc_average_distance_kernel<<<(uint32_t)((N + 63) / 64), 64, 0, sa>>>(acc->I[acc->cur], s->d_avg, acc->d,
-                                                                         (double)p.core_genes);
-        HIPCHK(hipGetLastError());
+        PSCHK(average_distance_device(acc, s->d_avg, sa));
         HIPCHK(hipMemcpyAsync(s->h_avg, s->d_avg, N * sizeof(double), hipMemcpyDeviceToHost, sa));
     }
     // main.rs:442-443: device half of sample_indices ...
