@@ -302,8 +302,18 @@ uint64_t orc_recombine_acc(uint8_t *pop, uint64_t N, uint64_t G, uint64_t seed, 
     memcpy(snap, pop, N * G);
     uint32_t key[2] = { (uint32_t)seed, (uint32_t)(seed >> 32) };
     uint64_t total = 0;
+    uint32_t *list = (uint32_t *)malloc(N * G * sizeof(uint32_t));   /* present genes of a donor */
+    uint32_t *cnt = (uint32_t *)malloc(N * sizeof(uint32_t));
     for (int c = 0; c < n_comp; c++) {
         if (lambdas[c] == 0.0) continue;                 /* population.rs:558 */
+        /* the donor's WeightedIndex over its present genes of the compartment
+         * (population.rs:636-680), built once per donor from the snapshot */
+        for (uint64_t d = 0; d < N; d++) {
+            uint32_t n = 0;
+            for (uint64_t g = comp_begin[c]; g < comp_end[c]; g++)
+                if (snap[d * G + g] != 0) list[d * G + n++] = (uint32_t)g;
+            cnt[d] = n;
+        }
         uint32_t stream_c = ORC_STREAM_HGT_COUNT | ((uint32_t)c << 8);
         uint64_t K = orc_poisson((double)N * lambdas[c], seed, stream_c, gen, NULL);
         total += K;
@@ -315,17 +325,14 @@ uint64_t orc_recombine_acc(uint8_t *pop, uint64_t N, uint64_t G, uint64_t seed, 
             uint32_t d = mulhi32(w[0], (uint32_t)N);
             uint32_t r = mulhi32(w[1], (uint32_t)(N - 1));
             if (r >= d) r++;
-            uint32_t n = 0;
-            for (uint64_t g = comp_begin[c]; g < comp_end[c]; g++) n += snap[(uint64_t)d * G + g] != 0;
+            uint32_t n = cnt[d];
             if (n == 0) continue;                        /* population.rs:672 */
             uint32_t j = mulhi32(w[2], n);
-            uint64_t gene = comp_begin[c];
-            for (;; gene++) {
-                if (snap[(uint64_t)d * G + gene] != 0) { if (j == 0) break; j--; }
-            }
-            pop[(uint64_t)r * G + gene] = 1;
+            pop[(uint64_t)r * G + list[(uint64_t)d * G + j]] = 1;
         }
     }
+    free(list);
+    free(cnt);
     free(snap);
     return total;
 }

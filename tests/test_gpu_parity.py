@@ -437,3 +437,79 @@ def test_block_sweep_equals_wave_sweep(pa, orc, N, L, lm, lh):
             pop.step(2, sample, True)
             assert np.array_equal(pop.read_matrix(), want)
             pop.close()
+
+
+# ----------------------------------------------------------------------------- BASELINE full sizes
+def _crc(a):
+    import zlib
+    return zlib.crc32(np.ascontiguousarray(a).view(np.uint8))
+
+
+def test_config2_full_size_generation_matches_oracle(pa, orc):
+    # BASELINE configs[1]: --pop_size 1000 --core_size 1200000 --pan_genes 6000 --seed 0.
+    # One whole generation (select, gather, mutate, HR, HGT) bit-exact against the oracle.
+    from orc_sim import OracleSim
+    kw = dict(pop_size=1000, core_size=1200000, pan_genes=6000, core_genes=2000)
+    sim = pa.Simulation(pa.make_params(seed=0, n_gen=2, max_distances=20000, **kw))
+    ref = OracleSim(seed=0, **kw)
+    sim.run(1)
+    sim.sync()
+    ref.generation(0)
+    assert np.array_equal(sim.last_parents(), ref.last_idx)
+    got = sim.core_genome.read_matrix()
+    assert _crc(got) == _crc(ref.core) and np.array_equal(got, ref.core)
+    assert np.array_equal(sim.pan_genome.read_matrix(), ref.acc)
+    core_d, acc_d = sim.final_distances()
+    assert np.array_equal(core_d, orc.pairwise_distances(ref.core, True, 2000, sim.range1, sim.range2))
+    assert np.array_equal(acc_d, orc.pairwise_distances(ref.acc, False, 2000, sim.range1, sim.range2))
+    sim.close()
+
+
+def test_config2_full_size_properties(pa):
+    # size-independent properties at the full benchmark size, over several generations
+    kw = dict(pop_size=1000, core_size=1200000, pan_genes=6000, core_genes=2000)
+    runs = []
+    for _ in range(2):
+        sim = pa.Simulation(pa.make_params(seed=0, n_gen=8, max_distances=50000, **kw))
+        sim.run(8)
+        core_d, acc_d = sim.final_distances()
+        (cnt,) = sim.core_genome.pairwise_counts(sim.range1, sim.range2)
+        runs.append((sim.last_parents(), core_d, acc_d, cnt, sim.pan_genome.gene_frequencies()))
+        if not runs[1:]:
+            m = sim.core_genome.read_matrix()
+            assert np.isin(m, (1, 2, 4, 8)).all()                     # alleles stay one-hot
+            assert (cnt % 2 == 0).all()                                # so every mismatch counts 2 (population.rs:817)
+            i, j = int(sim.range1[0]), int(sim.range2[0])
+            assert cnt[0] == 2 * int((m[i] != m[j]).sum())
+            full_crc = [_crc(m[:, :600000]), _crc(m[:, 600000:])]
+        sim.close()
+    for a, b in zip(runs[0], runs[1]):                                 # deterministic replay under --seed
+        assert np.array_equal(a, b)
+    # two site shards reproduce their halves of the unsharded run and their counts add up
+    cnt_sum = np.zeros_like(runs[0][3])
+    for r in range(2):
+        sh = pa.Simulation(pa.make_params(seed=0, n_gen=8, max_distances=50000, shard_rank=r, shard_count=2, **kw))
+        sh.run(8)
+        sh.sync()
+        assert _crc(sh.core_genome.read_matrix()) == full_crc[r]
+        cnt_sum += sh.core_genome.pairwise_counts(sh.range1, sh.range2)[0]
+        sh.close()
+    assert np.array_equal(cnt_sum, runs[0][3])
+
+
+def test_config3_rates_full_width_rows(pa, orc):
+    # BASELINE configs[2]: HR_rate = HGT_rate = 0.5 (donor-copy path stressed), full population,
+    # a slice of the genome keyed at its global site offset
+    from orc_sim import OracleSim
+    kw = dict(pop_size=1000, core_size=1200000, pan_genes=6000, core_genes=2000, HR_rate=0.5, HGT_rate=0.5)
+    ref = OracleSim(seed=0, site_begin=700000, site_end=720000, **kw)
+    p = pa.make_params(seed=0, n_gen=3, max_distances=1000, shard_rank=35, shard_count=60, **kw)
+    sim = pa.Simulation(p)
+    assert sim.core_genome.ncols == 20000
+    for g in range(2):
+        sim.run(1)
+        ref.generation(g)
+    sim.sync()
+    assert np.array_equal(sim.core_genome.read_matrix(), ref.core)
+    assert np.array_equal(sim.pan_genome.read_matrix(), ref.acc)
+    sim.close()
