@@ -490,17 +490,20 @@ __global__ void __launch_bounds__(1024) core_sweep_block_kernel(core_sweep_args 
 
     for (uint32_t r0 = blockIdx.x * g.R; r0 < a.rows; r0 += gridDim.x * g.R) {
         const uint32_t nr = min(g.R, a.rows - r0);
-        // cooperative, coalesced load of the row group
-        for (uint32_t c = tid; c < nr * a.cpr; c += blockDim.x) {
-            const uint32_t rr = c / a.cpr, ch = c % a.cpr;
-            const uint4 v = *(const uint4 *)(a.state + (size_t)(r0 + rr) * a.pitch + 16u * ch);
-            *(uint4 *)((DO_GATHER ? rowA : rowS) + rr * a.pitch + 16u * ch) = v;
+        // cooperative, coalesced load of the row group (rows are contiguous in HBM and in LDS)
+        {
+            const uint8_t *src = a.state + (size_t)r0 * a.pitch;
+            uint8_t *dst = DO_GATHER ? rowA : rowS;
+            for (uint32_t o = tid * 16u; o < nr * a.pitch; o += blockDim.x * 16u)
+                *(uint4 *)(dst + o) = *(const uint4 *)(src + o);
         }
         __syncthreads();
 
         uint32_t nhr = 0;       // wave-uniform length of this wave's HR list
-        for (uint32_t item = wave; item < nr * g.segs; item += nw) {
-            const uint32_t rr = item / g.segs, sg = item % g.segs;
+        // items (row, segment) are dealt to the waves round-robin; (rr, sg) advance incrementally
+        uint32_t rr = wave / g.segs, sg = wave % g.segs;
+        for (uint32_t item = wave; item < nr * g.segs; item += nw, sg += nw) {
+            while (sg >= g.segs) { sg -= g.segs; rr++; }
             const uint32_t chunk = sg * 64u + lane;
             const bool has_chunk = chunk < a.cpr;
             const uint32_t i0 = chunk * 16u;
@@ -511,15 +514,16 @@ __global__ void __launch_bounds__(1024) core_sweep_block_kernel(core_sweep_args 
                 const uint8_t *par = rowA + rr * a.pitch;
                 uint32_t w[4] = { 0, 0, 0, 0 };
                 if (has_chunk) {
+                    // idxT[k][chunk]: consecutive lanes read consecutive words; entries beyond N
+                    // hold the index of the row's first padding byte (always 0)
+                    const uint32_t *ip = a.idxT + chunk;
 #pragma unroll
                     for (int j = 0; j < 4; j++) {
                         uint32_t x = 0;
 #pragma unroll
                         for (int b = 0; b < 4; b++) {
-                            const uint32_t k = 4 * j + b;
-                            // idxT[k][chunk]: consecutive lanes read consecutive words
-                            const uint32_t v = (k < nvalid) ? (uint32_t)par[a.idxT[k * a.cpr + chunk]] : 0u;
-                            x |= v << (8 * b);
+                            x |= (uint32_t)par[*ip] << (8 * b);
+                            ip += a.cpr;
                         }
                         w[j] = x;
                     }
@@ -527,10 +531,11 @@ __global__ void __launch_bounds__(1024) core_sweep_block_kernel(core_sweep_args 
                 }
             }
             if (!events) continue;
-            uint32_t vperm = 0;
-#pragma unroll
-            for (uint32_t k = 0; k < 16; k++)
-                if (k < nvalid) vperm |= 1u << (8u * (k & 3u) + 7u - (k >> 2));
+            uint32_t vperm = 0xF0F0F0F0u;   // all 16 cells valid
+            if (nvalid < 16u) {
+                vperm = 0;
+                for (uint32_t k = 0; k < nvalid; k++) vperm |= 1u << (8u * (k & 3u) + 7u - (k >> 2));
+            }
             const ps_u4 l1 = ps_philox(site, chunk, a.gen, PS_STREAM_CORE_L1, a.k0, a.k1);
             uint32_t cm = ps_candidates_swar(l1, c4) & vperm;
             uint32_t qn = 0;
@@ -613,9 +618,10 @@ __global__ void __launch_bounds__(1024) core_sweep_block_kernel(core_sweep_args 
             for (uint32_t e = lane; e < nhr; e += 64u) rowS[hr_a[e]] = (uint8_t)hr_b[e];
         }
         __syncthreads();
-        for (uint32_t c = tid; c < nr * a.cpr; c += blockDim.x) {
-            const uint32_t rr = c / a.cpr, ch = c % a.cpr;
-            *(uint4 *)(a.state + (size_t)(r0 + rr) * a.pitch + 16u * ch) = *(const uint4 *)(rowS + rr * a.pitch + 16u * ch);
+        {
+            uint8_t *dstg = a.state + (size_t)r0 * a.pitch;
+            for (uint32_t o = tid * 16u; o < nr * a.pitch; o += blockDim.x * 16u)
+                *(uint4 *)(dstg + o) = *(const uint4 *)(rowS + o);
         }
         __syncthreads();        // the next row group overwrites the LDS rows
     }
@@ -627,7 +633,7 @@ __global__ void idx_transpose_kernel(const uint32_t *idx, uint32_t *idxT, uint32
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= 16u * cpr) return;
     const uint32_t k = t / cpr, chunk = t % cpr, i = chunk * 16u + k;
-    idxT[t] = (i < N) ? idx[i] : 0u;
+    idxT[t] = (i < N) ? idx[i] : N;   // N = first padding byte of a row (always 0); unused if N == pitch
 }
 
 // clonal start: every individual gets allele_vec[site] (population.rs:206-212)
