@@ -158,7 +158,8 @@ def main():
     if rank == 0:
         avg_ms = sweep_ms / max(launches, 1)
         achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if launches else 0.0
-        traffic, traffic_src = pmc_traffic() if (args.pop_size, args.core_size) == (1000, 1200000) else (None, None)
+        default_wl = (args.pop_size, args.core_size, args.pan_genes, args.HR_rate, args.HGT_rate) == (1000, 1200000, 6000, 0.05, 0.05)
+        traffic, traffic_src = pmc_traffic() if default_wl else (None, None)
         out = {
             "metric": "generations/sec", "value": world * args.steps / dt,
             "unit": "generations/s (pop=%d, %d core sites per GPU, pan=%d)" % (args.pop_size, args.core_size, args.pan_genes),

@@ -181,22 +181,51 @@ __global__ void __launch_bounds__(256) acc_hgt_kernel(acc_hgt_args a)
     const acc_dims d = a.d;
     uint64_t total = 0;
     for (uint32_t c = 0; c < a.n_comp; c++) total += a.K[c];
-    for (uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total;
-         t += (uint64_t)gridDim.x * blockDim.x) {
-        uint32_t comp = 0;
-        uint64_t e = t;
-        while (comp + 1 < a.n_comp && e >= a.K[comp]) { e -= a.K[comp]; comp++; }
-        const ps_u4 r = ps_philox((uint32_t)e, (uint32_t)(e >> 32), a.gen, PS_STREAM_HGT | (comp << 8), a.k0, a.k1);
-        const uint32_t dn = ps_mulhi(r.x, d.N);
-        uint32_t rc = ps_mulhi(r.y, d.N - 1u);
-        rc += (rc >= dn) ? 1u : 0u;                         // population.rs:618
-        const uint32_t n = a.cnt[(uint64_t)comp * d.N + dn];
-        if (n == 0) continue;                               // population.rs:672
-        const uint32_t j = ps_mulhi(r.z, n);
-        const uint32_t gene = a.list[(uint64_t)dn * d.G + a.gb[comp] + j];
-        // 32-bit atomic on the half word that holds the bit
-        uint32_t *w32 = (uint32_t *)&a.dstI[(uint64_t)rc * d.GW + (gene >> 6)] + ((gene >> 5) & 1u);
-        atomicOr(w32, 1u << (gene & 31u));
+    // four independent events per thread and iteration: the dependent chain of an event
+    // (count -> list entry -> atomic) is pure memory latency, so keep several in flight
+    constexpr int E = 4;
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t t0 = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; t0 < total; t0 += stride * E) {
+        uint32_t comp[E], dn[E], rc[E], n[E], rz[E];
+        bool live[E];
+#pragma unroll
+        for (int q = 0; q < E; q++) {
+            const uint64_t t = t0 + (uint64_t)q * stride;
+            live[q] = t < total;
+            uint32_t c = 0;
+            uint64_t e = live[q] ? t : 0;
+            while (c + 1 < a.n_comp && e >= a.K[c]) { e -= a.K[c]; c++; }
+            comp[q] = c;
+            const ps_u4 r = ps_philox((uint32_t)e, (uint32_t)(e >> 32), a.gen, PS_STREAM_HGT | (c << 8), a.k0, a.k1);
+            dn[q] = ps_mulhi(r.x, d.N);
+            uint32_t x = ps_mulhi(r.y, d.N - 1u);
+            x += (x >= dn[q]) ? 1u : 0u;                    // population.rs:618
+            rc[q] = x;
+            rz[q] = r.z;
+        }
+#pragma unroll
+        for (int q = 0; q < E; q++) n[q] = live[q] ? a.cnt[(uint64_t)comp[q] * d.N + dn[q]] : 0u;
+        uint32_t gene[E];
+#pragma unroll
+        for (int q = 0; q < E; q++) {
+            live[q] = live[q] && n[q] != 0u;                // population.rs:672
+            gene[q] = live[q] ? a.list[(uint64_t)dn[q] * d.G + a.gb[comp[q]] + ps_mulhi(rz[q], n[q])] : 0u;
+        }
+        uint32_t *w32[E];
+        uint32_t cur[E];
+#pragma unroll
+        for (int q = 0; q < E; q++) {
+            // 32-bit half of the recipient's row word that holds the bit
+            w32[q] = (uint32_t *)&a.dstI[(uint64_t)rc[q] * d.GW + (gene[q] >> 6)] + ((gene[q] >> 5) & 1u);
+            cur[q] = live[q] ? __hip_atomic_load(w32[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0xFFFFFFFFu;
+        }
+#pragma unroll
+        for (int q = 0; q < E; q++) {
+            const uint32_t bit = 1u << (gene[q] & 31u);
+            // bits only ever get set here, so a stale read can only cause a redundant OR; most
+            // events target a gene the recipient already carries and skip the atomic
+            if (live[q] && (cur[q] & bit) == 0u) atomicOr(w32[q], bit);
+        }
     }
 }
 
