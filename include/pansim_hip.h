@@ -149,7 +149,8 @@ int ps_sync(ps_population *p);
  * (site rows a wave of that sweep takes per iteration, 2..4),
  * "force_block_sweep" (0/1: use the block sweep even when a row fits one wavefront),
  * "force_inline_sweep" (0/1: use the queue-free inline block sweep), "pair_mode" (core
- * distances: 0 = choose by cost, 1 = sampled-pair kernel, 2 = all-pairs tiles + lookup), "lds_limit" (bytes of LDS a workgroup may use). */
+ * distances: 0 = choose by cost, 1 = sampled-pair kernel, 2 = all-pairs tiles + lookup),
+ * "hgt_mode" (accessory recombination: 0 = choose, 1 = global atomics, 2 = LDS partitions), "lds_limit" (bytes of LDS a workgroup may use). */
 int ps_set_tuning(ps_population *p, const char *key, int64_t value);
 
 /* ------------------------------------------------------------------------ */

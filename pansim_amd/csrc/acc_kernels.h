@@ -76,7 +76,8 @@ __global__ void acc_unpack_rows_kernel(const uint64_t *accI, uint8_t *rows, acc_
 struct acc_step_args {
     const uint64_t *srcG;
     uint64_t *dstG, *dstI;
-    const uint32_t *idx;
+    const uint32_t *idx;      // parents; may alias host-mapped pinned memory (read once per lane)
+    uint32_t *idx_out;        // if set, the gene-block-0 waves publish the parents in device memory
     acc_dims d;
     uint32_t gen, k0, k1;
     ps_acc_plan plan;
@@ -93,6 +94,7 @@ __global__ void __launch_bounds__(64) acc_step_kernel(acc_step_args a)
     const uint32_t i = w * 64u + lane;
     const bool valid = i < d.N;
     const uint32_t p = (DO_GATHER && valid) ? a.idx[i] : (valid ? i : 0u);
+    if (DO_GATHER && a.idx_out && gw == 0 && valid) a.idx_out[i] = p;
     const uint32_t pw = p >> 6, pb = p & 63u;
     uint64_t rowword = 0;
     ps_u4 rnd = { 0, 0, 0, 0 };
@@ -180,10 +182,12 @@ __global__ void __launch_bounds__(256) acc_hgt_kernel(acc_hgt_args a)
 {
     const acc_dims d = a.d;
     uint64_t total = 0;
-    for (uint32_t c = 0; c < a.n_comp; c++) total += a.K[c];
+    total = a.K[0] + (a.n_comp > 1 ? a.K[1] : 0ull);
     // four independent events per thread and iteration: the dependent chain of an event
     // (count -> list entry -> atomic) is pure memory latency, so keep several in flight
     constexpr int E = 4;
+    const uint64_t K0 = a.K[0];
+    const uint32_t gb0 = a.gb[0], gb1 = a.gb[1];
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     for (uint64_t t0 = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; t0 < total; t0 += stride * E) {
         uint32_t comp[E], dn[E], rc[E], n[E], rz[E];
@@ -192,9 +196,11 @@ __global__ void __launch_bounds__(256) acc_hgt_kernel(acc_hgt_args a)
         for (int q = 0; q < E; q++) {
             const uint64_t t = t0 + (uint64_t)q * stride;
             live[q] = t < total;
-            uint32_t c = 0;
+            // two compartments at most: select instead of indexing the kernel arguments per lane
+            // (a per-lane index would force the argument arrays through scratch memory)
             uint64_t e = live[q] ? t : 0;
-            while (c + 1 < a.n_comp && e >= a.K[c]) { e -= a.K[c]; c++; }
+            const uint32_t c = (a.n_comp > 1 && e >= K0) ? 1u : 0u;
+            e -= c ? K0 : 0ull;
             comp[q] = c;
             const ps_u4 r = ps_philox((uint32_t)e, (uint32_t)(e >> 32), a.gen, PS_STREAM_HGT | (c << 8), a.k0, a.k1);
             dn[q] = ps_mulhi(r.x, d.N);
@@ -209,7 +215,7 @@ __global__ void __launch_bounds__(256) acc_hgt_kernel(acc_hgt_args a)
 #pragma unroll
         for (int q = 0; q < E; q++) {
             live[q] = live[q] && n[q] != 0u;                // population.rs:672
-            gene[q] = live[q] ? a.list[(uint64_t)dn[q] * d.G + a.gb[comp[q]] + ps_mulhi(rz[q], n[q])] : 0u;
+            gene[q] = live[q] ? a.list[(uint64_t)dn[q] * d.G + (comp[q] ? gb1 : gb0) + ps_mulhi(rz[q], n[q])] : 0u;
         }
         uint32_t *w32[E];
         uint32_t cur[E];
@@ -225,6 +231,51 @@ __global__ void __launch_bounds__(256) acc_hgt_kernel(acc_hgt_args a)
             // bits only ever get set here, so a stale read can only cause a redundant OR; most
             // events target a gene the recipient already carries and skip the atomic
             if (live[q] && (cur[q] & bit) == 0u) atomicOr(w32[q], bit);
+        }
+    }
+}
+
+// HGT with the recipients tiled through LDS (small populations, many events): workgroup
+// (part, slice) keeps the row words of the recipients of partition `part` in LDS, scans event
+// slice `slice`, ORs the events that land in its partition with LDS atomics and finally merges
+// its non-zero words into HBM with coalesced atomics.  Every partition re-derives the slice's
+// events (a Philox call is far cheaper than a scattered global atomic); same events, same keys.
+__global__ void __launch_bounds__(1024) acc_hgt_lds_kernel(acc_hgt_args a, uint32_t rows_per_part, uint32_t n_slices)
+{
+    extern __shared__ uint32_t lrow[];     // [rows_per_part][2*GW] 32-bit words
+    const acc_dims d = a.d;
+    const uint32_t part = blockIdx.x / n_slices, slice = blockIdx.x % n_slices;
+    const uint32_t r_lo = part * rows_per_part, r_hi = min(d.N, r_lo + rows_per_part);
+    const uint32_t W32 = 2u * d.GW;
+    for (uint32_t w = threadIdx.x; w < rows_per_part * W32; w += blockDim.x) lrow[w] = 0u;
+    __syncthreads();
+    uint64_t total = 0;
+    total = a.K[0] + (a.n_comp > 1 ? a.K[1] : 0ull);
+    const uint64_t K0 = a.K[0];
+    const uint32_t gb0 = a.gb[0], gb1 = a.gb[1];
+    const uint64_t per = (total + n_slices - 1) / n_slices;
+    const uint64_t t_end = min(total, (uint64_t)(slice + 1) * per);
+    for (uint64_t t = (uint64_t)slice * per + threadIdx.x; t < t_end; t += blockDim.x) {
+        uint64_t e = t;
+        const uint32_t comp = (a.n_comp > 1 && e >= K0) ? 1u : 0u;
+        e -= comp ? K0 : 0ull;
+        const ps_u4 r = ps_philox((uint32_t)e, (uint32_t)(e >> 32), a.gen, PS_STREAM_HGT | (comp << 8), a.k0, a.k1);
+        const uint32_t dn = ps_mulhi(r.x, d.N);
+        uint32_t rc = ps_mulhi(r.y, d.N - 1u);
+        rc += (rc >= dn) ? 1u : 0u;                         // population.rs:618
+        if (rc < r_lo || rc >= r_hi) continue;              // another partition's recipient
+        const uint32_t n = a.cnt[(uint64_t)comp * d.N + dn];
+        if (n == 0) continue;                               // population.rs:672
+        const uint32_t gene = a.list[(uint64_t)dn * d.G + (comp ? gb1 : gb0) + ps_mulhi(r.z, n)];
+        atomicOr(&lrow[(rc - r_lo) * W32 + (gene >> 5)], 1u << (gene & 31u));
+    }
+    __syncthreads();
+    uint32_t *dst32 = (uint32_t *)a.dstI;
+    for (uint32_t w = threadIdx.x; w < (r_hi - r_lo) * W32; w += blockDim.x) {
+        const uint32_t v = lrow[w];
+        if (v) {
+            uint32_t *g = dst32 + (uint64_t)r_lo * W32 + w;
+            if ((v & ~__hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) != 0u) atomicOr(g, v);
         }
     }
 }

@@ -193,6 +193,7 @@ struct ps_population {
     double *d_Dt = nullptr;          // all-pairs Jaccard distances (D-avg), N x N
     uint64_t H_cap = 0;
     int pair_mode = 0;               // 0 auto, 1 sampled kernel, 2 all-pairs kernel (tuning/tests)
+    int hgt_mode = 0;                // 0 auto, 1 global-atomic kernel, 2 LDS-partitioned kernel
     void *d_pairs = nullptr;         // sorted r1 | r2 | perm | outA | outB
     uint64_t pairs_cap = 0, pairs_cached = 0;
     std::vector<uint32_t> h_r1, h_r2; // the caller's list the device copy was built from
@@ -247,6 +248,7 @@ static int pop_create_impl(const ps_config *cfg, const uint8_t *init_vec, ps_pop
         const int v = atoi(e);
         if (v >= 1 && v <= 8) p->sweep_blocks_per_cu = (uint32_t)v;
     }
+    if (const char *e = getenv("PANSIM_HGT_MODE")) p->hgt_mode = atoi(e);
     if (const char *e = getenv("PANSIM_SWEEP_ROWS")) {
         const int v = atoi(e);
         if (v >= 2 && v <= 4) p->sweep_rows = (uint32_t)v;
@@ -376,6 +378,9 @@ extern "C" int ps_set_tuning(ps_population *p, const char *key, int64_t value)
     } else if (k == "sweep_rows") {
         if (value < 2 || value > 4) return ps_fail(PS_ERR_INVALID, "sweep_rows must be 2..4");
         p->sweep_rows = (uint32_t)value;
+    } else if (k == "hgt_mode") {
+        if (value < 0 || value > 2) return ps_fail(PS_ERR_INVALID, "hgt_mode must be 0 (auto), 1 (global atomics) or 2 (LDS partitions)");
+        p->hgt_mode = (int)value;
     } else if (k == "pair_mode") {
         if (value < 0 || value > 2) return ps_fail(PS_ERR_INVALID, "pair_mode must be 0 (auto), 1 (sampled) or 2 (all pairs)");
         p->pair_mode = (int)value;
@@ -632,7 +637,7 @@ static int launch_core_sweep(ps_population *p, const uint32_t *d_idx, uint32_t g
 // accessory step launches
 // ---------------------------------------------------------------------------
 static int launch_acc_step(ps_population *p, const uint32_t *d_idx, uint32_t gen, bool ga, bool mu,
-                           hipStream_t st)
+                           hipStream_t st, uint32_t *idx_out = nullptr)
 {
     if (p->d.G == 0) return PS_OK;
     acc_step_args a;
@@ -640,6 +645,7 @@ static int launch_acc_step(ps_population *p, const uint32_t *d_idx, uint32_t gen
     a.dstG = p->G[1 - p->cur];
     a.dstI = p->I[1 - p->cur];
     a.idx = d_idx;
+    a.idx_out = idx_out;
     a.d = p->d;
     a.gen = gen;
     a.k0 = (uint32_t)p->cfg.seed;
@@ -679,8 +685,24 @@ static int launch_acc_hgt(ps_population *p, uint32_t gen, hipStream_t st)
     a.gen = gen;
     a.k0 = (uint32_t)p->cfg.seed;
     a.k1 = (uint32_t)(p->cfg.seed >> 32);
-    const uint32_t blocks = (uint32_t)std::min<uint64_t>((total + 255) / 256, 256 * 8);
-    acc_hgt_kernel<<<blocks, 256, 0, st>>>(a);
+    // small population and very many events (>= 1e7, cfg3-like rates): tile the recipients through
+    // LDS (<= 8 partitions), which beats the scattered-global-atomic rate; otherwise one global
+    // atomic per event that changes a bit -- that kernel needs no LDS and co-runs with the sweep
+    const uint64_t row_bytes = (uint64_t)p->d.GW * 8;
+    const uint32_t part_cap = (uint32_t)(p->lds_limit / row_bytes);
+    const uint32_t parts = part_cap ? (p->d.N + part_cap - 1) / part_cap : 0;
+    if (p->hgt_mode != 1 && parts >= 1 && parts <= 8 && (total >= 10000000 || p->hgt_mode == 2)) {
+        const uint32_t rows_per_part = (p->d.N + parts - 1) / parts;
+        const uint32_t lds = (uint32_t)(rows_per_part * row_bytes);
+        const uint32_t n_slices = std::max(1u, 512u / parts);
+        auto kern = acc_hgt_lds_kernel;
+        if (lds > 64 * 1024)
+            HIPCHK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(kern, dim3(parts * n_slices), dim3(1024), lds, st, a, rows_per_part, n_slices);
+    } else {
+        const uint32_t blocks = (uint32_t)std::min<uint64_t>((total + 255) / 256, 256 * 8);
+        acc_hgt_kernel<<<blocks, 256, 0, st>>>(a);
+    }
     // rebuild the gene-major view from the individual-major one (one ballot per gene word)
     acc_i_to_g_kernel<<<dim3(p->d.W, p->d.GW), 64, 0, st>>>(p->I[p->cur], p->G[p->cur], p->d);
     HIPCHK(hipGetLastError());
@@ -697,10 +719,10 @@ static int upload_idx(ps_population *p, const uint32_t *sample)
 }
 
 static int step_device(ps_population *p, const uint32_t *d_idx, uint32_t gen, bool ga, bool mu, bool hr,
-                       hipStream_t st)
+                       hipStream_t st, uint32_t *idx_out = nullptr)
 {
     if (p->cfg.core) return launch_core_sweep(p, d_idx, gen, ga, mu, hr, st);
-    if (ga || mu) PSCHK(launch_acc_step(p, d_idx, gen, ga, mu, st));
+    if (ga || mu) PSCHK(launch_acc_step(p, d_idx, gen, ga, mu, st, idx_out));
     if (hr) PSCHK(launch_acc_hgt(p, gen, st));
     return PS_OK;
 }
@@ -1386,7 +1408,8 @@ struct ps_sim {
     // ring of parent-index slots so that the accessory chain (and the host) can run
     // ahead of the long core sweep
     uint32_t *d_idx[PS_RING] = {};
-    uint32_t *h_idx[PS_RING] = {};         // pinned
+    uint32_t *h_idx[PS_RING] = {};         // pinned, host-mapped
+    uint32_t *m_idx[PS_RING] = {};         // device alias of h_idx
     hipEvent_t ev_idx[PS_RING] = {}, ev_core[PS_RING] = {};
     bool slot_used[PS_RING] = {};
     int32_t *h_num_genes = nullptr, *m_num_genes = nullptr;   // pinned + its device alias
@@ -1473,7 +1496,8 @@ static int sim_create_impl(const ps_sim_params *p, ps_sim *s)
     PSCHK(use_device(s->core));
     for (int k = 0; k < PS_RING; k++) {
         HIPCHK(hipMalloc(&s->d_idx[k], N * sizeof(uint32_t)));
-        HIPCHK(hipHostMalloc(&s->h_idx[k], N * sizeof(uint32_t)));
+        HIPCHK(hipHostMalloc(&s->h_idx[k], N * sizeof(uint32_t), hipHostMallocMapped));
+        HIPCHK(hipHostGetDevicePointer((void **)&s->m_idx[k], s->h_idx[k], 0));
         HIPCHK(hipEventCreateWithFlags(&s->ev_idx[k], hipEventDisableTiming));
         HIPCHK(hipEventCreateWithFlags(&s->ev_core[k], hipEventDisableTiming));
     }
@@ -1511,7 +1535,7 @@ static int sim_one_generation(ps_sim *s, uint32_t gen)
 {
     ps_population *core = s->core, *acc = s->acc;
     const ps_sim_params &p = s->prm;
-    const uint64_t N = p.pop_size;
+    const uint64_t N = p.pop_size, G = acc->cfg.ncols;
     hipStream_t sa = acc->stream, sc = core->stream;
     const int slot = (int)(s->step_count % PS_RING);
     // main.rs:435-440
@@ -1535,10 +1559,13 @@ static int sim_one_generation(ps_sim *s, uint32_t gen)
                             p.no_control_genome_size, p.genome_size_penalty, p.competition_strength, w.data()));
     PSCHK(ps_draw_parents(w.data(), N, p.seed, gen, s->h_idx[slot]));
     memcpy(s->last_idx.data(), s->h_idx[slot], N * sizeof(uint32_t));
-    HIPCHK(hipMemcpyAsync(s->d_idx[slot], s->h_idx[slot], N * sizeof(uint32_t), hipMemcpyHostToDevice, sa));
+    // main.rs:447, :455, :462-464 on the accessory stream.  The gather kernel reads the parents
+    // straight from the host-mapped slot (4*N bytes over PCIe) and publishes the device copy the
+    // core sweep uses: no copy kernel has to fight the sweep for a CU.
+    if (G == 0) HIPCHK(hipMemcpyAsync(s->d_idx[slot], s->h_idx[slot], N * sizeof(uint32_t), hipMemcpyHostToDevice, sa));
+    PSCHK(launch_acc_step(acc, s->m_idx[slot], gen, true, true, sa, s->d_idx[slot]));
     HIPCHK(hipEventRecord(s->ev_idx[slot], sa));
-    // main.rs:447, :455, :462-464 on the accessory stream
-    PSCHK(step_device(acc, s->d_idx[slot], gen, true, true, p.HGT_rate > 0.0, sa));
+    if (p.HGT_rate > 0.0) PSCHK(launch_acc_hgt(acc, gen, sa));
     // main.rs:445, :452, :459-461 on the core stream, one fused pass
     HIPCHK(hipStreamWaitEvent(sc, s->ev_idx[slot], 0));
     hipEvent_t t0 = nullptr, t1 = nullptr;

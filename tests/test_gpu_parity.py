@@ -198,6 +198,14 @@ def test_acc_operators_match_oracle(pa, orc, N, G, comps, lm, lr):
     orc.recombine_acc(want2, seed, gen, cb, ce, lr)
     got2 = pop.read_matrix()
     assert np.array_equal(got2, want2)
+    for mode in (1, 2):               # global-atomic and LDS-partitioned HGT kernels agree
+        alt = pa.Population(N, G, 2, False, 0.25, seed, 10)
+        alt.set_tuning("hgt_mode", mode)
+        alt.set_rates(lm, lr, cb, ce)
+        alt.load_matrix(want)
+        alt.recombine(gen)
+        assert np.array_equal(alt.read_matrix(), want2)
+        alt.close()
     assert (got2 >= want).all()          # HGT never clears a gene
     # gene-major view stayed coherent with the individual-major one
     assert np.array_equal(pop.gene_frequencies()[:G], want2.sum(0) / N)
