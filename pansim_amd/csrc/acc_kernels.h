@@ -161,7 +161,7 @@ __global__ void __launch_bounds__(64) acc_gene_lists_kernel(const uint64_t *accI
     if (lane == 0) cnt[(uint64_t)c * d.N + i] = base;
 }
 
-// HGT events (population.rs:544-751 accessory path), all compartments in one launch:
+// HGT events (population.rs:544-751 accessory path):
 // event e of compartment c picks a uniform donor, a uniform other recipient and a
 // uniform gene among the donor's present genes of the compartment IN THE SNAPSHOT
 // (the gene lists); the recipient gains the gene (value always 1, :632) -- an
@@ -178,60 +178,26 @@ struct acc_hgt_args {
     uint32_t gen, k0, k1;
 };
 
-__global__ void __launch_bounds__(256) acc_hgt_kernel(acc_hgt_args a)
+__global__ void __launch_bounds__(256) acc_hgt_kernel(acc_hgt_args a, uint32_t comp)
 {
+    // One compartment per launch, one event per thread and iteration, one 64-bit atomicOr per
+    // event.  Deliberately light: this kernel runs beside the persistent core sweep, and a
+    // heavier variant (several events in flight, test-before-set loads) measurably delayed the
+    // sweep's workgroups (profiles/r01_sweep_ablation.md).
     const acc_dims d = a.d;
-    uint64_t total = 0;
-    total = a.K[0] + (a.n_comp > 1 ? a.K[1] : 0ull);
-    // four independent events per thread and iteration: the dependent chain of an event
-    // (count -> list entry -> atomic) is pure memory latency, so keep several in flight
-    constexpr int E = 4;
-    const uint64_t K0 = a.K[0];
-    const uint32_t gb0 = a.gb[0], gb1 = a.gb[1];
-    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-    for (uint64_t t0 = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; t0 < total; t0 += stride * E) {
-        uint32_t comp[E], dn[E], rc[E], n[E], rz[E];
-        bool live[E];
-#pragma unroll
-        for (int q = 0; q < E; q++) {
-            const uint64_t t = t0 + (uint64_t)q * stride;
-            live[q] = t < total;
-            // two compartments at most: select instead of indexing the kernel arguments per lane
-            // (a per-lane index would force the argument arrays through scratch memory)
-            uint64_t e = live[q] ? t : 0;
-            const uint32_t c = (a.n_comp > 1 && e >= K0) ? 1u : 0u;
-            e -= c ? K0 : 0ull;
-            comp[q] = c;
-            const ps_u4 r = ps_philox((uint32_t)e, (uint32_t)(e >> 32), a.gen, PS_STREAM_HGT | (c << 8), a.k0, a.k1);
-            dn[q] = ps_mulhi(r.x, d.N);
-            uint32_t x = ps_mulhi(r.y, d.N - 1u);
-            x += (x >= dn[q]) ? 1u : 0u;                    // population.rs:618
-            rc[q] = x;
-            rz[q] = r.z;
-        }
-#pragma unroll
-        for (int q = 0; q < E; q++) n[q] = live[q] ? a.cnt[(uint64_t)comp[q] * d.N + dn[q]] : 0u;
-        uint32_t gene[E];
-#pragma unroll
-        for (int q = 0; q < E; q++) {
-            live[q] = live[q] && n[q] != 0u;                // population.rs:672
-            gene[q] = live[q] ? a.list[(uint64_t)dn[q] * d.G + (comp[q] ? gb1 : gb0) + ps_mulhi(rz[q], n[q])] : 0u;
-        }
-        uint32_t *w32[E];
-        uint32_t cur[E];
-#pragma unroll
-        for (int q = 0; q < E; q++) {
-            // 32-bit half of the recipient's row word that holds the bit
-            w32[q] = (uint32_t *)&a.dstI[(uint64_t)rc[q] * d.GW + (gene[q] >> 6)] + ((gene[q] >> 5) & 1u);
-            cur[q] = live[q] ? __hip_atomic_load(w32[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0xFFFFFFFFu;
-        }
-#pragma unroll
-        for (int q = 0; q < E; q++) {
-            const uint32_t bit = 1u << (gene[q] & 31u);
-            // bits only ever get set here, so a stale read can only cause a redundant OR; most
-            // events target a gene the recipient already carries and skip the atomic
-            if (live[q] && (cur[q] & bit) == 0u) atomicOr(w32[q], bit);
-        }
+    const uint64_t K = a.K[comp];
+    const uint32_t gb = a.gb[comp];
+    const uint32_t stream = PS_STREAM_HGT | (comp << 8);
+    for (uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; e < K;
+         e += (uint64_t)gridDim.x * blockDim.x) {
+        const ps_u4 r = ps_philox((uint32_t)e, (uint32_t)(e >> 32), a.gen, stream, a.k0, a.k1);
+        const uint32_t dn = ps_mulhi(r.x, d.N);
+        uint32_t rc = ps_mulhi(r.y, d.N - 1u);
+        rc += (rc >= dn) ? 1u : 0u;                         // population.rs:618
+        const uint32_t n = a.cnt[(uint64_t)comp * d.N + dn];
+        if (n == 0) continue;                               // population.rs:672
+        const uint32_t gene = a.list[(uint64_t)dn * d.G + gb + ps_mulhi(r.z, n)];
+        atomicOr((unsigned long long *)&a.dstI[(uint64_t)rc * d.GW + (gene >> 6)], 1ull << (gene & 63u));
     }
 }
 

@@ -23,6 +23,8 @@ struct core_sweep_args {
     ps_core_plan plan;
     uint32_t *overflow_flag;   // host-mapped sticky error word
     unsigned long long *stamps; // diagnostic builds (PS_STAMP) only
+    uint32_t *work_ctr;        // wave sweep: 2 x 8 chunk counters, 128 bytes apart
+    uint32_t launch_parity;    // which counter set this launch uses
 };
 
 __device__ __forceinline__ void ps_set_byte(uint32_t (&w)[4], uint32_t k, uint32_t v)
@@ -284,9 +286,30 @@ __global__ void __launch_bounds__(256, PS_ROWS >= 4 ? 6 : 8) core_sweep_wave_ker
         for (uint32_t k = 0; k < 16; k++) pidx[k] = (k < nvalid) ? a.idx[i0 + k] : min(a.N, a.pitch - 1u);
     }
 
-    const uint32_t wpb = blockDim.x >> 6;
-    const uint32_t nwaves = gridDim.x * wpb;
-    for (uint32_t r0 = (blockIdx.x * wpb + wave) * PS_ROWS; r0 < a.rows; r0 += nwaves * PS_ROWS) {
+    // Dynamic row assignment.  The rows are split into 8 contiguous ranges, one per group of
+    // workgroups that share blockIdx.x % 8 (observed to share an XCD: affinity only); inside a
+    // range every wave grabs chunks of PS_CHUNK row batches from the range's atomic counter.
+    // A workgroup that starts late (another kernel held its CU) simply takes fewer chunks, so
+    // the kernel has no static tail.  The next grab is issued before the current chunk is
+    // processed; its latency is hidden behind the chunk's work.
+    constexpr uint32_t PS_CHUNK = 4u;
+    const uint32_t grp = blockIdx.x & 7u;
+    const uint32_t batches = (a.rows + PS_ROWS - 1u) / PS_ROWS;
+    const uint32_t b_lo = (uint32_t)((uint64_t)batches * grp / 8u), b_hi = (uint32_t)((uint64_t)batches * (grp + 1u) / 8u);
+    // two counter sets alternate between launches; this launch zeroes the set of the next one
+    // (the previous launch, which used that set, has completed: same stream)
+    uint32_t *ctr = a.work_ctr + (a.launch_parity * 8u + grp) * 32u;     // counters 128 bytes apart
+    if (blockIdx.x < 8u && threadIdx.x == 0) a.work_ctr[((a.launch_parity ^ 1u) * 8u + blockIdx.x) * 32u] = 0u;
+    uint32_t next_chunk = 0;
+    if (lane == 0) next_chunk = __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (;;) {
+        const uint32_t chunk = __builtin_amdgcn_readfirstlane(next_chunk);
+        if (b_lo + chunk * PS_CHUNK >= b_hi) break;
+        if (lane == 0) next_chunk = __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (uint32_t cb = 0; cb < PS_CHUNK; cb++) {
+        const uint32_t batch = b_lo + chunk * PS_CHUNK + cb;
+        if (batch >= b_hi) break;
+        const uint32_t r0 = batch * PS_ROWS;
         const uint32_t nr = min(PS_ROWS, a.rows - r0);
         uint4 v[PS_ROWS];
 #pragma unroll
@@ -450,6 +473,7 @@ __global__ void __launch_bounds__(256, PS_ROWS >= 4 ? 6 : 8) core_sweep_wave_ker
         }
         ps_wave_sync();   // the next iteration overwrites the LDS rows and the queue
         PS_T(6);   // LDS read-back + global store
+    }
     }
 #ifdef PS_STAMP
     if (lane == 0)

@@ -186,6 +186,8 @@ struct ps_population {
     // scratch
     uint32_t *d_idx = nullptr;       // N parents
     uint32_t *d_idxT = nullptr;      // transposed parents for the block sweep (16 x cpr)
+    uint32_t *d_work = nullptr;      // wave sweep: chunk counters (2 sets x 8 x 128 bytes)
+    uint64_t sweep_launches = 0;     // parity selects the counter set
     double *d_log1p = nullptr;       // G
     int32_t *d_num_genes = nullptr;  // N
     double *d_logw = nullptr;        // N
@@ -217,7 +219,7 @@ extern "C" void ps_population_destroy(ps_population *p)
     if (!p) return;
     (void)hipSetDevice(p->device);
     if (p->stream) (void)hipStreamSynchronize(p->stream);
-    void *ptrs[] = { p->state, p->G[0], p->G[1], p->I[0], p->I[1], p->glist, p->cnt, p->d_idx, p->d_idxT,
+    void *ptrs[] = { p->state, p->G[0], p->G[1], p->I[0], p->I[1], p->glist, p->cnt, p->d_idx, p->d_idxT, p->d_work,
                      p->d_log1p, p->d_num_genes, p->d_logw, p->d_pairs, p->d_H, p->d_Dt };
     for (void *q : ptrs)
         if (q) (void)hipFree(q);
@@ -243,7 +245,17 @@ static int pop_create_impl(const ps_config *cfg, const uint8_t *init_vec, ps_pop
         HIPCHK(hipGetDevice(&p->device));
     }
     PSCHK(use_device(p));
+#ifdef PS_EXP_COREPRIO
+    {
+        int lo = 0, hi = 0;
+        if (cfg->core && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && hi != lo)
+            HIPCHK(hipStreamCreateWithPriority(&p->stream, hipStreamNonBlocking, hi));
+        else
+            HIPCHK(hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking));
+    }
+#else
     HIPCHK(hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking));
+#endif
     if (const char *e = getenv("PANSIM_SWEEP_BLOCKS_PER_CU")) {
         const int v = atoi(e);
         if (v >= 1 && v <= 8) p->sweep_blocks_per_cu = (uint32_t)v;
@@ -269,6 +281,8 @@ static int pop_create_impl(const ps_config *cfg, const uint8_t *init_vec, ps_pop
         p->cpr = p->pitch / 16;
         HIPCHK(hipMalloc(&p->state, std::max<uint64_t>(C, 1) * p->pitch));
         HIPCHK(hipMalloc(&p->d_idxT, 16ull * p->cpr * sizeof(uint32_t)));
+        HIPCHK(hipMalloc(&p->d_work, 2 * 8 * 128));
+        HIPCHK(hipMemsetAsync(p->d_work, 0, 2 * 8 * 128, p->stream));
         if (C) {
             const uint64_t total = C * p->cpr;
             const uint32_t blocks = (uint32_t)std::min<uint64_t>((total + 255) / 256, 65536);
@@ -501,7 +515,7 @@ static int launch_core_sweep_wave_r(ps_population *p, const core_sweep_args &a, 
     const uint32_t want = (a.rows + wpb * ROWS - 1) / (wpb * ROWS);
     const uint32_t fit = std::max(1u, std::min(8u, p->lds_limit / lds));
     const uint32_t bpc = std::min(p->sweep_blocks_per_cu, fit);
-    const uint32_t grid = std::max(1u, std::min(want, 256u * bpc));
+    const uint32_t grid = std::max(8u, std::min((want + 7u) & ~7u, 256u * bpc));   // a multiple of the 8 groups
     hipLaunchKernelGGL((core_sweep_wave_kernel<ROWS, GA, MU, HR>), dim3(grid), dim3(block), lds, st, a);
     HIPCHK(hipGetLastError());
     return PS_OK;
@@ -615,6 +629,8 @@ static int launch_core_sweep(ps_population *p, const uint32_t *d_idx, uint32_t g
     const bool wave = wave_sweep_eligible(p, mu, hr);
     a.overflow_flag = p->d_flag;
     a.stamps = p->d_stamps;
+    a.work_ctr = p->d_work;
+    a.launch_parity = (uint32_t)(p->sweep_launches++ & 1u);
     a.idxT = p->d_idxT;
     if (!wave && ga) {
         const uint32_t n = 16u * p->cpr;
@@ -700,8 +716,11 @@ static int launch_acc_hgt(ps_population *p, uint32_t gen, hipStream_t st)
             HIPCHK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(kern, dim3(parts * n_slices), dim3(1024), lds, st, a, rows_per_part, n_slices);
     } else {
-        const uint32_t blocks = (uint32_t)std::min<uint64_t>((total + 255) / 256, 256 * 8);
-        acc_hgt_kernel<<<blocks, 256, 0, st>>>(a);
+        for (int c = 0; c < p->aplan.n_comp; c++) {
+            if (a.K[c] == 0) continue;
+            const uint32_t blocks = (uint32_t)std::min<uint64_t>((a.K[c] + 255) / 256, 256 * 16);
+            acc_hgt_kernel<<<blocks, 256, 0, st>>>(a, (uint32_t)c);
+        }
     }
     // rebuild the gene-major view from the individual-major one (one ballot per gene word)
     acc_i_to_g_kernel<<<dim3(p->d.W, p->d.GW), 64, 0, st>>>(p->I[p->cur], p->G[p->cur], p->d);
@@ -1489,6 +1508,11 @@ static int sim_create_impl(const ps_sim_params *p, ps_sim *s)
         for (int c = 0; c < d.n_comp; c++) lrec[c] = (p->HGT_rate > 0.0) ? d.n_recombinations_pan[c] : 0.0; // :462
         PSCHK(ps_set_rates(s->acc, d.n_comp, d.n_pan_mutations, lrec, d.comp_begin, d.comp_end));
     }
+    // Inside the generation loop the sweep shares the GPU with the accessory chain of the next
+    // generation: 6 resident workgroups per CU leave that chain 8 wave slots and 40 KB of LDS on
+    // every CU (the sweep's rows are assigned dynamically, so lower residency costs no tail).
+    // Measured at cfg2: 8 -> 1320-1370, 7 -> 1490, 6 -> 1620-1690, 5 -> 1620-1635 generations/s.
+    if (!getenv("PANSIM_SWEEP_BLOCKS_PER_CU")) s->core->sweep_blocks_per_cu = 6;
     s->r1.resize(p->max_distances);
     s->r2.resize(p->max_distances);
     PSCHK(ps_sample_pairs(p->seed, N, p->max_distances, s->r1.data(), s->r2.data())); // main.rs:413-427
@@ -1562,10 +1586,16 @@ static int sim_one_generation(ps_sim *s, uint32_t gen)
     // main.rs:447, :455, :462-464 on the accessory stream.  The gather kernel reads the parents
     // straight from the host-mapped slot (4*N bytes over PCIe) and publishes the device copy the
     // core sweep uses: no copy kernel has to fight the sweep for a CU.
+#ifdef PS_EXP_COPY
+    HIPCHK(hipMemcpyAsync(s->d_idx[slot], s->h_idx[slot], N * sizeof(uint32_t), hipMemcpyHostToDevice, sa));
+    HIPCHK(hipEventRecord(s->ev_idx[slot], sa));
+    PSCHK(launch_acc_step(acc, s->d_idx[slot], gen, true, true, sa, nullptr));
+#else
     if (G == 0) HIPCHK(hipMemcpyAsync(s->d_idx[slot], s->h_idx[slot], N * sizeof(uint32_t), hipMemcpyHostToDevice, sa));
     PSCHK(launch_acc_step(acc, s->m_idx[slot], gen, true, true, sa, s->d_idx[slot]));
     HIPCHK(hipEventRecord(s->ev_idx[slot], sa));
-    if (p.HGT_rate > 0.0) PSCHK(launch_acc_hgt(acc, gen, sa));
+#endif
+
     // main.rs:445, :452, :459-461 on the core stream, one fused pass
     HIPCHK(hipStreamWaitEvent(sc, s->ev_idx[slot], 0));
     hipEvent_t t0 = nullptr, t1 = nullptr;
@@ -1585,6 +1615,8 @@ static int sim_one_generation(ps_sim *s, uint32_t gen)
         s->tev.emplace_back(t0, t1);
     }
     HIPCHK(hipEventRecord(s->ev_core[slot], sc));
+    // HGT is enqueued after the sweep so that the sweep's launch is not queued behind it
+    if (p.HGT_rate > 0.0) PSCHK(launch_acc_hgt(acc, gen, sa));
     s->slot_used[slot] = true;
     s->step_count++;
     return PS_OK;
