@@ -274,6 +274,19 @@ __global__ void acc_fitness_kernel(const uint64_t *accI, const double *log1p_s, 
     logw[i] = neg_inf ? 0.0 : sum;
 }
 
+// neutral selection (every ln(1+s_g) is 0): only the gene counts are needed (population.rs:282-291,
+// log_sum = 0.0 for every row); one wave per individual, lanes over the row words
+__global__ void __launch_bounds__(256) acc_gene_count_rows_kernel(const uint64_t *accI, int32_t *num_genes,
+                                                                  double *logw, acc_dims d)
+{
+    const uint32_t i = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
+    if (i >= d.N) return;
+    uint32_t n = 0;
+    for (uint32_t gw = lane; gw < d.GW; gw += 64u) n += __popcll(accI[(uint64_t)i * d.GW + gw]);
+    for (int off = 32; off > 0; off >>= 1) n += __shfl_down(n, off, 64);
+    if (lane == 0) { num_genes[i] = (int32_t)n; logw[i] = 0.0; }
+}
+
 // population.rs:840-863 numerators: number of individuals carrying gene g
 __global__ void acc_gene_counts_kernel(const uint64_t *accG, uint32_t *counts, acc_dims d)
 {

@@ -1570,9 +1570,12 @@ static int sim_one_generation(ps_sim *s, uint32_t gen)
     }
     // main.rs:442-443: device half of sample_indices ...
     // the kernel writes its 12*N bytes straight into host-mapped pinned memory (no copy kernels)
-    acc_fitness_kernel<<<(uint32_t)((N + 255) / 256), 256, 0, sa>>>(acc->I[acc->cur], acc->d_log1p,
-                                                                 s->need_logw ? 1 : 0, s->m_num_genes,
-                                                                 s->m_logw, acc->d);
+    if (s->need_logw)
+        acc_fitness_kernel<<<(uint32_t)((N + 255) / 256), 256, 0, sa>>>(acc->I[acc->cur], acc->d_log1p, 1,
+                                                                     s->m_num_genes, s->m_logw, acc->d);
+    else
+        acc_gene_count_rows_kernel<<<(uint32_t)((N + 3) / 4), 256, 0, sa>>>(acc->I[acc->cur], s->m_num_genes,
+                                                                         s->m_logw, acc->d);
     HIPCHK(hipGetLastError());
     // the slot's previous core sweep must have consumed its indices
     if (s->slot_used[slot]) HIPCHK(hipEventSynchronize(s->ev_core[slot]));
