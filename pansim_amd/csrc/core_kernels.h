@@ -58,128 +58,86 @@ __device__ __forceinline__ uint32_t ps_l1_byte(const ps_u4 &l1, uint32_t k)
     return (w >> ((k & 3u) * 8u)) & 0xFFu;
 }
 
-// One pass over the matrix: optional gather, mutation and HR, fused.
-// WAVE_ROW: a row fits one wavefront (pitch <= 1024): each of the block's waves
-// owns its own row and keeps its 16 parent indices in registers.  Otherwise the
-// whole block cooperates on one row and lanes loop over its chunks.
-template <bool WAVE_ROW, bool DO_GATHER, bool DO_MUT, bool DO_HR>
-__global__ void __launch_bounds__(1024) core_sweep_kernel(core_sweep_args a)
+// Inline block sweep: the queue-free fallback of the block sweep below.  One 1024-thread
+// workgroup per row; every candidate is handled by its owner lane (lanes diverge), HR cells are
+// remembered in a 16-bit mask per chunk.  Correct for any rates (nothing can overflow); used when
+// the queues of core_sweep_block_kernel cannot be sized safely.
+template <bool DO_GATHER, bool DO_MUT, bool DO_HR>
+__global__ void __launch_bounds__(1024) core_sweep_inline_kernel(core_sweep_args a)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
-    const uint32_t tid = threadIdx.x;
-    const uint32_t lpr = WAVE_ROW ? 64u : blockDim.x;
-    const uint32_t rpb = WAVE_ROW ? (blockDim.x >> 6) : 1u;
-    const uint32_t slot = WAVE_ROW ? (tid >> 6) : 0u;
-    const uint32_t lane = WAVE_ROW ? (tid & 63u) : tid;
-    const uint32_t hrm_bytes = (a.cpr * 2u + 15u) & ~15u;
-    const uint32_t slot_bytes = 2u * a.pitch + hrm_bytes;
-    uint8_t *rowA = lds + slot * slot_bytes;
+    const uint32_t lane = threadIdx.x, lpr = blockDim.x;
+    uint8_t *rowA = lds;
     uint8_t *rowS = rowA + a.pitch;
     uint16_t *hrm = (uint16_t *)(rowS + a.pitch);
     const ps_core_plan pl = a.plan;
     const bool events = pl.has_events && (DO_MUT || DO_HR);
 
-    uint32_t pidx[16];
-    if (WAVE_ROW && DO_GATHER) {
-#pragma unroll
-        for (int k = 0; k < 16; k++) {
-            const uint32_t i = lane * 16u + k;
-            pidx[k] = (i < a.N) ? a.idx[i] : 0u;
-        }
-    }
-
-    for (uint32_t r0 = blockIdx.x * rpb; r0 < a.rows; r0 += gridDim.x * rpb) {
-        const uint32_t row = r0 + slot;
-        const bool active = row < a.rows;
+    for (uint32_t row = blockIdx.x; row < a.rows; row += gridDim.x) {
         const uint32_t site = a.site_offset + row;
         uint8_t *grow = a.state + (size_t)row * a.pitch;
-
         if (DO_GATHER) {
-            if (active)
-                for (uint32_t c = lane; c < a.cpr; c += lpr)
-                    *(uint4 *)(rowA + 16u * c) = *(const uint4 *)(grow + 16u * c);
+            for (uint32_t c = lane; c < a.cpr; c += lpr)
+                *(uint4 *)(rowA + 16u * c) = *(const uint4 *)(grow + 16u * c);
             __syncthreads();
         }
-
-        uint32_t d_keep[4] = { 0, 0, 0, 0 };
-        uint32_t hm_keep = 0;
-        if (active) {
-            for (uint32_t c = lane; c < a.cpr; c += lpr) {
-                uint32_t d[4];
-                if (DO_GATHER) {
+        for (uint32_t c = lane; c < a.cpr; c += lpr) {
+            uint32_t d[4];
+            if (DO_GATHER) {
 #pragma unroll
-                    for (int j = 0; j < 4; j++) {
-                        uint32_t w = 0;
+                for (int j = 0; j < 4; j++) {
+                    uint32_t w = 0;
 #pragma unroll
-                        for (int b = 0; b < 4; b++) {
-                            const uint32_t i = c * 16u + 4 * j + b;
-                            uint32_t p;
-                            if (WAVE_ROW) p = pidx[4 * j + b];
-                            else p = (i < a.N) ? a.idx[i] : 0u;
-                            const uint32_t v = (i < a.N) ? (uint32_t)rowA[p] : 0u;
-                            w |= v << (8 * b);
-                        }
-                        d[j] = w;
+                    for (int b = 0; b < 4; b++) {
+                        const uint32_t i = c * 16u + 4 * j + b;
+                        const uint32_t v = (i < a.N) ? (uint32_t)rowA[a.idx[i]] : 0u;
+                        w |= v << (8 * b);
                     }
-                } else {
-                    const uint4 v = *(const uint4 *)(grow + 16u * c);
-                    d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+                    d[j] = w;
                 }
-                uint32_t hm = 0;
-                if (events) {
-                    const ps_u4 l1 = ps_philox(site, c, a.gen, PS_STREAM_CORE_L1, a.k0, a.k1);
-                    uint32_t cm = ps_candidate_mask(l1, pl.bC);
-                    while (cm) {
-                        const uint32_t k = __builtin_ctz(cm);
-                        cm &= cm - 1u;
-                        const uint32_t i = c * 16u + k;
-                        if (i >= a.N) continue;
-                        const ps_u4 l2 = ps_philox(site, i, a.gen, PS_STREAM_CORE_L2, a.k0, a.k1);
-                        const uint32_t u = (ps_l1_byte(l1, k) << 24) | (l2.x >> 8);
-                        const ps_cell cell = ps_classify(u, pl);
-                        if (DO_MUT && cell.mut) ps_set_byte(d, k, cell.mut);
-                        if (DO_HR && cell.hr) hm |= 1u << k;
-                    }
-                }
-                if (DO_HR) {
-                    *(uint4 *)(rowS + 16u * c) = make_uint4(d[0], d[1], d[2], d[3]);
-                    if (WAVE_ROW) {
-                        d_keep[0] = d[0]; d_keep[1] = d[1]; d_keep[2] = d[2]; d_keep[3] = d[3];
-                        hm_keep = hm;
-                    } else {
-                        hrm[c] = (uint16_t)hm;
-                    }
-                } else {
-                    *(uint4 *)(grow + 16u * c) = make_uint4(d[0], d[1], d[2], d[3]);
+            } else {
+                const uint4 v = *(const uint4 *)(grow + 16u * c);
+                d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+            }
+            uint32_t hm = 0;
+            if (events) {
+                const ps_u4 l1 = ps_philox(site, c, a.gen, PS_STREAM_CORE_L1, a.k0, a.k1);
+                uint32_t cm = ps_candidate_mask(l1, pl.bC);
+                while (cm) {
+                    const uint32_t k = __builtin_ctz(cm);
+                    cm &= cm - 1u;
+                    const uint32_t i = c * 16u + k;
+                    if (i >= a.N) continue;
+                    const ps_u4 l2 = ps_philox(site, i, a.gen, PS_STREAM_CORE_L2, a.k0, a.k1);
+                    const uint32_t u = (ps_l1_byte(l1, k) << 24) | (l2.x >> 8);
+                    const ps_cell cell = ps_classify(u, pl);
+                    if (DO_MUT && cell.mut) ps_set_byte(d, k, cell.mut);
+                    if (DO_HR && cell.hr) hm |= 1u << k;
                 }
             }
+            if (DO_HR) {
+                *(uint4 *)(rowS + 16u * c) = make_uint4(d[0], d[1], d[2], d[3]);
+                hrm[c] = (uint16_t)hm;
+            } else {
+                *(uint4 *)(grow + 16u * c) = make_uint4(d[0], d[1], d[2], d[3]);
+            }
         }
-
         if (DO_HR) {
             __syncthreads();   // rowS now holds the post-mutation snapshot of the row
-            if (active) {
-                for (uint32_t c = lane; c < a.cpr; c += lpr) {
-                    uint32_t d[4];
-                    uint32_t hm;
-                    if (WAVE_ROW) {
-                        d[0] = d_keep[0]; d[1] = d_keep[1]; d[2] = d_keep[2]; d[3] = d_keep[3];
-                        hm = hm_keep;
-                    } else {
-                        const uint4 v = *(const uint4 *)(rowS + 16u * c);
-                        d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
-                        hm = hrm[c];
-                    }
-                    while (hm) {
-                        const uint32_t k = __builtin_ctz(hm);
-                        hm &= hm - 1u;
-                        const uint32_t i = c * 16u + k;
-                        const ps_u4 l2 = ps_philox(site, i, a.gen, PS_STREAM_CORE_L2, a.k0, a.k1);
-                        uint32_t donor = ps_mulhi(l2.y, a.N - 1u);
-                        donor += (donor >= i) ? 1u : 0u;          // population.rs:618
-                        ps_set_byte(d, k, (uint32_t)rowS[donor]); // snapshot read, :693-695
-                    }
-                    *(uint4 *)(grow + 16u * c) = make_uint4(d[0], d[1], d[2], d[3]);
+            for (uint32_t c = lane; c < a.cpr; c += lpr) {
+                const uint4 v = *(const uint4 *)(rowS + 16u * c);
+                uint32_t d[4] = { v.x, v.y, v.z, v.w };
+                uint32_t hm = hrm[c];
+                while (hm) {
+                    const uint32_t k = __builtin_ctz(hm);
+                    hm &= hm - 1u;
+                    const uint32_t i = c * 16u + k;
+                    const ps_u4 l2 = ps_philox(site, i, a.gen, PS_STREAM_CORE_L2, a.k0, a.k1);
+                    uint32_t donor = ps_mulhi(l2.y, a.N - 1u);
+                    donor += (donor >= i) ? 1u : 0u;          // population.rs:618
+                    ps_set_byte(d, k, (uint32_t)rowS[donor]); // snapshot read, :693-695
                 }
+                *(uint4 *)(grow + 16u * c) = make_uint4(d[0], d[1], d[2], d[3]);
             }
             if (!DO_GATHER) __syncthreads();   // rowS is rewritten by the next row
         }
@@ -354,7 +312,6 @@ __global__ void __launch_bounds__(256, PS_ROWS >= 4 ? 6 : 8) core_sweep_wave_ker
                 // the LDS row becomes the child row; every gather read precedes this store
                 if (DO_GATHER) ps_wave_sync();
                 if (has_chunk && (DO_GATHER || events)) *(uint4 *)(row + i0) = d;
-#if !defined(PS_ABLATE) || PS_ABLATE > 1
                 if (events) {
                     // compact every candidate cell of the row into the wave queue
                     for (;;) {
@@ -375,16 +332,10 @@ __global__ void __launch_bounds__(256, PS_ROWS >= 4 ? 6 : 8) core_sweep_wave_ker
                     }
                 }
                 PS_T(3);   // queue push
-#else
-                if (cm == 0xFFFFFFFFu) qn = 1;   // keep the detection alive
-#endif
             }
         }
         ps_wave_sync();
 
-#if defined(PS_ABLATE) && PS_ABLATE < 3
-        if (qn == 12345u) q[lane] = qn;
-#else
         if (events) {
             if (qn > PS_QCAP) {
                 if (lane == 0) atomicOr(a.overflow_flag, 1u);
@@ -459,7 +410,6 @@ __global__ void __launch_bounds__(256, PS_ROWS >= 4 ? 6 : 8) core_sweep_wave_ker
             }
             ps_wave_sync();
         }
-#endif
         PS_T(5);   // exact pass + HR
 
         if (has_chunk) {
@@ -757,9 +707,6 @@ __global__ void __launch_bounds__(1024) core_pair_counts_tiled(
         // loads (a wave reads 256 contiguous bytes of a site row), repacked into one
         // 16-byte nibble string per individual
         const uint32_t quads = (N + 3u) >> 2, sgs = W >> 2;
-#if defined(PS_PAIR_ABLATE) && PS_PAIR_ABLATE == 1
-        if (t == 0)
-#endif
         for (uint32_t it = tid; it < quads * sgs; it += blockDim.x) {
             const uint32_t qd = it % quads, sg = it / quads;
             const uint32_t sb = s0 + 32u * sg;
@@ -782,9 +729,6 @@ __global__ void __launch_bounds__(1024) core_pair_counts_tiled(
             }
         }
         __syncthreads();
-#if defined(PS_PAIR_ABLATE) && PS_PAIR_ABLATE == 2
-        if (t == 0)
-#endif
 #pragma unroll
         for (int q = 0; q < A; q++) {
             uint32_t s = 0;

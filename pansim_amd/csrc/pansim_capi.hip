@@ -245,17 +245,7 @@ static int pop_create_impl(const ps_config *cfg, const uint8_t *init_vec, ps_pop
         HIPCHK(hipGetDevice(&p->device));
     }
     PSCHK(use_device(p));
-#ifdef PS_EXP_COREPRIO
-    {
-        int lo = 0, hi = 0;
-        if (cfg->core && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && hi != lo)
-            HIPCHK(hipStreamCreateWithPriority(&p->stream, hipStreamNonBlocking, hi));
-        else
-            HIPCHK(hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking));
-    }
-#else
     HIPCHK(hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking));
-#endif
     if (const char *e = getenv("PANSIM_SWEEP_BLOCKS_PER_CU")) {
         const int v = atoi(e);
         if (v >= 1 && v <= 8) p->sweep_blocks_per_cu = (uint32_t)v;
@@ -599,7 +589,7 @@ static int launch_core_sweep_block(ps_population *p, const core_sweep_args &a, h
     if (lds > p->lds_limit)
         return ps_fail(PS_ERR_INVALID, "pop_size %u needs %u bytes of LDS per row (limit %u)", a.N, lds,
                        p->lds_limit);
-    auto kern = core_sweep_kernel<false, GA, MU, HR>;
+    auto kern = core_sweep_inline_kernel<GA, MU, HR>;
     if (lds > 64 * 1024)
         HIPCHK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const uint32_t cap = 256u * (lds > 80 * 1024 ? 1u : 2u);
@@ -1589,15 +1579,9 @@ static int sim_one_generation(ps_sim *s, uint32_t gen)
     // main.rs:447, :455, :462-464 on the accessory stream.  The gather kernel reads the parents
     // straight from the host-mapped slot (4*N bytes over PCIe) and publishes the device copy the
     // core sweep uses: no copy kernel has to fight the sweep for a CU.
-#ifdef PS_EXP_COPY
-    HIPCHK(hipMemcpyAsync(s->d_idx[slot], s->h_idx[slot], N * sizeof(uint32_t), hipMemcpyHostToDevice, sa));
-    HIPCHK(hipEventRecord(s->ev_idx[slot], sa));
-    PSCHK(launch_acc_step(acc, s->d_idx[slot], gen, true, true, sa, nullptr));
-#else
     if (G == 0) HIPCHK(hipMemcpyAsync(s->d_idx[slot], s->h_idx[slot], N * sizeof(uint32_t), hipMemcpyHostToDevice, sa));
     PSCHK(launch_acc_step(acc, s->m_idx[slot], gen, true, true, sa, s->d_idx[slot]));
     HIPCHK(hipEventRecord(s->ev_idx[slot], sa));
-#endif
 
     // main.rs:445, :452, :459-461 on the core stream, one fused pass
     HIPCHK(hipStreamWaitEvent(sc, s->ev_idx[slot], 0));
