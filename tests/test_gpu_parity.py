@@ -521,3 +521,77 @@ def test_config3_rates_full_width_rows(pa, orc):
     assert np.array_equal(sim.core_genome.read_matrix(), ref.core)
     assert np.array_equal(sim.pan_genome.read_matrix(), ref.acc)
     sim.close()
+
+
+# ----------------------------------------------------------------------------- randomized differential
+@pytest.mark.parametrize("trial", range(30))
+def test_random_operator_sequences(pa, orc, trial):
+    """Random sizes, rates and call sequences: after every call the HBM state must equal the oracle's."""
+    rng = np.random.default_rng(1000 + trial)
+    N = int(rng.choice([2, 3, 17, 64, 100, 129, 640, 1000, 1024, 1025, 1500, 2100]))
+    L = int(rng.integers(1, 400))
+    LG = L + int(rng.integers(0, 1000))
+    off = int(rng.integers(0, LG - L + 1))
+    G = int(rng.integers(1, 300))
+    seed = int(rng.integers(0, 2**63))
+    lm = float(rng.choice([0.0, 0.3, 5.0, 0.05 * LG, 0.3 * LG]))
+    lh = float(rng.choice([0.0, 0.2, 0.05 * LG, 0.2 * LG]))
+    g1 = int(rng.integers(0, G + 1))
+    comps = [(0, g1), (g1, G)] if 0 < g1 < G else [(0, G)]
+    cb, ce = [c[0] for c in comps], [c[1] for c in comps]
+    am = [float(rng.choice([0.0, 0.5, 1.0, 1000.0])) * (e - b) for b, e in comps]
+    ar = [float(rng.choice([0.0, 1.0, 30.0, 400.0])) for _ in comps]
+    core = pa.Population(N, L, 4, True, 0.0, seed, 0, col_offset=off, global_cols=LG)
+    acc = pa.Population(N, G, 2, False, 0.3, seed, 7)
+    core.set_rates([lm], [lh])
+    acc.set_rates(am, ar, cb, ce)
+    if rng.random() < 0.5:
+        core.set_tuning("sweep_rows", int(rng.integers(2, 5)))
+        core.set_tuning("sweep_blocks_per_cu", int(rng.integers(1, 9)))
+    if rng.random() < 0.3:
+        core.set_tuning("force_block_sweep", 1)
+    if rng.random() < 0.3:
+        acc.set_tuning("hgt_mode", int(rng.integers(0, 3)))
+    plan = orc.core_plan(lm, lh, LG)
+    mc = _rand_core(rng, N, L)
+    ma = _rand_acc(rng, N, G, 0.3)
+    core.load_matrix(mc)
+    acc.load_matrix(ma)
+    for step in range(8):
+        op = rng.choice(["gather", "mutate", "recombine", "step", "step_norec"])
+        gen = int(rng.integers(0, 2**31))
+        sample = rng.integers(0, N, N).astype(np.uint32)
+        if op == "gather":
+            core.next_generation(sample)
+            acc.next_generation(sample)
+            mc, ma = orc.next_generation(mc, sample), orc.next_generation(ma, sample)
+        elif op == "mutate":
+            core.mutate_alleles(gen)
+            acc.mutate_alleles(gen)
+            orc.mutate_core(mc, off, seed, gen, plan)
+            orc.mutate_acc(ma, seed, gen, cb, ce, am)
+        elif op == "recombine":
+            core.recombine(gen)
+            acc.recombine(gen)
+            orc.recombine_core(mc, off, seed, gen, plan)
+            orc.recombine_acc(ma, seed, gen, cb, ce, ar)
+        else:
+            rec = op == "step"
+            core.step(gen, sample, rec)
+            acc.step(gen, sample, rec)
+            mc, ma = orc.next_generation(mc, sample), orc.next_generation(ma, sample)
+            orc.mutate_core(mc, off, seed, gen, plan)
+            orc.mutate_acc(ma, seed, gen, cb, ce, am)
+            if rec:
+                orc.recombine_core(mc, off, seed, gen, plan)
+                orc.recombine_acc(ma, seed, gen, cb, ce, ar)
+        assert np.array_equal(core.read_matrix(), mc), (trial, step, op, N, L, lm, lh)
+        assert np.array_equal(acc.read_matrix(), ma), (trial, step, op, N, G, am, ar)
+    P = 300
+    if N >= 2:
+        r1, r2 = orc.sample_pairs(seed % 1000, N, P)
+        assert np.array_equal(core.pairwise_counts(r1, r2)[0], orc.pairwise_hamming_counts(mc, 0, L, r1, r2))
+        assert np.array_equal(acc.pairwise_distances(P, r1, r2), orc.pairwise_distances(ma, False, 7, r1, r2))
+    assert np.array_equal(acc.gene_frequencies(), orc.gene_frequencies(ma, 7))
+    core.close()
+    acc.close()
