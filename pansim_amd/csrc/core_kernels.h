@@ -669,6 +669,44 @@ __global__ void __launch_bounds__(256) core_transpose_kernel(uint8_t *state, uin
     }
 }
 
+// Population::write for the core matrix (population.rs:865-880) on the device: the text of
+// individuals [i0, i0+ni) -- letters A/C/G/T/N (population.rs:154-162) joined by ',' and ended by
+// '\n', 2*L bytes per individual -- produced from the site-major state through a 64x64 LDS tile so
+// that both the state reads and the text writes are coalesced.
+__global__ void __launch_bounds__(256) core_csv_kernel(const uint8_t *state, uint8_t *text, uint32_t pitch,
+                                                       uint64_t L, uint32_t i0, uint32_t ni)
+{
+    __shared__ uint8_t tile[64][65];
+    const uint32_t tx = threadIdx.x & 63u, ty = threadIdx.x >> 6;
+    const uint64_t s0 = (uint64_t)blockIdx.x * 64u;
+    const uint32_t ib = blockIdx.y * 64u;
+    for (uint32_t r = ty; r < 64; r += 4) {
+        const uint64_t s = s0 + r;
+        const uint32_t i = ib + tx;
+        tile[r][tx] = (s < L && i < ni) ? state[s * pitch + i0 + i] : 0;
+    }
+    __syncthreads();
+    // 128 text bytes per individual and tile: thread tx writes bytes 2*tx' .. for two halves
+    for (uint32_t r = ty; r < 64; r += 4) {
+        const uint32_t i = ib + r;
+        if (i >= ni) continue;
+        uint8_t *row = text + (uint64_t)i * 2u * L + 2u * s0;
+#pragma unroll
+        for (uint32_t h = 0; h < 2; h++) {
+            const uint32_t c = h * 64u + tx;          // character index inside the tile's 128 bytes
+            const uint64_t s = s0 + (c >> 1);
+            if (s >= L) continue;
+            uint8_t ch;
+            if (c & 1u) ch = (s == L - 1) ? '\n' : ',';
+            else {
+                const uint8_t v = tile[c >> 1][r];
+                ch = (v == 1) ? 'A' : (v == 2) ? 'C' : (v == 4) ? 'G' : (v == 8) ? 'T' : 'N';
+            }
+            row[c] = ch;
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------
 // sampled-pair Hamming numerators: out[k] += sum_s popcount(x[s][i_k] ^ x[s][j_k])
 // (distances.rs:22-52 over the columns held by this handle).

@@ -1243,11 +1243,48 @@ extern "C" int ps_write(ps_population *p, const char *outpref)
 {
     if (!p || !outpref) return ps_fail(PS_ERR_INVALID, "null argument");
     const uint64_t N = p->cfg.pop_size, C = p->cfg.ncols;
-    std::vector<uint8_t> rows(std::max<uint64_t>(N * C, 1));
-    PSCHK(ps_read_matrix(p, rows.data()));
     const std::string path = std::string(outpref) + (p->cfg.core ? "_core_genome.csv" : "_pangenome.csv");
     FILE *f = fopen(path.c_str(), "w");
     if (!f) return ps_fail(PS_ERR_IO, "cannot create %s", path.c_str());
+    if (p->cfg.core && C > 0) {
+        // the text is expanded on the device, individuals in chunks of <= 256 MiB, two pinned
+        // buffers so that the D2H copy of one chunk overlaps the fwrite of the previous one
+        PSCHK(use_device(p));
+        const uint64_t row_bytes = 2 * C;
+        const uint32_t chunk = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(N, (256ull << 20) / row_bytes));
+        uint8_t *d_text = nullptr, *h_text[2] = { nullptr, nullptr };
+        int rc = PS_OK;
+        if (hipMalloc(&d_text, (uint64_t)chunk * row_bytes) != hipSuccess
+            || hipHostMalloc(&h_text[0], (uint64_t)chunk * row_bytes) != hipSuccess
+            || hipHostMalloc(&h_text[1], (uint64_t)chunk * row_bytes) != hipSuccess)
+            rc = ps_fail(PS_ERR_OOM, "cannot allocate the text buffers of ps_write");
+        uint64_t pending = 0;
+        int pending_buf = -1, k = 0;
+        for (uint64_t i0 = 0; rc == PS_OK && i0 < N; i0 += chunk, k ^= 1) {
+            const uint32_t ni = (uint32_t)std::min<uint64_t>(chunk, N - i0);
+            dim3 grid((uint32_t)((C + 63) / 64), (ni + 63) / 64);
+            core_csv_kernel<<<grid, 256, 0, p->stream>>>(p->state, d_text, p->pitch, C, (uint32_t)i0, ni);
+            if (hipMemcpyAsync(h_text[k], d_text, (uint64_t)ni * row_bytes, hipMemcpyDeviceToHost, p->stream) != hipSuccess)
+                rc = ps_fail(PS_ERR_NO_DEVICE, "D2H copy failed in ps_write");
+            if (pending_buf >= 0 && fwrite(h_text[pending_buf], 1, pending, f) != pending)
+                rc = ps_fail(PS_ERR_IO, "short write to %s", path.c_str());
+            if (hipStreamSynchronize(p->stream) != hipSuccess && rc == PS_OK)
+                rc = ps_fail(PS_ERR_NO_DEVICE, "device failure in ps_write");
+            pending = (uint64_t)ni * row_bytes;
+            pending_buf = k;
+        }
+        if (rc == PS_OK && pending_buf >= 0 && fwrite(h_text[pending_buf], 1, pending, f) != pending)
+            rc = ps_fail(PS_ERR_IO, "short write to %s", path.c_str());
+        if (d_text) (void)hipFree(d_text);
+        for (auto *h : h_text) if (h) (void)hipHostFree(h);
+        fclose(f);
+        return rc;
+    }
+    std::vector<uint8_t> rows(std::max<uint64_t>(N * C, 1));
+    {
+        const int rc = ps_read_matrix(p, rows.data());
+        if (rc != PS_OK) { fclose(f); return rc; }
+    }
     std::string line;
     for (uint64_t i = 0; i < N; i++) {
         line.clear();

@@ -353,6 +353,19 @@ def test_write_matrices(pa, orc, tmp_path):
     assert (tmp_path / "got_pangenome.csv").read_text().splitlines()[0].startswith("1,1,")
 
 
+@pytest.mark.parametrize("N,L", [(130, 777), (1000, 129), (3, 64), (70, 1)])
+def test_write_core_matrix_tiles(pa, orc, tmp_path, N, L):
+    # the device-side text expansion across tile boundaries, byte for byte against the oracle writer
+    rng = np.random.default_rng(N + L)
+    m = _rand_core(rng, N, L)
+    m[rng.integers(0, N), rng.integers(0, L)] = 7          # not an allele -> 'N'
+    core = pa.Population(N, L, 4, True, 0.0, 0, 0)
+    core.load_matrix(m)
+    core.write(str(tmp_path / "got"))
+    orc.lib().orc_write_matrix(m, N, L, 1, 0, str(tmp_path / "want").encode())
+    assert (tmp_path / "got_core_genome.csv").read_bytes() == (tmp_path / "want_core_genome.csv").read_bytes()
+
+
 # ----------------------------------------------------------------------------- L-loop
 SIM_CASES = [
     dict(pop_size=100, core_size=12000, pan_genes=600, core_genes=200),                   # config 1'
