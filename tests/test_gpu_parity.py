@@ -608,3 +608,57 @@ def test_random_operator_sequences(pa, orc, trial):
     assert np.array_equal(acc.gene_frequencies(), orc.gene_frequencies(ma, 7))
     core.close()
     acc.close()
+
+
+# ----------------------------------------------------------------------------- error behaviour
+def test_error_codes_replace_reference_panics(pa):
+    pop = pa.Population(10, 50, 4, True, 0.0, 0, 0)
+    with pytest.raises(pa.PansimError) as e:             # rates are a precondition of the keyed operators
+        pop.mutate_alleles(0)
+    assert e.value.code == -6
+    with pytest.raises(pa.PansimError) as e:             # parent index out of range (ndarray would panic)
+        pop.next_generation(np.full(10, 10, np.uint32))
+    assert e.value.code == -1
+    with pytest.raises(pa.PansimError):                  # pair index out of range
+        pop.pairwise_counts([0, 11], [1, 2])
+    with pytest.raises(pa.PansimError):                  # unknown tuning key
+        pop.set_tuning("no_such_key", 1)
+    with pytest.raises(pa.PansimError):                  # Poisson::new(lambda < 0).unwrap() (population.rs:484)
+        pop.set_rates([-1.0], [0.0])
+    one = pa.Population(1, 20, 4, True, 0.0, 0, 0)
+    with pytest.raises(pa.PansimError):                  # Uniform::new(0, 0) panics for pop_size 1 (population.rs:584)
+        one.set_rates([1.0], [1.0])
+    one.set_rates([5.0], [0.0])
+    one.mutate_alleles(0)                                # mutation alone is fine for a single individual
+    acc = pa.Population(10, 30, 2, False, 0.5, 0, 0)
+    with pytest.raises(pa.PansimError) as e:             # ln(penalty) = NaN -> WeightedIndex::new panics (:440)
+        acc.sample_indices(0, 10, np.ones(10), np.zeros(30), False, False, -1.0, 0.0)
+    assert e.value.code == -4
+    with pytest.raises(pa.PansimError):                  # gene_frequencies is an accessory-matrix method in main()
+        pop.gene_frequencies()
+    with pytest.raises(pa.PansimError):                  # pop_size 1 cannot draw pairs (main.rs:421 panics)
+        pa.Simulation(pa.make_params(pop_size=1, core_size=100, pan_genes=60, core_genes=20))
+    # a failed generation leaves an error, not a crash
+    sim = pa.Simulation(pa.make_params(pop_size=20, core_size=200, pan_genes=60, core_genes=20, genome_size_penalty=-1.0))
+    with pytest.raises(pa.PansimError) as e:
+        sim.run(1)
+    assert e.value.code == -4
+    sim.close()
+
+
+def test_zero_accessory_genes(pa, orc):
+    # pan_genes == core_genes: the accessory matrix has no columns (population.rs:293-296 keeps weights 1.0)
+    from orc_sim import OracleSim
+    kw = dict(pop_size=50, core_size=700, pan_genes=100, core_genes=100, avg_gene_freq=1.0)
+    sim = pa.Simulation(pa.make_params(seed=2, n_gen=3, max_distances=200, **kw))
+    ref = OracleSim(seed=2, **kw)
+    sim.run(3)
+    sim.sync()
+    for g in range(3):
+        ref.generation(g)
+    assert np.array_equal(sim.last_parents(), ref.last_idx)
+    assert np.array_equal(sim.core_genome.read_matrix(), ref.core)
+    core_d, acc_d = sim.final_distances()
+    assert np.array_equal(acc_d, orc.pairwise_distances(ref.acc, False, 100, sim.range1, sim.range2))
+    assert (acc_d == 0.0).all()
+    sim.close()
