@@ -433,22 +433,34 @@ __global__ void __launch_bounds__(256, PS_ROWS >= 4 ? 6 : 8) core_sweep_wave_ker
 
 // ---------------------------------------------------------------------------
 // Block sweep for rows wider than one wavefront (pitch > 1024: cfg4/cfg5 populations).
-// A 1024-thread workgroup stages R whole site rows in LDS (parent rows and child rows);
-// its 16 waves split the rows into 1024-cell segments and treat each segment exactly like
-// the wave-per-row sweep treats a row (level-1 Philox, SWAR detection, wave-private
-// candidate queue, dense byte classification, exact level-2 pass).  A mutation only
-// touches the cells of the segment's own wave, so it needs no block barrier; cells that
-// receive a donor allele are collected in a per-wave HR list, and the donor reads /
-// writes happen between block barriers once every segment of the row has been mutated.
+// A workgroup of nw waves stages R whole site rows in LDS (parent rows and child rows) and
+// splits them into 1024-cell segments.  A wave takes PS_SB consecutive segments per
+// iteration and treats them exactly like the wave-per-row sweep treats its PS_ROWS rows:
+// level-1 Philox, SWAR detection, ONE wave-private candidate queue for the whole batch,
+// dense byte classification, one exact level-2 pass with (nearly) every lane busy.
+// A mutation only touches cells of the wave's own segments, so it needs no block barrier;
+// cells that receive a donor allele are collected in a per-wave HR list, and the donor
+// reads / writes happen between block barriers once every segment of the row group has
+// been mutated (the donor may sit in any segment).
+// Queue entry: LDS byte offset of the cell in rowS (20 bits) | level-1 byte << 20 | slot << 28.
 // ---------------------------------------------------------------------------
+#define PS_PF 4u   // prefetch registers (uint4) per thread: pf0..pf3 in the kernel
+// Workgroup barrier that orders LDS traffic only: outstanding global loads (the prefetch of the
+// next row group) and stores (the finished row group) stay in flight across it.
+__device__ __forceinline__ void ps_block_sync_lds()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 struct core_block_geom {
     uint32_t R;        // rows per workgroup iteration
     uint32_t segs;     // 1024-cell segments per row
-    uint32_t QW;       // candidate queue entries per wave
-    uint32_t HW;       // HR list entries per wave
+    uint32_t QW;       // candidate queue entries per wave (one batch of PS_SB segments)
+    uint32_t HW;       // HR list entries per wave (one row group)
+    uint32_t SB;       // segments per wave batch (template parameter PS_SB: 4, or 2 when LDS is short)
 };
 
-template <bool DO_GATHER, bool DO_MUT, bool DO_HR>
+template <uint32_t PS_SB, bool PRE, bool DO_GATHER, bool DO_MUT, bool DO_HR>
 __global__ void __launch_bounds__(1024) core_sweep_block_kernel(core_sweep_args a, core_block_geom g)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
@@ -461,74 +473,143 @@ __global__ void __launch_bounds__(1024) core_sweep_block_kernel(core_sweep_args 
     const bool events = pl.has_events && (DO_MUT || DO_HR);
     const uint32_t c4 = (pl.bC + 1u) * 0x01010101u;
     const uint32_t t0b = pl.T[0] >> 24, t1b = pl.T[1] >> 24, t2b = pl.T[2] >> 24;
+    unsigned long long lut = 0;     // 2-bit code per byte value < 32 (see the wave sweep)
+    for (uint32_t bb = 0; bb < 32u; bb++) {
+        const unsigned long long code = (bb < t0b) ? 1ull : (bb > t0b && bb < t1b) ? 2ull : (bb > t1b && bb < t2b) ? 3ull : 0ull;
+        lut |= code << (2u * bb);
+    }
+    const bool use_lut = pl.bC < 32u;
+    // (row, segment) of the first item of this wave's first batch, and the batch-to-batch stride
+    const uint32_t first_rr = (wave * PS_SB) / g.segs, first_sg = (wave * PS_SB) % g.segs;
+    const uint32_t step_rr = (nw * PS_SB) / g.segs, step_sg = (nw * PS_SB) % g.segs;
 
-    for (uint32_t r0 = blockIdx.x * g.R; r0 < a.rows; r0 += gridDim.x * g.R) {
-        const uint32_t nr = min(g.R, a.rows - r0);
-        // cooperative, coalesced load of the row group (rows are contiguous in HBM and in LDS)
-        {
-            const uint8_t *src = a.state + (size_t)r0 * a.pitch;
-            uint8_t *dst = DO_GATHER ? rowA : rowS;
-            for (uint32_t o = tid * 16u; o < nr * a.pitch; o += blockDim.x * 16u)
-                *(uint4 *)(dst + o) = *(const uint4 *)(src + o);
+    // PRE: every wave has exactly one batch per row group, i.e. the same PS_SB segments for the
+    // whole launch, and all parent indices fit 16 bits: the wave keeps the 16 parents of each of
+    // its lanes' cells in registers, two per VGPR (idxP[chunk][8], built by idx_pack16_kernel)
+    uint32_t pid[PS_SB][8];
+    if (PRE && DO_GATHER) {
+        uint32_t sg = first_sg;
+#pragma unroll
+        for (uint32_t s = 0; s < PS_SB; s++) {
+            const uint32_t chunk = min(sg * 64u + lane, a.cpr - 1u);
+            const uint4 lo = *(const uint4 *)(a.idxT + 8u * chunk), hi = *(const uint4 *)(a.idxT + 8u * chunk + 4u);
+            pid[s][0] = lo.x; pid[s][1] = lo.y; pid[s][2] = lo.z; pid[s][3] = lo.w;
+            pid[s][4] = hi.x; pid[s][5] = hi.y; pid[s][6] = hi.z; pid[s][7] = hi.w;
+            if (++sg == g.segs) sg = 0;
         }
-        __syncthreads();
+    }
+    // Software pipeline over the row groups of this workgroup: the next group is fetched into
+    // registers (PS_PF x 16 bytes per thread) while the current one is processed, and the stores
+    // of the finished group are never waited for (the barriers order LDS traffic only).
+    uint8_t *stage = DO_GATHER ? rowA : rowS;
+    const uint32_t gstride = gridDim.x * g.R;
+    const bool pipelined = g.R * a.pitch <= blockDim.x * 16u * PS_PF;
+    uint4 pf0 = make_uint4(0, 0, 0, 0), pf1 = pf0, pf2 = pf0, pf3 = pf0;
+    const uint32_t po0 = tid * 16u, po1 = po0 + blockDim.x * 16u, po2 = po1 + blockDim.x * 16u, po3 = po2 + blockDim.x * 16u;
+    uint32_t r0 = blockIdx.x * g.R;
+    if (r0 < a.rows) {
+        const uint32_t nr = min(g.R, a.rows - r0);
+        const uint8_t *src = a.state + (size_t)r0 * a.pitch;
+        for (uint32_t o = tid * 16u; o < nr * a.pitch; o += blockDim.x * 16u)
+            *(uint4 *)(stage + o) = *(const uint4 *)(src + o);
+    }
+    ps_block_sync_lds();
+    for (; r0 < a.rows; r0 += gstride) {
+        const uint32_t nr = min(g.R, a.rows - r0);
+        const uint32_t rnext = r0 + gstride;
+        const uint32_t nbytes_next = rnext < a.rows ? min(g.R, a.rows - rnext) * a.pitch : 0u;
+        if (pipelined) {
+            // unconditional loads (offsets past the group read its first bytes, never stored)
+            const uint8_t *src = a.state + (nbytes_next ? (size_t)rnext * a.pitch : (size_t)0);
+            pf0 = *(const uint4 *)(src + (po0 < nbytes_next ? po0 : 0u));
+            pf1 = *(const uint4 *)(src + (po1 < nbytes_next ? po1 : 0u));
+            pf2 = *(const uint4 *)(src + (po2 < nbytes_next ? po2 : 0u));
+            pf3 = *(const uint4 *)(src + (po3 < nbytes_next ? po3 : 0u));
+        }
 
         uint32_t nhr = 0;       // wave-uniform length of this wave's HR list
-        // items (row, segment) are dealt to the waves round-robin; (rr, sg) advance incrementally
-        uint32_t rr = wave / g.segs, sg = wave % g.segs;
-        for (uint32_t item = wave; item < nr * g.segs; item += nw, sg += nw) {
-            while (sg >= g.segs) { sg -= g.segs; rr++; }
-            const uint32_t chunk = sg * 64u + lane;
-            const bool has_chunk = chunk < a.cpr;
-            const uint32_t i0 = chunk * 16u;
-            const uint32_t nvalid = (i0 >= a.N) ? 0u : min(16u, a.N - i0);
-            const uint32_t site = a.site_offset + r0 + rr;
-            uint8_t *row = rowS + rr * a.pitch;
-            if (DO_GATHER) {
-                const uint8_t *par = rowA + rr * a.pitch;
-                uint32_t w[4] = { 0, 0, 0, 0 };
-                if (has_chunk) {
-                    // idxT[k][chunk]: consecutive lanes read consecutive words; entries beyond N
-                    // hold the index of the row's first padding byte (always 0)
-                    const uint32_t *ip = a.idxT + chunk;
-#pragma unroll
-                    for (int j = 0; j < 4; j++) {
-                        uint32_t x = 0;
-#pragma unroll
-                        for (int b = 0; b < 4; b++) {
-                            x |= (uint32_t)par[*ip] << (8 * b);
-                            ip += a.cpr;
-                        }
-                        w[j] = x;
-                    }
-                    *(uint4 *)(row + i0) = make_uint4(w[0], w[1], w[2], w[3]);
-                }
-            }
-            if (!events) continue;
-            uint32_t vperm = 0xF0F0F0F0u;   // all 16 cells valid
-            if (nvalid < 16u) {
-                vperm = 0;
-                for (uint32_t k = 0; k < nvalid; k++) vperm |= 1u << (8u * (k & 3u) + 7u - (k >> 2));
-            }
-            const ps_u4 l1 = ps_philox(site, chunk, a.gen, PS_STREAM_CORE_L1, a.k0, a.k1);
-            uint32_t cm = ps_candidates_swar(l1, c4) & vperm;
+        const uint32_t items = nr * g.segs;
+        uint32_t rr0 = first_rr, sg0 = first_sg;
+        for (uint32_t item0 = wave * PS_SB; item0 < items; item0 += nw * PS_SB) {
+            uint32_t s_base[PS_SB], s_site[PS_SB];   // wave-uniform per slot: LDS offset of the row, site
             uint32_t qn = 0;
-            for (;;) {
-                const bool act = cm != 0u;
-                const uint64_t bal = __ballot(act);
-                if (bal == 0ull) break;
-                if (act) {
-                    const uint32_t p = __builtin_ctz(cm);
-                    cm &= cm - 1u;
-                    const uint32_t b = p >> 3, j = 7u - (p & 7u);
-                    const uint32_t sel = ((j & 1u) * 4u + b) | 0x0c0c0c00u;
-                    const uint32_t byte = (j & 2u) ? __builtin_amdgcn_perm(l1.w, l1.z, sel)
-                                                   : __builtin_amdgcn_perm(l1.y, l1.x, sel);
-                    const uint32_t pos = qn + ps_lane_prefix(bal);
-                    if (pos < g.QW) q[pos] = (i0 + 4u * j + b) | (byte << 20);
+            uint32_t rr = rr0, sg = sg0;
+#pragma unroll
+            for (uint32_t s = 0; s < PS_SB; s++) {
+                s_base[s] = rr * a.pitch;
+                s_site[s] = a.site_offset + r0 + rr;
+                if (item0 + s < items) {
+                    const uint32_t chunk = sg * 64u + lane;
+                    const bool has_chunk = chunk < a.cpr;
+                    const uint32_t i0 = chunk * 16u;
+                    uint8_t *row = rowS + s_base[s];
+                    if (DO_GATHER) {
+                        const uint8_t *par = rowA + s_base[s];
+                        if (has_chunk) {
+                            uint32_t w[4];
+                            if (PRE) {
+#pragma unroll
+                                for (int j = 0; j < 4; j++) {
+                                    uint32_t x = 0;
+#pragma unroll
+                                    for (int b = 0; b < 4; b++) {
+                                        const uint32_t pk = pid[s][(4 * j + b) >> 1];
+                                        x |= (uint32_t)par[(b & 1) ? (pk >> 16) : (pk & 0xFFFFu)] << (8 * b);
+                                    }
+                                    w[j] = x;
+                                }
+                            } else {
+                                // idxT[k][chunk]: consecutive lanes read consecutive words; entries beyond N
+                                // hold the index of the row's first padding byte (always 0)
+                                const uint32_t *ip = a.idxT + chunk;
+#pragma unroll
+                                for (int j = 0; j < 4; j++) {
+                                    uint32_t x = 0;
+#pragma unroll
+                                    for (int b = 0; b < 4; b++) {
+                                        x |= (uint32_t)par[*ip] << (8 * b);
+                                        ip += a.cpr;
+                                    }
+                                    w[j] = x;
+                                }
+                            }
+                            *(uint4 *)(row + i0) = make_uint4(w[0], w[1], w[2], w[3]);
+                        }
+                    }
+                    if (events) {
+                        const uint32_t nvalid = (i0 >= a.N) ? 0u : min(16u, a.N - i0);
+                        uint32_t vperm = 0xF0F0F0F0u;   // all 16 cells valid
+                        if (nvalid < 16u) {
+                            vperm = 0;
+                            for (uint32_t k = 0; k < nvalid; k++) vperm |= 1u << (8u * (k & 3u) + 7u - (k >> 2));
+                        }
+                        const ps_u4 l1 = ps_philox(s_site[s], chunk, a.gen, PS_STREAM_CORE_L1, a.k0, a.k1);
+                        uint32_t cm = ps_candidates_swar(l1, c4) & vperm;
+                        const uint32_t off0 = s_base[s] + i0;
+                        for (;;) {
+                            const bool act = cm != 0u;
+                            const uint64_t bal = __ballot(act);
+                            if (bal == 0ull) break;
+                            if (act) {
+                                const uint32_t p = __builtin_ctz(cm);
+                                cm &= cm - 1u;
+                                const uint32_t b = p >> 3, j = 7u - (p & 7u);
+                                const uint32_t sel = ((j & 1u) * 4u + b) | 0x0c0c0c00u;
+                                const uint32_t byte = (j & 2u) ? __builtin_amdgcn_perm(l1.w, l1.z, sel)
+                                                               : __builtin_amdgcn_perm(l1.y, l1.x, sel);
+                                const uint32_t pos = qn + ps_lane_prefix(bal);
+                                if (pos < g.QW) q[pos] = (off0 + 4u * j + b) | (byte << 20) | (s << 28);
+                            }
+                            qn += (uint32_t)__popcll(bal);
+                        }
+                    }
                 }
-                qn += (uint32_t)__popcll(bal);
+                if (++sg == g.segs) { sg = 0; rr++; }
             }
+            rr0 += step_rr;
+            sg0 += step_sg;
+            if (sg0 >= g.segs) { sg0 -= g.segs; rr0++; }
+            if (!events) continue;
             ps_wave_sync();
             if (qn > g.QW) {
                 if (lane == 0) atomicOr(a.overflow_flag, 2u);
@@ -540,13 +621,18 @@ __global__ void __launch_bounds__(1024) core_sweep_block_kernel(core_sweep_args 
                 const uint32_t e = base + lane;
                 const bool valid = e < qn;
                 const uint32_t ent = valid ? q[e] : 0u;
-                const uint32_t byte = ent >> 20;
+                const uint32_t byte = (ent >> 20) & 0xFFu;
                 uint32_t allele = 0;
-                if (byte < t0b) allele = 2u;
-                else if (byte > t0b && byte < t1b) allele = 4u;
-                else if (byte > t1b && byte < t2b) allele = 8u;
+                if (use_lut) {
+                    const uint32_t code = (uint32_t)(lut >> (2u * (byte & 31u))) & 3u;
+                    allele = code ? (1u << code) : 0u;
+                } else {
+                    if (byte < t0b) allele = 2u;
+                    else if (byte > t0b && byte < t1b) allele = 4u;
+                    else if (byte > t1b && byte < t2b) allele = 8u;
+                }
                 const bool amb = valid && allele == 0u;
-                if (DO_MUT && valid && allele) row[ent & 0xFFFFFu] = (uint8_t)allele;
+                if (DO_MUT && valid && allele) rowS[ent & 0xFFFFFu] = (uint8_t)allele;
                 const uint64_t bal = __ballot(amb);
                 if (amb) q[n2 + ps_lane_prefix(bal)] = ent;
                 n2 += (uint32_t)__popcll(bal);
@@ -556,14 +642,22 @@ __global__ void __launch_bounds__(1024) core_sweep_block_kernel(core_sweep_args 
             for (uint32_t base = 0; base < n2; base += 64u) {
                 const uint32_t e = base + lane;
                 bool hr = false;
-                uint32_t cellidx = 0, donor = 0;
+                uint32_t off = 0, donor = 0, rbase = 0;
                 if (e < n2) {
                     const uint32_t ent = q[e];
-                    cellidx = ent & 0xFFFFFu;
-                    const uint32_t byte = ent >> 20;
+                    off = ent & 0xFFFFFu;
+                    const uint32_t byte = (ent >> 20) & 0xFFu, s = ent >> 28;
+                    rbase = s_base[0];
+                    uint32_t site = s_site[0];
+#pragma unroll
+                    for (uint32_t k = 1; k < PS_SB; k++) {
+                        rbase = (s == k) ? s_base[k] : rbase;
+                        site = (s == k) ? s_site[k] : site;
+                    }
+                    const uint32_t cellidx = off - rbase;
                     const ps_u4 l2 = ps_philox(site, cellidx, a.gen, PS_STREAM_CORE_L2, a.k0, a.k1);
                     const ps_cell cell = ps_classify((byte << 24) | (l2.x >> 8), pl);
-                    if (DO_MUT && cell.mut) row[cellidx] = (uint8_t)cell.mut;
+                    if (DO_MUT && cell.mut) rowS[off] = (uint8_t)cell.mut;
                     if (DO_HR && cell.hr) {
                         hr = true;
                         donor = ps_mulhi(l2.y, a.N - 1u);
@@ -574,7 +668,7 @@ __global__ void __launch_bounds__(1024) core_sweep_block_kernel(core_sweep_args 
                     const uint64_t bal = __ballot(hr);
                     if (hr) {
                         const uint32_t pos = nhr + ps_lane_prefix(bal);
-                        if (pos < g.HW) { hr_a[pos] = rr * a.pitch + cellidx; hr_b[pos] = rr * a.pitch + donor; }
+                        if (pos < g.HW) { hr_a[pos] = off; hr_b[pos] = rbase + donor; }
                     }
                     nhr += (uint32_t)__popcll(bal);
                 }
@@ -586,19 +680,41 @@ __global__ void __launch_bounds__(1024) core_sweep_block_kernel(core_sweep_args 
                 if (lane == 0) atomicOr(a.overflow_flag, 4u);
                 nhr = g.HW;
             }
-            __syncthreads();    // every segment is mutated: rowS is the snapshot (population.rs:693-695)
+            ps_block_sync_lds();    // every segment is mutated: rowS is the snapshot (population.rs:693-695)
             for (uint32_t e = lane; e < nhr; e += 64u) hr_b[e] = (uint32_t)rowS[hr_b[e]];
-            __syncthreads();    // all donor reads done
+            ps_block_sync_lds();    // all donor reads done
             for (uint32_t e = lane; e < nhr; e += 64u) rowS[hr_a[e]] = (uint8_t)hr_b[e];
         }
-        __syncthreads();
+        ps_block_sync_lds();        // the child rows are final; nobody reads the parent rows any more
         {
             uint8_t *dstg = a.state + (size_t)r0 * a.pitch;
             for (uint32_t o = tid * 16u; o < nr * a.pitch; o += blockDim.x * 16u)
                 *(uint4 *)(dstg + o) = *(const uint4 *)(rowS + o);
         }
-        __syncthreads();        // the next row group overwrites the LDS rows
+        // stage the next row group; a thread overwrites only LDS bytes it has just read itself
+        if (pipelined) {
+            if (po0 < nbytes_next) *(uint4 *)(stage + po0) = pf0;
+            if (po1 < nbytes_next) *(uint4 *)(stage + po1) = pf1;
+            if (po2 < nbytes_next) *(uint4 *)(stage + po2) = pf2;
+            if (po3 < nbytes_next) *(uint4 *)(stage + po3) = pf3;
+        } else if (nbytes_next) {
+            const uint8_t *src = a.state + (size_t)rnext * a.pitch;
+            for (uint32_t o = tid * 16u; o < nbytes_next; o += blockDim.x * 16u)
+                *(uint4 *)(stage + o) = *(const uint4 *)(src + o);
+        }
+        ps_block_sync_lds();        // the next iteration overwrites the child rows
     }
+}
+
+// idxP[chunk][j] = idx[16*chunk + 2j] | idx[16*chunk + 2j + 1] << 16 (N beyond N, as in idxT):
+// the parents of a lane's 16 cells as two 16-byte loads (block sweep with N <= 65536)
+__global__ void idx_pack16_kernel(const uint32_t *idx, uint32_t *idxP, uint32_t N, uint32_t cpr)
+{
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= 8u * cpr) return;
+    const uint32_t i = 2u * t;
+    const uint32_t lo = (i < N) ? idx[i] : N, hi = (i + 1u < N) ? idx[i + 1u] : N;
+    idxP[t] = (lo & 0xFFFFu) | (hi << 16);
 }
 
 // idxT[k][chunk] = idx[16*chunk + k] (0 beyond N): coalesced parent indices for the block sweep

@@ -204,6 +204,8 @@ struct ps_population {
     uint32_t sweep_rows = 3;            // wave-per-row sweep: site rows per wave iteration (2..4)
     bool force_block_sweep = false;     // tests: run the block sweep on small populations
     bool force_inline_sweep = false;    // tests: run the inline (queue-free) block sweep
+    uint32_t block_waves = 0;           // block sweep: waves per workgroup (0 = auto: 4, 8 or 16)
+    bool no_block_preload = false;      // tests: block sweep reads its parent indices per batch
     uint32_t *h_flag = nullptr, *d_flag = nullptr;   // host-mapped sticky device error word
     unsigned long long *h_stamps = nullptr, *d_stamps = nullptr;   // diagnostic phase stamps
 };
@@ -392,6 +394,11 @@ extern "C" int ps_set_tuning(ps_population *p, const char *key, int64_t value)
         p->force_block_sweep = value != 0;
     } else if (k == "force_inline_sweep") {
         p->force_inline_sweep = value != 0;
+    } else if (k == "no_block_preload") {
+        p->no_block_preload = value != 0;
+    } else if (k == "block_waves") {
+        if (value != 0 && value != 4 && value != 8 && value != 16) return ps_fail(PS_ERR_INVALID, "block_waves must be 0 (auto), 4, 8 or 16");
+        p->block_waves = (uint32_t)value;
     } else if (k == "lds_limit") {
         if (value < 1024 || value > 160 * 1024) return ps_fail(PS_ERR_INVALID, "lds_limit must be 1 KiB..160 KiB");
         p->lds_limit = (uint32_t)value;
@@ -544,43 +551,78 @@ static bool wave_sweep_eligible(ps_population *p, bool mu, bool hr)
 
 // geometry of the block sweep for this population and these rates; false if its queues cannot
 // be sized safely (then the inline block kernel, correct for any rates, is used)
-static bool block_sweep_geometry(const ps_population *p, bool ga, bool mu, bool hr, core_block_geom *g, uint32_t *lds)
+static bool block_sweep_geometry(const ps_population *p, bool ga, bool mu, bool hr, core_block_geom *g,
+                                 uint32_t *lds, uint32_t *waves)
 {
     const ps_core_plan &pl = p->cplan;
     const bool events = pl.has_events && (mu || hr);
     if (events && pl.bC > 126) return false;
     g->segs = (p->cpr + 63u) / 64u;
     auto up16 = [](double x) { return (uint32_t)(((uint64_t)std::ceil(x) + 15u) & ~15ull); };
-    const double mq = events ? 1024.0 * (double)(pl.bC + 1u) / 256.0 : 0.0;
-    g->QW = std::max(64u, up16(mq + 10.0 * std::sqrt(mq) + 16.0));
     const double hr_frac = (events && hr) ? (double)(pl.T[6] - pl.T[2]) / 4294967296.0 : 0.0;
-    for (uint32_t R = std::max(1u, 16u / std::max(1u, g->segs)); R >= 1; R >>= 1) {
-        const uint32_t items_per_wave = (R * g->segs + 15u) / 16u;
-        const double mh = (double)items_per_wave * 1024.0 * hr_frac;
-        g->R = R;
-        g->HW = std::max(16u, up16(mh + 10.0 * std::sqrt(mh) + 16.0));
-        *lds = (ga ? 2u : 1u) * R * p->pitch + 16u * (g->QW + 2u * g->HW) * 4u;
-        if (*lds <= p->lds_limit) return true;
-        if (R == 1) break;
+    // a wave works on batches of SB segments (4, or 2 when the queues of 4 do not fit beside the
+    // rows); the workgroup is as small as a row allows (4, 8 or 16 waves), so that several
+    // workgroups per CU overlap their load / compute / store phases
+    for (uint32_t SB = 4; SB >= 2; SB >>= 1) {
+        uint32_t nw = 4;
+        while (nw < 16u && nw * SB < g->segs) nw *= 2u;
+        if (p->block_waves) nw = p->block_waves;
+        *waves = nw;
+        g->SB = SB;
+        const double mq = events ? SB * 1024.0 * (double)(pl.bC + 1u) / 256.0 : 0.0;
+        g->QW = std::max(64u, up16(mq + 10.0 * std::sqrt(mq)));
+        for (uint32_t R = std::max(1u, nw * SB / std::max(1u, g->segs)); R >= 1; R >>= 1) {
+            const uint32_t batches_per_wave = (R * g->segs + nw * SB - 1u) / (nw * SB);
+            const double mh = (double)batches_per_wave * SB * 1024.0 * hr_frac;
+            g->R = R;
+            g->HW = std::max(16u, up16(mh + 10.0 * std::sqrt(mh) + 16.0));
+            *lds = (ga ? 2u : 1u) * R * p->pitch + nw * (g->QW + 2u * g->HW) * 4u;
+            if (*lds <= p->lds_limit) return true;
+            if (R == 1) break;
+        }
     }
     return false;
 }
 
+// PRE variant of the block sweep: one batch per wave and row group, 16-bit parent indices
+static bool block_sweep_preload(const ps_population *p, const core_block_geom &g, uint32_t nw)
+{
+    return p->pitch <= 65536u && g.R * g.segs <= nw * g.SB && !p->no_block_preload;
+}
+
+template <uint32_t SB, bool PRE, bool GA, bool MU, bool HR>
+static int launch_block_kernel(const core_sweep_args &a, const core_block_geom &g, uint32_t lds, uint32_t nw, hipStream_t st)
+{
+    auto kern = core_sweep_block_kernel<SB, PRE, GA, MU, HR>;
+    if (lds > 64 * 1024)
+        HIPCHK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const uint32_t groups = (a.rows + g.R - 1) / g.R;
+    int bpc = 0;
+    HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, (const void *)kern, (int)(64u * nw), lds));
+    bpc = std::max(1, bpc);
+    const uint32_t grid = std::max(1u, std::min(groups, 256u * (uint32_t)bpc));
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(64u * nw), lds, st, a, g);
+    HIPCHK(hipGetLastError());
+    return PS_OK;
+}
+
 template <bool GA, bool MU, bool HR>
-static int launch_core_sweep_block(ps_population *p, const core_sweep_args &a, hipStream_t st)
+static int launch_core_sweep_block(ps_population *p, const core_sweep_args &a, const uint32_t *d_idx, hipStream_t st)
 {
     core_block_geom g{};
-    uint32_t lds = 0;
-    if (!p->force_inline_sweep && block_sweep_geometry(p, GA, MU, HR, &g, &lds)) {
-        auto kern = core_sweep_block_kernel<GA, MU, HR>;
-        if (lds > 64 * 1024)
-            HIPCHK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        const uint32_t groups = (a.rows + g.R - 1) / g.R;
-        const uint32_t bpc = std::max(1u, std::min(2u, p->lds_limit / lds));
-        const uint32_t grid = std::max(1u, std::min(groups, 256u * bpc));
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(1024), lds, st, a, g);
-        HIPCHK(hipGetLastError());
-        return PS_OK;
+    uint32_t lds = 0, nw = 0;
+    if (!p->force_inline_sweep && block_sweep_geometry(p, GA, MU, HR, &g, &lds, &nw)) {
+        const bool pre = GA && block_sweep_preload(p, g, nw);
+        if (GA) {
+            const uint32_t n = (pre ? 8u : 16u) * p->cpr;
+            if (pre) idx_pack16_kernel<<<(n + 255) / 256, 256, 0, st>>>(d_idx, p->d_idxT, a.N, p->cpr);
+            else idx_transpose_kernel<<<(n + 255) / 256, 256, 0, st>>>(d_idx, p->d_idxT, a.N, p->cpr);
+        }
+        if (GA && pre)
+            return g.SB == 4u ? launch_block_kernel<4, GA, GA, MU, HR>(a, g, lds, nw, st)
+                              : launch_block_kernel<2, GA, GA, MU, HR>(a, g, lds, nw, st);
+        return g.SB == 4u ? launch_block_kernel<4, false, GA, MU, HR>(a, g, lds, nw, st)
+                          : launch_block_kernel<2, false, GA, MU, HR>(a, g, lds, nw, st);
     }
     // inline kernel: every candidate handled by its owner lane, no queues to overflow
     const uint32_t block = 1024u;
@@ -622,14 +664,10 @@ static int launch_core_sweep(ps_population *p, const uint32_t *d_idx, uint32_t g
     a.work_ctr = p->d_work;
     a.launch_parity = (uint32_t)(p->sweep_launches++ & 1u);
     a.idxT = p->d_idxT;
-    if (!wave && ga) {
-        const uint32_t n = 16u * p->cpr;
-        idx_transpose_kernel<<<(n + 255) / 256, 256, 0, st>>>(d_idx, p->d_idxT, a.N, p->cpr);
-    }
 #define PS_DISPATCH(G_, M_, H_)                                              \
     if (ga == G_ && mu == M_ && hr == H_)                                    \
         return wave ? launch_core_sweep_wave<G_, M_, H_>(p, a, st)           \
-                    : launch_core_sweep_block<G_, M_, H_>(p, a, st);
+                    : launch_core_sweep_block<G_, M_, H_>(p, a, d_idx, st);
     PS_DISPATCH(true, false, false)
     PS_DISPATCH(false, true, false)
     PS_DISPATCH(false, false, true)

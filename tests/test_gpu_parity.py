@@ -114,6 +114,8 @@ CORE_CASES = [
     (1500, 150, 3000, 100, 150.0, 15.0),         # block sweep, two segments per row
     (5000, 60, 60000, 0, 3000.0, 3000.0),        # block sweep, five segments, partial last one
     (20000, 9, 900, 0, 45.0, 200.0),             # block sweep, one row per workgroup iteration
+    (70000, 5, 500, 0, 5.0, 1.0),                # block sweep, 69 segments: 16 waves, two batches for some
+    (65536, 3, 1200000, 77, 60000.0, 3000.0),    # cfg4 population at the default rates (LDS exactly full)
     (17, 64, 64, 0, 64.0, 0.0),
     (2, 300, 300, 0, 30.0, 30.0),
 ]
@@ -458,6 +460,32 @@ def test_block_sweep_equals_wave_sweep(pa, orc, N, L, lm, lh):
             pop.step(2, sample, True)
             assert np.array_equal(pop.read_matrix(), want)
             pop.close()
+
+
+@pytest.mark.parametrize("N,L,tune", [(5000, 40, {"block_waves": 8}), (5000, 40, {"block_waves": 16}),
+                                      (3000, 50, {"lds_limit": 12000}), (9000, 30, {"lds_limit": 40000}),
+                                      (2500, 64, {"block_waves": 16, "lds_limit": 30000}),
+                                      (5000, 40, {"no_block_preload": 1}), (9000, 30, {"no_block_preload": 1, "block_waves": 16}),
+                                      (3000, 50, {"block_waves": 4, "lds_limit": 9000})])
+def test_block_sweep_geometries(pa, orc, N, L, tune):
+    # workgroup size, rows per iteration and the 4- or 2-segment batches are host choices that
+    # must not change the result
+    rng = np.random.default_rng(N + L)
+    m0 = _rand_core(rng, N, L)
+    sample = rng.integers(0, N, N).astype(np.uint32)
+    lm, lh = 0.05 * L, 0.02 * L
+    plan = orc.core_plan(lm, lh, L)
+    want = orc.next_generation(m0, sample)
+    orc.mutate_core(want, 0, 9, 3, plan)
+    orc.recombine_core(want, 0, 9, 3, plan)
+    pop = pa.Population(N, L, 4, True, 0.0, 9, 0)
+    for k, v in tune.items():
+        pop.set_tuning(k, v)
+    pop.set_rates([lm], [lh])
+    pop.load_matrix(m0)
+    pop.step(3, sample, True)
+    assert np.array_equal(pop.read_matrix(), want)
+    pop.close()
 
 
 # ----------------------------------------------------------------------------- BASELINE full sizes
