@@ -833,72 +833,100 @@ __global__ void __launch_bounds__(256) core_csv_kernel(const uint8_t *state, uin
 // LDS reads.  Each pair keeps its partial count in a register across the tiles
 // of the block's site range; one atomicAdd per (range, pair).
 // ---------------------------------------------------------------------------
+// Nibble strings of 4 individuals from 8 site rows: v[b] holds the bytes (alleles < 16) of
+// individuals 4*qd .. 4*qd+3 at site b; out[j] gets site b of individual j in bits 4b..4b+3.
+// Two rows share a byte (v_lshl_or), then a 4 x 4 byte transpose (8 v_perm).
+__device__ __forceinline__ void ps_nibble_pack8(const uint32_t *v, uint32_t (&out)[4])
+{
+    const uint32_t t0 = v[0] | (v[1] << 4), t1 = v[2] | (v[3] << 4), t2 = v[4] | (v[5] << 4), t3 = v[6] | (v[7] << 4);
+    // __builtin_amdgcn_perm(hi, lo, sel): byte k of the result is byte sel[k] of {hi:lo} (lo = bytes 0-3)
+    const uint32_t a01 = __builtin_amdgcn_perm(t1, t0, 0x05010400u);   // t0.b0 t1.b0 t0.b1 t1.b1
+    const uint32_t b01 = __builtin_amdgcn_perm(t1, t0, 0x07030602u);   // t0.b2 t1.b2 t0.b3 t1.b3
+    const uint32_t a23 = __builtin_amdgcn_perm(t3, t2, 0x05010400u);
+    const uint32_t b23 = __builtin_amdgcn_perm(t3, t2, 0x07030602u);
+    out[0] = __builtin_amdgcn_perm(a23, a01, 0x05040100u);             // individual 0: t0.b0 t1.b0 t2.b0 t3.b0
+    out[1] = __builtin_amdgcn_perm(a23, a01, 0x07060302u);
+    out[2] = __builtin_amdgcn_perm(b23, b01, 0x05040100u);
+    out[3] = __builtin_amdgcn_perm(b23, b01, 0x07060302u);
+}
+
 template <int A>
 __global__ void __launch_bounds__(1024) core_pair_counts_tiled(
     const uint8_t *state, uint32_t N, uint32_t pitch, uint32_t rows, const uint32_t *r1,
     const uint32_t *r2, const uint32_t *perm /* output slot of pair k, or null */, uint64_t P,
-    uint32_t *out, uint32_t W /* dwords per individual per tile */, uint32_t tiles_per_range)
+    uint32_t *out, uint32_t W /* dwords per individual per tile */, uint32_t tiles_per_range,
+    uint32_t a_eff /* pairs per thread, <= A */)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t T[];
-    const uint32_t RS = W + 4u;
+    const uint32_t RS4 = (W >> 2) + 1u;      // row stride in 16-byte units (odd: spreads the banks)
     const uint32_t tid = threadIdx.x;
-    const uint32_t sites_per_tile = W * 8u;
-    const uint64_t kbase = (uint64_t)blockIdx.y * A * blockDim.x + tid;
-    uint32_t pi[A], pj[A], acc[A];
+    // a thread owns a_eff CONSECUTIVE pairs of the list sorted by first individual: the first
+    // individual's string is re-read only when it changes (about once per thread)
+    const uint64_t kbase = ((uint64_t)blockIdx.y * blockDim.x + tid) * a_eff;
+    // per-pair counts of this workgroup's site range, two 16-bit counters per register (the host
+    // keeps a range below 65536 / 2 sites)
+    uint32_t pij[A], acc[A / 2];
 #pragma unroll
     for (int q = 0; q < A; q++) {
-        const uint64_t k = kbase + (uint64_t)q * blockDim.x;
-        acc[q] = 0;
-        // row offsets in 16-byte units so that the tile reads are provably aligned (ds_read_b128)
-        if (k < P) { pi[q] = r1[k] * (RS >> 2); pj[q] = r2[k] * (RS >> 2); }
-        else { pi[q] = 0; pj[q] = 0; }     // same row twice: contributes nothing
+        const uint64_t k = kbase + q;
+        if (!(q & 1)) acc[q >> 1] = 0;
+        pij[q] = ((uint32_t)q < a_eff && k < P) ? (r1[k] * RS4) | ((r2[k] * RS4) << 16) : 0u;   // same row twice: adds nothing
     }
+    const uint4 *T4 = (const uint4 *)T;
     for (uint32_t t = 0; t < tiles_per_range; t++) {
-        const uint32_t s0 = (blockIdx.x * tiles_per_range + t) * sites_per_tile;
+        const uint32_t s0 = (blockIdx.x * tiles_per_range + t) * W * 8u;
         if (s0 >= rows) break;
         __syncthreads();
-        // work item = (4 consecutive individuals, 32 consecutive sites): 32 independent dword
-        // loads (a wave reads 256 contiguous bytes of a site row), repacked into one
-        // 16-byte nibble string per individual
-        const uint32_t quads = (N + 3u) >> 2, sgs = W >> 2;
+        // work item = (4 consecutive individuals, 16 consecutive sites): 16 independent dword
+        // loads (a wave reads 256 contiguous bytes of a site row), repacked into one 8-byte
+        // nibble string per individual
+        const uint32_t quads = (N + 3u) >> 2, sgs = W >> 1;
         for (uint32_t it = tid; it < quads * sgs; it += blockDim.x) {
             const uint32_t qd = it % quads, sg = it / quads;
-            const uint32_t sb = s0 + 32u * sg;
+            const uint32_t sb = min(s0 + 16u * sg, rows - 1u);   // (a whole item past the end packs zeros)
+            const bool item_valid = s0 + 16u * sg < rows;
             const uint8_t *base = state + (size_t)sb * pitch + 4u * qd;
-            uint32_t v[32];
+            // 16 unconditional loads in flight (rows past the end re-read the last row and are
+            // zeroed afterwards: only the last tile takes that branch)
+            uint32_t v[16];
 #pragma unroll
-            for (int b = 0; b < 32; b++)
-                v[b] = (sb + b < rows) ? *(const uint32_t *)(base + (size_t)b * pitch) : 0u;
+            for (int b = 0; b < 16; b++)
+                v[b] = *(const uint32_t *)(base + (size_t)min((uint32_t)b, rows - 1u - sb) * pitch);
+            if (sb + 16u > rows) {
 #pragma unroll
-            for (int j = 0; j < 4; j++) {
-                uint32_t o[4];
-#pragma unroll
-                for (int m = 0; m < 4; m++) {
-                    uint32_t x = 0;
-#pragma unroll
-                    for (int b = 0; b < 8; b++) x |= ((v[8 * m + b] >> (8 * j)) & 0xFu) << (4 * b);
-                    o[m] = x;
-                }
-                if (4u * qd + j < N) ((uint4 *)T)[(4u * qd + j) * (RS >> 2) + sg] = make_uint4(o[0], o[1], o[2], o[3]);
+                for (int b = 0; b < 16; b++)
+                    if (!item_valid || sb + b >= rows) v[b] = 0u;
             }
+            uint32_t lo[4], hi[4];
+            ps_nibble_pack8(v, lo);
+            ps_nibble_pack8(v + 8, hi);
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+                if (4u * qd + j < N) ((uint2 *)T)[(4u * qd + j) * (RS4 * 2u) + sg] = make_uint2(lo[j], hi[j]);
         }
         __syncthreads();
+        for (uint32_t w4 = 0; w4 < (W >> 2); w4++) {
+            uint4 x = make_uint4(0, 0, 0, 0);
+            uint32_t cur = 0xFFFFFFFFu;
 #pragma unroll
-        for (int q = 0; q < A; q++) {
-            uint32_t s = 0;
-            const uint4 *T4 = (const uint4 *)T;
-            for (uint32_t w4 = 0; w4 < (W >> 2); w4++) {
-                const uint4 x = T4[pi[q] + w4];
-                const uint4 y = T4[pj[q] + w4];
-                s += __popc(x.x ^ y.x) + __popc(x.y ^ y.y) + __popc(x.z ^ y.z) + __popc(x.w ^ y.w);
+            for (int q = 0; q < A; q++) {
+                if ((uint32_t)q < a_eff) {
+                    const uint32_t ri = pij[q] & 0xFFFFu, rj = pij[q] >> 16;
+                    if (ri != cur) { x = T4[ri + w4]; cur = ri; }
+                    const uint4 y = T4[rj + w4];
+                    const uint32_t c = __popc(x.x ^ y.x) + __popc(x.y ^ y.y) + __popc(x.z ^ y.z) + __popc(x.w ^ y.w);
+                    acc[q >> 1] += (q & 1) ? (c << 16) : c;
+                }
+                // keep at most 4 pairs' LDS reads in flight (the scheduler would hoist all A of them)
+                if ((q & 3) == 3) __builtin_amdgcn_sched_barrier(0);
             }
-            acc[q] += s;
         }
     }
 #pragma unroll
     for (int q = 0; q < A; q++) {
-        const uint64_t k = kbase + (uint64_t)q * blockDim.x;
-        if (k < P && acc[q]) atomicAdd(&out[perm ? perm[k] : k], acc[q]);
+        const uint64_t k = kbase + q;
+        const uint32_t c = (q & 1) ? (acc[q >> 1] >> 16) : (acc[q >> 1] & 0xFFFFu);
+        if ((uint32_t)q < a_eff && k < P && c) atomicAdd(&out[perm ? perm[k] : k], c);
     }
 }
 
@@ -921,21 +949,24 @@ __device__ __forceinline__ void ps_pack_tile(uint4 *T, const uint8_t *state, uin
         const uint32_t sb = s0 + 32u * sg;
         const uint32_t icol = ibase + 4u * qd;
         uint32_t v[32];
+        const bool item_valid = sb < rows && icol < pitch;
+        const uint32_t sbc = min(sb, rows - 1u);
+        const uint8_t *base = state + (size_t)sbc * pitch + min(icol, pitch - 4u);
 #pragma unroll
         for (int b = 0; b < 32; b++)
-            v[b] = (sb + b < rows && icol < pitch) ? *(const uint32_t *)(state + (size_t)(sb + b) * pitch + icol) : 0u;
+            v[b] = *(const uint32_t *)(base + (size_t)min((uint32_t)b, rows - 1u - sbc) * pitch);
+        if (!item_valid || sb + 32u > rows) {
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
-            uint32_t o[4];
-#pragma unroll
-            for (int m = 0; m < 4; m++) {
-                uint32_t x = 0;
-#pragma unroll
-                for (int b = 0; b < 8; b++) x |= ((v[8 * m + b] >> (8 * j)) & 0xFu) << (4 * b);
-                o[m] = x;
-            }
-            T[(4u * qd + j) * RS4 + sg] = make_uint4(o[0], o[1], o[2], o[3]);
+            for (int b = 0; b < 32; b++)
+                if (!item_valid || sb + b >= rows) v[b] = 0u;
         }
+        uint32_t o0[4], o1[4], o2[4], o3[4];
+        ps_nibble_pack8(v, o0);
+        ps_nibble_pack8(v + 8, o1);
+        ps_nibble_pack8(v + 16, o2);
+        ps_nibble_pack8(v + 24, o3);
+#pragma unroll
+        for (int j = 0; j < 4; j++) T[(4u * qd + j) * RS4 + sg] = make_uint4(o0[j], o1[j], o2[j], o3[j]);
     }
     (void)N;
 }

@@ -1014,10 +1014,11 @@ static int pair_counts_device(ps_population *p, uint64_t P, const uint32_t *d_r1
         for (uint32_t w : { 32u, 16u, 8u, 4u })
             if ((uint64_t)N * (w + 4) * 4 <= p->lds_limit) { W = w; break; }
         // all-pairs tiles cost ~N^2/2 * L regardless of P; the sampled kernel ~P * L with a
-        // worse constant (it re-packs the matrix once per 16384 pairs)
+        // worse constant (it re-packs the matrix once per 32768 pairs): measured crossover at
+        // N = 1000 is P ~ 250 k = half of all pairs
         const double all_pairs = 0.5 * (double)N * (double)N;
         const bool use_all = p->nibble_safe && p->pair_mode != 1 && (uint64_t)N * N * 4 <= (8ull << 30)
-                             && (p->pair_mode == 2 || (double)P * 2.5 > all_pairs || !W);
+                             && (p->pair_mode == 2 || (double)P * 2.0 > all_pairs || !W);
         if (use_all) {
             const uint32_t WA = 32u, ntile = (N + 127u) / 128u;
             const uint32_t lds = 2u * 128u * ((WA >> 2) + 1u) * 16u;
@@ -1038,20 +1039,26 @@ static int pair_counts_device(ps_population *p, uint64_t P, const uint32_t *d_r1
                                                                           cpr, ntile);
             core_pair_lookup_kernel<<<(uint32_t)((P + 255) / 256), 256, 0, st>>>(p->d_H, N, d_r1, d_r2, d_perm, P, d_a);
         } else if (p->nibble_safe && W) {
-            constexpr int A = 16;
+            constexpr int A = 32;
             constexpr uint32_t PT = 1024;
-            const uint32_t lds = N * (W + 4) * 4;
+            const uint32_t lds = N * ((W >> 2) + 1u) * 16u;
             auto kern = core_pair_counts_tiled<A>;
             if (lds > 64 * 1024)
                 HIPCHK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             const uint32_t n_tiles = (rows + W * 8 - 1) / (W * 8);
+            // every workgroup re-packs its site tiles, so use as few pair blocks as A allows and
+            // spread the pairs evenly over their threads
             const uint32_t pair_blocks = (uint32_t)((P + (uint64_t)PT * A - 1) / ((uint64_t)PT * A));
+            const uint32_t a_eff = (uint32_t)((P + (uint64_t)PT * pair_blocks - 1) / ((uint64_t)PT * pair_blocks));
             // enough site ranges to fill the chip a few times over
             uint32_t ranges = std::max(1u, std::min(n_tiles, (256u * 4u + pair_blocks - 1) / pair_blocks));
+            // the kernel counts a range in 16 bits: at most 2 * sites per range < 65536
+            const uint32_t max_tpr = std::max(1u, 32767u / (W * 8u));
+            ranges = std::max(ranges, (n_tiles + max_tpr - 1) / max_tpr);
             const uint32_t tpr = (n_tiles + ranges - 1) / ranges;
             ranges = (n_tiles + tpr - 1) / tpr;
             hipLaunchKernelGGL(kern, dim3(ranges, pair_blocks), dim3(PT), lds, st, p->state, N, p->pitch,
-                               rows, d_r1, d_r2, d_perm, P, d_a, W, tpr);
+                               rows, d_r1, d_r2, d_perm, P, d_a, W, tpr, a_eff);
         } else {
             const uint32_t slices = std::max(1u, std::min(rows, 64u));
             const uint32_t rps = (rows + slices - 1) / slices;

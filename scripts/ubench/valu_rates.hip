@@ -24,6 +24,12 @@ __global__ void __launch_bounds__(256) k(uint32_t *out, uint32_t seed)
             asm volatile("v_mad_u32_u16 %0, %1, %2, %3" : "=v"(b) : "v"(c), "v"(d), "v"(a));
             c += a; d += b;
         }
+        if (OP == 6) { a = __builtin_amdgcn_perm(a, b, 0x05010400u); b = __builtin_amdgcn_perm(c, d, 0x07030602u); c += a; d += b; }
+        if (OP == 7) { a = __builtin_amdgcn_perm(a, b, c); b = __builtin_amdgcn_perm(c, d, a); c += a; d += b; }
+        if (OP == 8) { a = (a << 4) | b; b = (c << 4) | d; c += a; d += b; }                     // v_lshl_or_b32
+        if (OP == 9) { a = __builtin_amdgcn_ubfe(a, 8, 4) + b; b = __builtin_amdgcn_ubfe(c, 16, 4) + d; c += a; d += b; }
+        if (OP == 10) { a = __builtin_popcount(a ^ b) + c; b = __builtin_popcount(c ^ d) + a; c += a; d += b; } // xor + bcnt
+        if (OP == 11) { a = (a & 0xFFFFu) + b; b = (c >> 16) + d; c += a; d += b; }
     }
     out[blockIdx.x * blockDim.x + threadIdx.x] = a ^ b ^ c ^ d;
 }
@@ -60,6 +66,12 @@ int main()
         run<3>("2x mul_lo + 2 xor + 2 add", 6, w);
         run<4>("2x mul_u32_u24 + 2xor + 2add", 6, w);
         run<5>("2x mad_u32_u16 + 2 add", 4, w);
+        run<6>("2x perm (const sel) + 2 add", 4, w);
+        run<7>("2x perm (vgpr sel) + 2 add", 4, w);
+        run<8>("2x lshl_or + 2 add", 4, w);
+        run<9>("2x bfe + 4 add", 6, w);
+        run<10>("2x xor + 2x bcnt + 2 add", 6, w);
+        run<11>("and/shr + 4 add", 6, w);
     }
     return 0;
 }
