@@ -179,7 +179,11 @@ struct ps_population {
     acc_dims d{};
     uint64_t *G[2] = { nullptr, nullptr };
     uint64_t *I[2] = { nullptr, nullptr };
-    uint16_t *glist = nullptr;           // rank/select tables of HGT donors, N x G
+    uint16_t *glist = nullptr;           // gene lists of HGT donors, N x G
+    uint8_t *sel_buf = nullptr;          // compact rank/select tables of HGT donors (acc_select_tabs)
+    void *hgt_scratch = nullptr;         // slice images of the LDS-partitioned HGT kernel
+    uint64_t hgt_scratch_cap = 0;
+    uint32_t hgt_slices = 0;             // tuning: event slices of the LDS-partitioned HGT kernel (0 = choose)
     uint32_t *cnt = nullptr;
     int cur = 0;
     ps_acc_plan aplan{};
@@ -195,7 +199,7 @@ struct ps_population {
     double *d_Dt = nullptr;          // all-pairs Jaccard distances (D-avg), N x N
     uint64_t H_cap = 0;
     int pair_mode = 0;               // 0 auto, 1 sampled kernel, 2 all-pairs kernel (tuning/tests)
-    int hgt_mode = 0;                // 0 auto, 1 global-atomic kernel, 2 LDS-partitioned kernel
+    int hgt_mode = 0;                // 0 auto, 1 global-atomic, 2 LDS-partitioned, 3 test-before-set, 4 rank/select tables, 5 binned
     void *d_pairs = nullptr;         // sorted r1 | r2 | perm | outA | outB
     uint64_t pairs_cap = 0, pairs_cached = 0;
     std::vector<uint32_t> h_r1, h_r2; // the caller's list the device copy was built from
@@ -221,7 +225,7 @@ extern "C" void ps_population_destroy(ps_population *p)
     if (!p) return;
     (void)hipSetDevice(p->device);
     if (p->stream) (void)hipStreamSynchronize(p->stream);
-    void *ptrs[] = { p->state, p->G[0], p->G[1], p->I[0], p->I[1], p->glist, p->cnt, p->d_idx, p->d_idxT, p->d_work,
+    void *ptrs[] = { p->state, p->G[0], p->G[1], p->I[0], p->I[1], p->glist, p->sel_buf, p->hgt_scratch, p->cnt, p->d_idx, p->d_idxT, p->d_work,
                      p->d_log1p, p->d_num_genes, p->d_logw, p->d_pairs, p->d_H, p->d_Dt };
     for (void *q : ptrs)
         if (q) (void)hipFree(q);
@@ -253,6 +257,7 @@ static int pop_create_impl(const ps_config *cfg, const uint8_t *init_vec, ps_pop
         if (v >= 1 && v <= 8) p->sweep_blocks_per_cu = (uint32_t)v;
     }
     if (const char *e = getenv("PANSIM_HGT_MODE")) p->hgt_mode = atoi(e);
+    if (const char *e = getenv("PANSIM_HGT_SLICES")) p->hgt_slices = (uint32_t)atoi(e);
     if (const char *e = getenv("PANSIM_SWEEP_ROWS")) {
         const int v = atoi(e);
         if (v >= 2 && v <= 4) p->sweep_rows = (uint32_t)v;
@@ -295,6 +300,10 @@ static int pop_create_impl(const ps_config *cfg, const uint8_t *init_vec, ps_pop
         if (C > 65536) return ps_fail(PS_ERR_INVALID, "at most 65536 accessory genes are supported");
         HIPCHK(hipMalloc(&p->glist, std::max<uint64_t>(N * C, 1) * sizeof(uint16_t)));
         HIPCHK(hipMalloc(&p->cnt, std::max<uint64_t>(N, 1) * PS_MAX_COMP * sizeof(uint32_t)));
+        {
+            const uint64_t GW8 = ((uint64_t)p->d.GW + 7) & ~7ull, NG8 = (GW8 / 8 + 7) & ~7ull;
+            HIPCHK(hipMalloc(&p->sel_buf, std::max<uint64_t>(N, 1) * (p->d.GW * 8ull + GW8 * 2 + NG8 * 2) + 64));
+        }
         HIPCHK(hipMalloc(&p->d_log1p, std::max<uint64_t>(C, 1) * sizeof(double)));
         HIPCHK(hipMalloc(&p->d_num_genes, std::max<uint64_t>(N, 1) * sizeof(int32_t)));
         HIPCHK(hipMalloc(&p->d_logw, std::max<uint64_t>(N, 1) * sizeof(double)));
@@ -356,7 +365,7 @@ extern "C" int ps_init_vector(uint64_t seed, int core, uint64_t col_offset, uint
 static int check_device_flag(ps_population *p)
 {
     if (p->h_flag && *p->h_flag != 0)
-        return ps_fail(PS_ERR_STATE, "core sweep queue overflowed (flag %u: 1 wave queue, 2 block queue, 4 HR list): results are invalid",
+        return ps_fail(PS_ERR_STATE, "a device queue overflowed (flag %u: 1 sweep wave queue, 2 sweep block queue, 4 HR list, 8 HGT bin): results are invalid",
                        *p->h_flag);
     return PS_OK;
 }
@@ -385,7 +394,7 @@ extern "C" int ps_set_tuning(ps_population *p, const char *key, int64_t value)
         if (value < 2 || value > 4) return ps_fail(PS_ERR_INVALID, "sweep_rows must be 2..4");
         p->sweep_rows = (uint32_t)value;
     } else if (k == "hgt_mode") {
-        if (value < 0 || value > 2) return ps_fail(PS_ERR_INVALID, "hgt_mode must be 0 (auto), 1 (global atomics) or 2 (LDS partitions)");
+        if (value < 0 || value > 5) return ps_fail(PS_ERR_INVALID, "hgt_mode must be 0 (auto), 1 (global atomics), 2 (LDS partitions), 3 (test before set), 4 (rank/select tables) or 5 (binned, two passes)");
         p->hgt_mode = (int)value;
     } else if (k == "pair_mode") {
         if (value < 0 || value > 2) return ps_fail(PS_ERR_INVALID, "pair_mode must be 0 (auto), 1 (sampled) or 2 (all pairs)");
@@ -394,6 +403,9 @@ extern "C" int ps_set_tuning(ps_population *p, const char *key, int64_t value)
         p->force_block_sweep = value != 0;
     } else if (k == "force_inline_sweep") {
         p->force_inline_sweep = value != 0;
+    } else if (k == "hgt_slices") {
+        if (value < 0 || value > 4096) return ps_fail(PS_ERR_INVALID, "hgt_slices must be 0..4096");
+        p->hgt_slices = (uint32_t)value;
     } else if (k == "no_block_preload") {
         p->no_block_preload = value != 0;
     } else if (k == "block_waves") {
@@ -719,9 +731,11 @@ static int launch_acc_hgt(ps_population *p, uint32_t gen, hipStream_t st)
         total += a.K[c];
     }
     if (total == 0) return PS_OK;
+    const bool use_select = p->hgt_mode == 4 && p->d.G <= 65535u;
     // the gene lists ARE the pre-recombination snapshot the donors are read from
-    acc_gene_lists_kernel<<<dim3(p->d.N, p->aplan.n_comp), 64, 0, st>>>(p->I[p->cur], p->glist, p->cnt,
-                                                                         p->d, p->aplan);
+    if (!use_select)
+        acc_gene_lists_kernel<<<dim3(p->d.N, p->aplan.n_comp), 64, 0, st>>>(p->I[p->cur], p->glist, p->cnt,
+                                                                             p->d, p->aplan);
     a.list = p->glist;
     a.cnt = p->cnt;
     a.dstI = p->I[p->cur];
@@ -735,14 +749,93 @@ static int launch_acc_hgt(ps_population *p, uint32_t gen, hipStream_t st)
     const uint64_t row_bytes = (uint64_t)p->d.GW * 8;
     const uint32_t part_cap = (uint32_t)(p->lds_limit / row_bytes);
     const uint32_t parts = part_cap ? (p->d.N + part_cap - 1) / part_cap : 0;
-    if (p->hgt_mode != 1 && parts >= 1 && parts <= 8 && (total >= 10000000 || p->hgt_mode == 2)) {
+    if (use_select) {
+        // heavy HGT: compact rank/select tables (stay in L2 beside the streaming sweep)
+        acc_hgt_select_args sa{};
+        const uint64_t N = p->d.N;
+        sa.t.GW8 = (p->d.GW + 7u) & ~7u;
+        sa.t.NG8 = (sa.t.GW8 / 8u + 7u) & ~7u;
+        sa.t.snap = (uint64_t *)p->sel_buf;
+        sa.t.cum = (uint16_t *)(p->sel_buf + N * p->d.GW * 8ull);
+        sa.t.top = sa.t.cum + N * sa.t.GW8;
+        sa.t.nb = p->cnt;
+        sa.dstI = p->I[p->cur];
+        sa.d = p->d;
+        sa.gen = gen;
+        sa.k0 = a.k0;
+        sa.k1 = a.k1;
+        for (int c = 0; c < PS_MAX_COMP; c++) sa.K[c] = a.K[c];
+        acc_rank_tables_kernel<<<p->d.N, 64, 0, st>>>(p->I[p->cur], sa.t, p->d, p->aplan);
+        for (int c = 0; c < p->aplan.n_comp; c++) {
+            if (a.K[c] == 0) continue;
+            const uint32_t blocks = (uint32_t)std::min<uint64_t>((a.K[c] + 511) / 512, 256 * 8);
+            acc_hgt_select_kernel<<<blocks, 256, 0, st>>>(sa, (uint32_t)c);
+        }
+    } else if ((p->hgt_mode == 5 || (p->hgt_mode == 0 && total >= 10000000)) && parts >= 1 && parts <= 8 && p->d.G <= 65536u) {
+        // heavy HGT, two passes: bin the effective events by recipient partition, then OR the bins
+        // into LDS images of the partitions and reduce the images into the matrix
         const uint32_t rows_per_part = (p->d.N + parts - 1) / parts;
         const uint32_t lds = (uint32_t)(rows_per_part * row_bytes);
-        const uint32_t n_slices = std::max(1u, 512u / parts);
+        const uint32_t n_slices = std::max(1u, p->hgt_slices ? p->hgt_slices : 256u / parts);
+        const uint32_t bin_blocks = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(1024, (total + 16383) / 16384));
+        const uint64_t per_block = (total + bin_blocks - 1) / bin_blocks;
+        const double mean = (double)per_block / parts * ((double)rows_per_part * parts / p->d.N);
+        const uint32_t cap = (uint32_t)(((uint64_t)(mean + 10.0 * std::sqrt(mean) + 64.0) + 63) & ~63ull);
+        const uint64_t words = (uint64_t)p->d.N * p->d.GW;
+        const uint64_t img_bytes = (uint64_t)n_slices * words * 8;
+        const uint64_t bin_bytes = (uint64_t)bin_blocks * parts * cap * 4;
+        const uint64_t cnt_bytes = ((uint64_t)bin_blocks * parts * 4 + 255) & ~255ull;
+        const uint64_t need = img_bytes + bin_bytes + cnt_bytes;
+        if (p->hgt_scratch_cap < need) {
+            if (p->hgt_scratch) HIPCHK(hipFree(p->hgt_scratch));
+            p->hgt_scratch = nullptr;
+            p->hgt_scratch_cap = 0;
+            HIPCHK(hipMalloc(&p->hgt_scratch, need));
+            p->hgt_scratch_cap = need;
+        }
+        acc_hgt_bin_args b{};
+        a.scratch = (uint32_t *)p->hgt_scratch;
+        b.h = a;
+        b.bins = (uint32_t *)((uint8_t *)p->hgt_scratch + img_bytes);
+        b.counts = (uint32_t *)((uint8_t *)p->hgt_scratch + img_bytes + bin_bytes);
+        b.parts = parts;
+        b.rows_per_part = rows_per_part;
+        b.cap = cap;
+        b.per_block = per_block;
+        b.overflow_flag = p->d_flag;
+        acc_hgt_bin_kernel<<<bin_blocks, 256, 0, st>>>(b);
+        auto kern = acc_hgt_apply_kernel;
+        if (lds > 64 * 1024)
+            HIPCHK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(kern, dim3(parts * n_slices), dim3(1024), lds, st, b, bin_blocks, n_slices);
+        acc_hgt_reduce_kernel<<<(uint32_t)((words + 255) / 256), 256, 0, st>>>((const uint64_t *)p->hgt_scratch,
+                                                                              p->I[p->cur], words, n_slices);
+    } else if ((p->hgt_mode == 2 || (p->hgt_mode == 0 && total >= 10000000)) && parts >= 1 && parts <= 8) {
+        const uint32_t rows_per_part = (p->d.N + parts - 1) / parts;
+        const uint32_t lds = (uint32_t)(rows_per_part * row_bytes);
+        const uint32_t n_slices = std::max(1u, p->hgt_slices ? p->hgt_slices : 512u / parts);
         auto kern = acc_hgt_lds_kernel;
         if (lds > 64 * 1024)
             HIPCHK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        const uint64_t words = (uint64_t)p->d.N * p->d.GW;
+        const uint64_t need = (uint64_t)n_slices * words * 8;
+        if (p->hgt_scratch_cap < need) {
+            if (p->hgt_scratch) HIPCHK(hipFree(p->hgt_scratch));
+            p->hgt_scratch = nullptr;
+            p->hgt_scratch_cap = 0;
+            HIPCHK(hipMalloc(&p->hgt_scratch, need));
+            p->hgt_scratch_cap = need;
+        }
+        a.scratch = (uint32_t *)p->hgt_scratch;
         hipLaunchKernelGGL(kern, dim3(parts * n_slices), dim3(1024), lds, st, a, rows_per_part, n_slices);
+        acc_hgt_reduce_kernel<<<(uint32_t)((words + 255) / 256), 256, 0, st>>>((const uint64_t *)p->hgt_scratch,
+                                                                              p->I[p->cur], words, n_slices);
+    } else if (p->hgt_mode == 3 || (p->hgt_mode == 0 && total >= 10000000)) {
+        for (int c = 0; c < p->aplan.n_comp; c++) {
+            if (a.K[c] == 0) continue;
+            const uint32_t blocks = (uint32_t)std::min<uint64_t>((a.K[c] + 1023) / 1024, 256 * 8);
+            acc_hgt_tbs_kernel<<<blocks, 256, 0, st>>>(a, (uint32_t)c);
+        }
     } else {
         for (int c = 0; c < p->aplan.n_comp; c++) {
             if (a.K[c] == 0) continue;
@@ -1502,6 +1595,8 @@ struct ps_sim {
     uint32_t *h_idx[PS_RING] = {};         // pinned, host-mapped
     uint32_t *m_idx[PS_RING] = {};         // device alias of h_idx
     hipEvent_t ev_idx[PS_RING] = {}, ev_core[PS_RING] = {};
+    hipEvent_t ev_hgt = nullptr;
+    bool heavy_hgt = false;             // expected HGT events per generation >= 1e7: HGT and sweep take turns
     bool slot_used[PS_RING] = {};
     int32_t *h_num_genes = nullptr, *m_num_genes = nullptr;   // pinned + its device alias
     double *h_logw = nullptr, *m_logw = nullptr, *h_avg = nullptr;
@@ -1525,6 +1620,7 @@ extern "C" void ps_sim_destroy(ps_sim *s)
         if (s->h_idx[k]) (void)hipHostFree(s->h_idx[k]);
         if (s->ev_idx[k]) (void)hipEventDestroy(s->ev_idx[k]);
         if (s->ev_core[k]) (void)hipEventDestroy(s->ev_core[k]);
+        if (k == 0 && s->ev_hgt) (void)hipEventDestroy(s->ev_hgt);
     }
     if (s->h_num_genes) (void)hipHostFree(s->h_num_genes);
     if (s->h_logw) (void)hipHostFree(s->h_logw);
@@ -1597,6 +1693,9 @@ static int sim_create_impl(const ps_sim_params *p, ps_sim *s)
         HIPCHK(hipEventCreateWithFlags(&s->ev_idx[k], hipEventDisableTiming));
         HIPCHK(hipEventCreateWithFlags(&s->ev_core[k], hipEventDisableTiming));
     }
+    HIPCHK(hipEventCreateWithFlags(&s->ev_hgt, hipEventDisableTiming));
+    s->heavy_hgt = (double)N * s->der.n_recombinations_pan_total >= 1.0e7;
+    if (const char *e = getenv("PANSIM_HEAVY_HGT")) s->heavy_hgt = atoi(e) != 0;
     HIPCHK(hipHostMalloc(&s->h_num_genes, N * sizeof(int32_t), hipHostMallocMapped));
     HIPCHK(hipHostMalloc(&s->h_logw, N * sizeof(double), hipHostMallocMapped));
     HIPCHK(hipHostGetDevicePointer((void **)&s->m_num_genes, s->h_num_genes, 0));
@@ -1664,6 +1763,18 @@ static int sim_one_generation(ps_sim *s, uint32_t gen)
     if (G == 0) HIPCHK(hipMemcpyAsync(s->d_idx[slot], s->h_idx[slot], N * sizeof(uint32_t), hipMemcpyHostToDevice, sa));
     PSCHK(launch_acc_step(acc, s->m_idx[slot], gen, true, true, sa, s->d_idx[slot]));
     HIPCHK(hipEventRecord(s->ev_idx[slot], sa));
+    // Heavy HGT (cfg3-like rates, >= 1e7 expected events): its scattered loads and the streaming
+    // sweep slow each other down far more than their sum, so they take turns on the chip:
+    // HGT(g) runs after sweep(g-1) has finished and before sweep(g) starts, and the host half of
+    // generation g+1 hides behind sweep(g).
+    const bool heavy_hgt = p.HGT_rate > 0.0 && s->heavy_hgt;
+    if (heavy_hgt) {
+        const int prev = (slot + PS_RING - 1) % PS_RING;
+        if (s->slot_used[prev]) HIPCHK(hipStreamWaitEvent(sa, s->ev_core[prev], 0));
+        PSCHK(launch_acc_hgt(acc, gen, sa));
+        HIPCHK(hipEventRecord(s->ev_hgt, sa));
+        HIPCHK(hipStreamWaitEvent(sc, s->ev_hgt, 0));
+    }
 
     // main.rs:445, :452, :459-461 on the core stream, one fused pass
     HIPCHK(hipStreamWaitEvent(sc, s->ev_idx[slot], 0));
@@ -1685,7 +1796,7 @@ static int sim_one_generation(ps_sim *s, uint32_t gen)
     }
     HIPCHK(hipEventRecord(s->ev_core[slot], sc));
     // HGT is enqueued after the sweep so that the sweep's launch is not queued behind it
-    if (p.HGT_rate > 0.0) PSCHK(launch_acc_hgt(acc, gen, sa));
+    if (p.HGT_rate > 0.0 && !heavy_hgt) PSCHK(launch_acc_hgt(acc, gen, sa));
     s->slot_used[slot] = true;
     s->step_count++;
     return PS_OK;
@@ -1705,6 +1816,7 @@ extern "C" int ps_sim_sync(ps_sim *s)
     PSCHK(use_device(s->core));
     HIPCHK(hipStreamSynchronize(s->acc->stream));
     HIPCHK(hipStreamSynchronize(s->core->stream));
+    PSCHK(check_device_flag(s->acc));
     return check_device_flag(s->core);
 }
 

@@ -178,6 +178,7 @@ ACC_CASES = [
     (130, 200, [(0, 200)], [20.0], [500.0]),
     (70, 129, [(0, 64), (64, 129)], [0.0, 10.0], [5.0, 0.0]),
     (50, 300, [(0, 100), (100, 300)], [1.0, 1.0], [2000.0, 2000.0]),
+    (60, 9000, [(0, 8100), (8100, 9000)], [10.0, 10.0], [300.0, 50.0]),   # 141 row words: 3 chunks of group entries
 ]
 
 
@@ -200,7 +201,7 @@ def test_acc_operators_match_oracle(pa, orc, N, G, comps, lm, lr):
     orc.recombine_acc(want2, seed, gen, cb, ce, lr)
     got2 = pop.read_matrix()
     assert np.array_equal(got2, want2)
-    for mode in (1, 2):               # global-atomic and LDS-partitioned HGT kernels agree
+    for mode in (1, 2, 3, 4, 5):      # every HGT kernel variant applies the same keyed events
         alt = pa.Population(N, G, 2, False, 0.25, seed, 10)
         alt.set_tuning("hgt_mode", mode)
         alt.set_rates(lm, lr, cb, ce)
@@ -592,7 +593,7 @@ def test_random_operator_sequences(pa, orc, trial):
     if rng.random() < 0.3:
         core.set_tuning("force_block_sweep", 1)
     if rng.random() < 0.3:
-        acc.set_tuning("hgt_mode", int(rng.integers(0, 3)))
+        acc.set_tuning("hgt_mode", int(rng.integers(0, 6)))
     plan = orc.core_plan(lm, lh, LG)
     mc = _rand_core(rng, N, L)
     ma = _rand_acc(rng, N, G, 0.3)
