@@ -1694,7 +1694,14 @@ static int sim_create_impl(const ps_sim_params *p, ps_sim *s)
         HIPCHK(hipEventCreateWithFlags(&s->ev_core[k], hipEventDisableTiming));
     }
     HIPCHK(hipEventCreateWithFlags(&s->ev_hgt, hipEventDisableTiming));
-    s->heavy_hgt = (double)N * s->der.n_recombinations_pan_total >= 1.0e7;
+    {
+        // take turns only where the binned kernel applies (small populations: the recipients fit 8 LDS
+        // partitions); at cfg4 sizes HGT streams from HBM anyway and co-running was 5 % faster
+        const uint64_t row_bytes = (uint64_t)s->acc->d.GW * 8;
+        const uint64_t part_cap = row_bytes ? s->acc->lds_limit / row_bytes : 0;
+        const uint64_t parts = part_cap ? (N + part_cap - 1) / part_cap : 0;
+        s->heavy_hgt = (double)N * s->der.n_recombinations_pan_total >= 1.0e7 && parts >= 1 && parts <= 8;
+    }
     if (const char *e = getenv("PANSIM_HEAVY_HGT")) s->heavy_hgt = atoi(e) != 0;
     HIPCHK(hipHostMalloc(&s->h_num_genes, N * sizeof(int32_t), hipHostMallocMapped));
     HIPCHK(hipHostMalloc(&s->h_logw, N * sizeof(double), hipHostMallocMapped));
