@@ -1693,6 +1693,12 @@ static int sim_create_impl(const ps_sim_params *p, ps_sim *s)
         HIPCHK(hipEventCreateWithFlags(&s->ev_idx[k], hipEventDisableTiming));
         HIPCHK(hipEventCreateWithFlags(&s->ev_core[k], hipEventDisableTiming));
     }
+    // the pair list is fixed for the whole run (main.rs:413-427): sort and upload it now, so that
+    // the distance phase starts with the device copy in place
+    if (p->max_distances > 0) {
+        PSCHK(upload_pairs(s->core, p->max_distances, s->r1.data(), s->r2.data()));
+        PSCHK(upload_pairs(s->acc, p->max_distances, s->r1.data(), s->r2.data()));
+    }
     HIPCHK(hipEventCreateWithFlags(&s->ev_hgt, hipEventDisableTiming));
     {
         // take turns only where the binned kernel applies (small populations: the recipients fit 8 LDS
