@@ -691,3 +691,32 @@ def test_zero_accessory_genes(pa, orc):
     assert np.array_equal(acc_d, orc.pairwise_distances(ref.acc, False, 100, sim.range1, sim.range2))
     assert (acc_d == 0.0).all()
     sim.close()
+
+
+# ----------------------------------------------------------------------------- long runs
+@pytest.mark.parametrize("kw,extra,gens", [
+    (dict(pop_size=300, core_size=4000, pan_genes=1200, core_genes=300), dict(), 150),
+    (dict(pop_size=200, core_size=2500, pan_genes=900, core_genes=250, HR_rate=0.4, HGT_rate=0.4),
+     dict(prop_positive=0.2, competition_strength=20.0), 60),
+    (dict(pop_size=1100, core_size=600, pan_genes=500, core_genes=100), dict(genome_size_penalty=0.9), 40),
+])
+@pytest.mark.parametrize("env", [{}, {"PANSIM_HEAVY_HGT": "1", "PANSIM_HGT_MODE": "5"}])
+def test_long_run_stays_bit_exact(pa, orc, monkeypatch, kw, extra, gens, env):
+    # many generations without host synchronisation in between (slot ring, event ordering, the
+    # counter sets of the sweep, the heavy-HGT turn-taking): every parent draw must still match
+    from orc_sim import OracleSim
+    for k, v in env.items():       # force the cfg3 schedule (HGT and sweep take turns) and the binned HGT kernels
+        monkeypatch.setenv(k, v)
+    sim = pa.Simulation(pa.make_params(seed=77, n_gen=gens, max_distances=500, **kw, **extra))
+    ref = OracleSim(seed=77, **kw, **extra)
+    done = 0
+    for chunk in (gens // 3, gens - gens // 3):
+        sim.run(chunk)
+        sim.sync()
+        for g in range(done, done + chunk):
+            ref.generation(g)
+        done += chunk
+        assert np.array_equal(sim.last_parents(), ref.last_idx)
+        assert np.array_equal(sim.pan_genome.read_matrix(), ref.acc)
+        assert np.array_equal(sim.core_genome.read_matrix(), ref.core)
+    sim.close()
