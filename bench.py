@@ -46,8 +46,21 @@ def host_cores():
     return max(1, n)
 
 
-def cpu_baseline(kw, seed, budget_s=20.0):
-    """Reference algorithm (event-driven, rows in parallel like rayon) timed on the host cores."""
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(kw, seed, pairs, budget_s=20.0):
+    """Reference algorithm (event-driven, rows in parallel like rayon) timed on the host cores:
+    all cores (the figure `value` reports), one thread (the reference's --threads default), and the
+    sampled-pair distance phase on a bounded number of pairs."""
+    import numpy as np
     from oracle import oracle as o
     threads = host_cores()
     sim = o.RefSim(o.make_params(**kw), seed=seed, threads=threads)
@@ -59,11 +72,30 @@ def cpu_baseline(kw, seed, budget_s=20.0):
     for g in range(n):
         sim.generation(1 + g)
     dt = time.perf_counter() - t0
+    # distance phase of the reference (2 rows streamed per pair), all cores, bounded sample
+    r1, r2 = pairs
+    n_pairs = min(len(r1), 20000)
+    t0 = time.perf_counter()
+    sim.pairwise(True, r1[:n_pairs], r2[:n_pairs])
+    sim.pairwise(False, r1[:n_pairs], r2[:n_pairs])
+    dist_dt = time.perf_counter() - t0
     sim.close()
+    # --threads 1 is the reference's default (main.rs:127-131): one generation, state already warm
+    sim1 = o.RefSim(o.make_params(**kw), seed=seed, threads=1)
+    t0 = time.perf_counter()
+    sim1.generation(0)
+    dt1 = time.perf_counter() - t0
+    sim1.close()
     return {"value": n / dt, "unit": "generations/s", "cores": threads, "kind": "port",
+            "cpu_model": cpu_model(),
             "sample": "%d generations of pop=%d core=%d pan=%d after 1 warm-up generation; "
                       "event-driven reference algorithm (oracle/pansim_oracle.c orc_ref_*), %d threads"
-                      % (n, kw["pop_size"], kw["core_size"], kw["pan_genes"], threads)}
+                      % (n, kw["pop_size"], kw["core_size"], kw["pan_genes"], threads),
+            "threads1": {"value": 1.0 / dt1, "unit": "generations/s", "cores": 1,
+                         "sample": "1 generation (the first, no warm-up) with one thread, the reference's --threads default"},
+            "distances": {"value": n_pairs / dist_dt / 1e6, "unit": "Mpairs/s", "cores": threads,
+                          "sample": "%d of the run's sampled pairs, core Hamming + accessory Jaccard, 2 rows streamed per pair"
+                                    % n_pairs}}
 
 
 def main():
@@ -179,7 +211,7 @@ def main():
                          "algorithmic_bytes_per_launch": bytes_per_launch},
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(kw, seed)
+            out["cpu_baseline"] = cpu_baseline(kw, seed, (sim.range1, sim.range2))
         print(json.dumps(out), flush=True)
     sim.close()
     if world > 1:
