@@ -205,6 +205,10 @@ def main():
                        "parallelism": "site-shard x%d" % world},
             "mpairs_per_s": P / dist_dt / 1e6,
             "distance_ms": 1e3 * dist_dt,
+            # regime (ii), pairs compared from LDS tiles (HBM traffic ~ N*L per 32768 pairs,
+            # integer-VALU bound); secondary figure pair-sites/s over the whole distance phase
+            "distance_regime": "ii (LDS-tiled with reuse)",
+            "pair_sites_per_s": P * float(kw["core_size"]) / dist_dt,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": "core_sweep_wave_kernel<gather,mutate,HR>", "avg_launch_ms": avg_ms,
