@@ -150,7 +150,7 @@ int ps_sync(ps_population *p);
  * "force_block_sweep" (0/1: use the block sweep even when a row fits one wavefront),
  * "force_inline_sweep" (0/1: use the queue-free inline block sweep), "pair_mode" (core
  * distances: 0 = choose by cost, 1 = sampled-pair kernel, 2 = all-pairs tiles + lookup),
- * "hgt_mode" (accessory recombination: 0 = choose, 1 = global atomics, 2 = LDS partitions, 3 = global atomics with test before set, 4 = compact rank/select tables, 5 = two passes: bin by recipient partition, OR in LDS), "lds_limit" (bytes of LDS a workgroup may use), "block_waves" (block sweep: waves per workgroup, 0 = choose), "no_block_preload" (block sweep: parent indices re-read per batch). */
+ * "hgt_mode" (accessory recombination: 0 = choose, 1 = global atomics, 2 = LDS partitions, 3 = global atomics with test before set, 4 = compact rank/select tables, 5 = two passes: bin by recipient partition, OR in LDS), "lds_limit" (bytes of LDS a workgroup may use), "block_waves" (block sweep: waves per workgroup, 0 = choose), "block_batch" (block sweep: segments per wave batch, 0 = choose, 2 or 4), "hgt_slices" (heavy HGT: event slices, 0 = choose), "no_block_preload" (block sweep: parent indices re-read per batch). */
 int ps_set_tuning(ps_population *p, const char *key, int64_t value);
 
 /* ------------------------------------------------------------------------ */

@@ -210,6 +210,7 @@ struct ps_population {
     bool force_inline_sweep = false;    // tests: run the inline (queue-free) block sweep
     uint32_t block_waves = 0;           // block sweep: waves per workgroup (0 = auto: 4, 8 or 16)
     bool no_block_preload = false;      // tests: block sweep reads its parent indices per batch
+    uint32_t block_batch = 0;           // block sweep: segments per wave batch (0 = 4, falling back to 2; 2 = force 2)
     uint32_t *h_flag = nullptr, *d_flag = nullptr;   // host-mapped sticky device error word
     unsigned long long *h_stamps = nullptr, *d_stamps = nullptr;   // diagnostic phase stamps
 };
@@ -257,6 +258,8 @@ static int pop_create_impl(const ps_config *cfg, const uint8_t *init_vec, ps_pop
         if (v >= 1 && v <= 8) p->sweep_blocks_per_cu = (uint32_t)v;
     }
     if (const char *e = getenv("PANSIM_HGT_MODE")) p->hgt_mode = atoi(e);
+    if (const char *e = getenv("PANSIM_BLOCK_BATCH")) p->block_batch = (uint32_t)atoi(e);
+    if (const char *e = getenv("PANSIM_BLOCK_WAVES")) p->block_waves = (uint32_t)atoi(e);
     if (const char *e = getenv("PANSIM_HGT_SLICES")) p->hgt_slices = (uint32_t)atoi(e);
     if (const char *e = getenv("PANSIM_SWEEP_ROWS")) {
         const int v = atoi(e);
@@ -406,6 +409,9 @@ extern "C" int ps_set_tuning(ps_population *p, const char *key, int64_t value)
     } else if (k == "hgt_slices") {
         if (value < 0 || value > 4096) return ps_fail(PS_ERR_INVALID, "hgt_slices must be 0..4096");
         p->hgt_slices = (uint32_t)value;
+    } else if (k == "block_batch") {
+        if (value != 0 && value != 2 && value != 4) return ps_fail(PS_ERR_INVALID, "block_batch must be 0 (choose), 2 or 4");
+        p->block_batch = (uint32_t)value;
     } else if (k == "no_block_preload") {
         p->no_block_preload = value != 0;
     } else if (k == "block_waves") {
@@ -575,7 +581,7 @@ static bool block_sweep_geometry(const ps_population *p, bool ga, bool mu, bool 
     // a wave works on batches of SB segments (4, or 2 when the queues of 4 do not fit beside the
     // rows); the workgroup is as small as a row allows (4, 8 or 16 waves), so that several
     // workgroups per CU overlap their load / compute / store phases
-    for (uint32_t SB = 4; SB >= 2; SB >>= 1) {
+    for (uint32_t SB = (p->block_batch == 2 ? 2u : 4u); SB >= 2; SB >>= 1) {
         uint32_t nw = 4;
         while (nw < 16u && nw * SB < g->segs) nw *= 2u;
         if (p->block_waves) nw = p->block_waves;

@@ -467,7 +467,8 @@ def test_block_sweep_equals_wave_sweep(pa, orc, N, L, lm, lh):
                                       (3000, 50, {"lds_limit": 12000}), (9000, 30, {"lds_limit": 40000}),
                                       (2500, 64, {"block_waves": 16, "lds_limit": 30000}),
                                       (5000, 40, {"no_block_preload": 1}), (9000, 30, {"no_block_preload": 1, "block_waves": 16}),
-                                      (3000, 50, {"block_waves": 4, "lds_limit": 9000})])
+                                      (3000, 50, {"block_waves": 4, "lds_limit": 9000}),
+                                      (5000, 40, {"block_batch": 2}), (9000, 30, {"block_batch": 2, "block_waves": 8})])
 def test_block_sweep_geometries(pa, orc, N, L, tune):
     # workgroup size, rows per iteration and the 4- or 2-segment batches are host choices that
     # must not change the result
