@@ -110,6 +110,9 @@ def main():
     ap.add_argument("--HGT_rate", type=float, default=0.05)
     ap.add_argument("--max_distances", type=int, default=100000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
+                    help="weak (default, the driver's contract): --core_size sites PER GPU; strong: --core_size is the "
+                         "whole genome, split by site over the ranks (BASELINE configs[3]: --pop_size 65536 --scaling strong)")
     args = ap.parse_args()
 
     import torch
@@ -144,7 +147,8 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    kw = dict(pop_size=args.pop_size, core_size=args.core_size * world, pan_genes=args.pan_genes,
+    strong = args.scaling == "strong"
+    kw = dict(pop_size=args.pop_size, core_size=args.core_size * (1 if strong else world), pan_genes=args.pan_genes,
               HR_rate=args.HR_rate, HGT_rate=args.HGT_rate)
     seed = 0
     sim = pa.Simulation(pa.make_params(seed=seed, n_gen=args.steps + args.warmup,
@@ -190,17 +194,19 @@ def main():
     if rank == 0:
         avg_ms = sweep_ms / max(launches, 1)
         achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if launches else 0.0
-        default_wl = (args.pop_size, args.core_size, args.pan_genes, args.HR_rate, args.HGT_rate) == (1000, 1200000, 6000, 0.05, 0.05)
+        default_wl = (args.pop_size, args.core_size, args.pan_genes, args.HR_rate, args.HGT_rate, strong) == (1000, 1200000, 6000, 0.05, 0.05, False)
         traffic, traffic_src = pmc_traffic() if default_wl else (None, None)
         out = {
-            "metric": "generations/sec", "value": world * args.steps / dt,
-            "unit": "generations/s (pop=%d, %d core sites per GPU, pan=%d)" % (args.pop_size, args.core_size, args.pan_genes),
+            "metric": "generations/sec", "value": (1 if strong else world) * args.steps / dt,
+            "unit": ("generations/s (pop=%d, %d core sites in all, pan=%d)" if strong else
+                     "generations/s (pop=%d, %d core sites per GPU, pan=%d)") % (args.pop_size, args.core_size, args.pan_genes),
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": args.scaling,
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-            "config": {"workload": "BASELINE configs[1]: --pop_size %d --core_size %d --pan_genes %d, seed 0, "
+            "config": {"workload": ("BASELINE configs[1]: " if default_wl else "BASELINE configs[3]: " if args.pop_size == 65536
+                                    else "") + "--pop_size %d --core_size %d --pan_genes %d, seed 0, "
                                    "HR_rate %g HGT_rate %g; core sites sharded %d-way"
-                                   % (args.pop_size, args.core_size * world, args.pan_genes, args.HR_rate,
+                                   % (args.pop_size, kw["core_size"], args.pan_genes, args.HR_rate,
                                       args.HGT_rate, world),
                        "parallelism": "site-shard x%d" % world},
             "mpairs_per_s": P / dist_dt / 1e6,
@@ -211,7 +217,8 @@ def main():
             "pair_sites_per_s": P * float(kw["core_size"]) / dist_dt,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                         "kernel": "core_sweep_wave_kernel<gather,mutate,HR>", "avg_launch_ms": avg_ms,
+                         "kernel": ("core_sweep_wave_kernel<gather,mutate,HR>" if args.pop_size <= 1024 else
+                                    "core_sweep_block_kernel<gather,mutate,HR>"), "avg_launch_ms": avg_ms,
                          "algorithmic_bytes_per_launch": bytes_per_launch},
         }
         if world == 1 and not args.no_cpu_baseline:
