@@ -184,6 +184,7 @@ struct ps_population {
     void *hgt_scratch = nullptr;         // slice images of the LDS-partitioned HGT kernel
     uint64_t hgt_scratch_cap = 0;
     uint32_t hgt_slices = 0;             // tuning: event slices of the LDS-partitioned HGT kernel (0 = choose)
+    uint32_t hgt_events_per_thread = 0;  // light HGT kernel: 0 = whole chip, else narrow launch (set by ps_sim)
     uint32_t *cnt = nullptr;
     int cur = 0;
     ps_acc_plan aplan{};
@@ -845,8 +846,19 @@ static int launch_acc_hgt(ps_population *p, uint32_t gen, hipStream_t st)
     } else {
         for (int c = 0; c < p->aplan.n_comp; c++) {
             if (a.K[c] == 0) continue;
-            const uint32_t blocks = (uint32_t)std::min<uint64_t>((a.K[c] + 255) / 256, 256 * 16);
-            acc_hgt_kernel<<<blocks, 256, 0, st>>>(a, (uint32_t)c);
+            // beside a long core sweep (ps_sim sets hgt_events_per_thread) the kernel is launched
+            // narrow -- one-wave workgroups, ~64 events per thread: the same events then disturb the
+            // sweep for longer but far less (cfg2: sweep 0.571 -> 0.550 ms, +4.6 % generations/s);
+            // stand-alone calls use the whole chip
+            uint32_t thr = 256, blocks = (uint32_t)std::min<uint64_t>((a.K[c] + 255) / 256, 256 * 16);
+            if (p->hgt_events_per_thread) {
+                thr = 64;
+                // the same width for every compartment, sized on the generation's total: the launches
+                // run one after the other, so their durations add up to total / width events per thread
+                const uint64_t want = (total + (uint64_t)p->hgt_events_per_thread * 64 - 1) / ((uint64_t)p->hgt_events_per_thread * 64);
+                blocks = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(std::min<uint64_t>(want, (a.K[c] + 63) / 64), 1), 256 * 64);
+            }
+            acc_hgt_kernel<<<blocks, thr, 0, st>>>(a, (uint32_t)c);
         }
     }
     // rebuild the gene-major view from the individual-major one (one ballot per gene word)
@@ -1704,6 +1716,17 @@ static int sim_create_impl(const ps_sim_params *p, ps_sim *s)
     if (p->max_distances > 0) {
         PSCHK(upload_pairs(s->core, p->max_distances, s->r1.data(), s->r2.data()));
         PSCHK(upload_pairs(s->acc, p->max_distances, s->r1.data(), s->r2.data()));
+    }
+    // light HGT co-runs with the sweep: launch it narrow when the sweep is long enough to hide it.
+    // The chain of a generation is ~0.3 ms of latency-bound work plus ~2 us per event a thread handles
+    // in sequence; it is given half of what the sweep (estimated at 4.2 TB/s) leaves.  A short sweep
+    // leaves the accessory chain critical, which wants the whole chip (0).  An adaptive controller
+    // (widen when the core stream is found idle) was tried and lost to its own overshoots.
+    {
+        const double sweep_ms = 2.0 * (double)N * (double)s->core->cfg.ncols / 4.2e12 * 1e3;
+        const double ept = (sweep_ms - 0.3) / 2.0e-3 * 0.5;
+        s->acc->hgt_events_per_thread = ept >= 16.0 ? (uint32_t)std::min(ept, 96.0) : 0u;
+        if (const char *e = getenv("PANSIM_HGT_EVENTS_PER_THREAD")) s->acc->hgt_events_per_thread = (uint32_t)atoi(e);
     }
     HIPCHK(hipEventCreateWithFlags(&s->ev_hgt, hipEventDisableTiming));
     {
