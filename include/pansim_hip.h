@@ -150,7 +150,11 @@ int ps_sync(ps_population *p);
  * "force_block_sweep" (0/1: use the block sweep even when a row fits one wavefront),
  * "force_inline_sweep" (0/1: use the queue-free inline block sweep), "pair_mode" (core
  * distances: 0 = choose by cost, 1 = sampled-pair kernel, 2 = all-pairs tiles + lookup),
- * "hgt_mode" (accessory recombination: 0 = choose, 1 = global atomics, 2 = LDS partitions, 3 = global atomics with test before set, 4 = compact rank/select tables, 5 = two passes: bin by recipient partition, OR in LDS), "lds_limit" (bytes of LDS a workgroup may use), "block_waves" (block sweep: waves per workgroup, 0 = choose), "block_batch" (block sweep: segments per wave batch, 0 = choose, 2 or 4), "hgt_slices" (heavy HGT: event slices, 0 = choose), "no_block_preload" (block sweep: parent indices re-read per batch). */
+ * "hgt_mode" (accessory recombination: 0 = choose, 1 = one atomic per event, 2 = two passes: bin
+ * by recipient partition, OR in LDS images), "hgt_slices" (binned HGT: event slices, 0 = choose),
+ * "lds_limit" (bytes of LDS a workgroup may use), "block_waves" (block sweep: waves per
+ * workgroup, 0 = choose), "block_batch" (block sweep: segments per wave batch, 0 = choose, 2 or 4),
+ * "no_block_preload" (block sweep: parent indices re-read per batch). */
 int ps_set_tuning(ps_population *p, const char *key, int64_t value);
 
 /* ------------------------------------------------------------------------ */
@@ -166,6 +170,11 @@ int ps_standard_deviation(const double *values, uint64_t n, double *std_out, dou
 char ps_int_to_base(uint8_t n);
 /* Rust `{}` Display of f64 as used by every writer (main.rs:328, :481, :496, :546) */
 int ps_fmt_f64(double v, char *buf, size_t cap);
+/* The Poisson sampler behind the per-donor HGT event counts (population.rs:562, :599 use statrs'
+ * Poisson; only the distribution is contractual): thr[j] = floor(P(K <= kmin + j) * 2^32) over
+ * lambda +- (12 sigma + 12); a 32-bit uniform u gives kmin + #{j : thr[j] <= u}.  Returns the
+ * table length, 0 if lambda <= 0 or cap is too small. */
+uint32_t ps_poisson_table(double lambda, uint32_t *kmin_out, uint32_t *thr, uint32_t cap);
 
 /* ------------------------------------------------------------------------ */
 /* main() as a library: parameter derivation and the generation loop         */

@@ -87,6 +87,8 @@ def lib():
         "orc_recombine_core": (None, [_u8p, u64, u64, u64, u64, u32, C.POINTER(CorePlan)]),
         "orc_mutate_acc": (None, [_u8p, u64, u64, u64, u32, ci, _u64p, _u64p, _f64p]),
         "orc_recombine_acc": (u64, [_u8p, u64, u64, u64, u32, ci, _u64p, _u64p, _f64p]),
+        "orc_poisson_table": (u32, [f64, _u32p, _u32p, u32]),
+        "orc_poisson_from_table": (u32, [u32, u32, _u32p, u32]),
         "orc_fmt_f64": (ci, [f64, C.c_char_p, C.c_size_t]),
         "orc_write_matrix": (ci, [_u8p, u64, u64, ci, u64, C.c_char_p]),
         "orc_ref_create": (C.c_void_p, [C.POINTER(Params), u64, ci]),
@@ -279,6 +281,19 @@ def mutate_acc(pop, seed, gen, comp_begin, comp_end, lambdas):
     b, e, l = _comps(comp_begin, comp_end, lambdas)
     lib().orc_mutate_acc(pop, pop.shape[0], pop.shape[1], int(seed), int(gen), len(l), b, e, l)
     return pop
+
+
+def poisson_table(lam):
+    """(kmin, thresholds) of the integer Poisson inversion table of HGT event counts."""
+    cap = int(24.0 * np.sqrt(lam) + 64.0)
+    thr = np.zeros(cap, np.uint32)
+    kmin = np.zeros(1, np.uint32)
+    n = lib().orc_poisson_table(float(lam), kmin, thr, cap)
+    return int(kmin[0]), thr[:n].copy()
+
+
+def poisson_from_table(u, kmin, thr):
+    return int(lib().orc_poisson_from_table(int(u), int(kmin), np.ascontiguousarray(thr, np.uint32), len(thr)))
 
 
 def recombine_acc(pop, seed, gen, comp_begin, comp_end, lambdas):

@@ -288,11 +288,52 @@ void orc_mutate_acc(uint8_t *pop, uint64_t N, uint64_t G, uint64_t seed, uint32_
     free(thr);
 }
 
-/* population.rs:544-751 accessory path.  Per compartment the reference draws
- * Poisson(lam) events per donor; the superposition is Poisson(N*lam) events
- * with a uniform donor each.  Recipient uniform over the others (:584, :616-619),
- * locus uniform among the donor's present genes of the compartment in the
- * pre-recombination snapshot (:636-680), value always 1 (:632). */
+/* Poisson(lambda) by inversion over an integer threshold table: thr[j] =
+ * floor(P(K <= kmin + j) * 2^32) for kmin + j in [lambda - 12 sigma - 12, lambda + 12 sigma + 12]
+ * (the mass outside is below 1e-30); a 32-bit uniform u gives k = kmin + #{j : thr[j] <= u},
+ * capped at the table's last value.  Integer comparison only at draw time, so the host table and
+ * a device kernel give the same counts.  statrs' Poisson (population.rs:562, :599) is
+ * un-vendored; only the distribution is contractual.  Returns the table length (0 if cap is too
+ * small or lambda <= 0). */
+uint32_t orc_poisson_table(double lambda, uint32_t *kmin_out, uint32_t *thr, uint32_t cap)
+{
+    if (!(lambda > 0.0)) return 0;
+    const double spread = 12.0 * sqrt(lambda) + 12.0;
+    const double lo = floor(lambda - spread);
+    const uint32_t kmin = lo > 0.0 ? (uint32_t)lo : 0u;
+    const uint32_t kmax = (uint32_t)ceil(lambda + spread);
+    const uint32_t len = kmax - kmin + 1u;
+    if (len > cap) return 0;
+    const double loglam = log(lambda);
+    double cdf = 0.0;
+    for (uint32_t j = 0; j < len; j++) {
+        const double k = (double)(kmin + j);
+        cdf += exp(k * loglam - lambda - lgamma(k + 1.0));
+        const double scaled = floor(cdf * 4294967296.0);
+        thr[j] = scaled >= 4294967295.0 ? 4294967295u : (uint32_t)scaled;
+    }
+    *kmin_out = kmin;
+    return len;
+}
+
+uint32_t orc_poisson_from_table(uint32_t u, uint32_t kmin, const uint32_t *thr, uint32_t len)
+{
+    uint32_t lo = 0, hi = len;              /* number of thresholds <= u (they ascend) */
+    while (lo < hi) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (thr[mid] <= u) lo = mid + 1u; else hi = mid;
+    }
+    if (lo >= len) lo = len - 1u;
+    return kmin + lo;
+}
+
+/* population.rs:544-751, accessory path (HGT), keyed per donor like the reference draws it:
+ * donor d of compartment c sends k_d ~ Poisson(lambda_c) events (:599; here the threshold table
+ * above on word 0 of Philox(d, 0, gen, HGT_COUNT | c << 8)).  Event j of donor d:
+ * Philox(j, d, gen, HGT | c << 8) -> recipient uniform over the others (:584, :616-619; word 1),
+ * locus uniform among the donor's present genes of the compartment in the pre-recombination
+ * snapshot (:636-680; word 2), value always 1 (:632).  A donor without genes in the compartment
+ * sends nothing (:672, :740).  Returns the number of events drawn (donors without genes included). */
 uint64_t orc_recombine_acc(uint8_t *pop, uint64_t N, uint64_t G, uint64_t seed, uint32_t gen,
                            int n_comp, const uint64_t *comp_begin, const uint64_t *comp_end,
                            const double *lambdas)
@@ -302,37 +343,37 @@ uint64_t orc_recombine_acc(uint8_t *pop, uint64_t N, uint64_t G, uint64_t seed, 
     memcpy(snap, pop, N * G);
     uint32_t key[2] = { (uint32_t)seed, (uint32_t)(seed >> 32) };
     uint64_t total = 0;
-    uint32_t *list = (uint32_t *)malloc(N * G * sizeof(uint32_t));   /* present genes of a donor */
-    uint32_t *cnt = (uint32_t *)malloc(N * sizeof(uint32_t));
+    uint32_t *list = (uint32_t *)malloc(G * sizeof(uint32_t));   /* present genes of the donor */
     for (int c = 0; c < n_comp; c++) {
         if (lambdas[c] == 0.0) continue;                 /* population.rs:558 */
-        /* the donor's WeightedIndex over its present genes of the compartment
-         * (population.rs:636-680), built once per donor from the snapshot */
-        for (uint64_t d = 0; d < N; d++) {
-            uint32_t n = 0;
-            for (uint64_t g = comp_begin[c]; g < comp_end[c]; g++)
-                if (snap[d * G + g] != 0) list[d * G + n++] = (uint32_t)g;
-            cnt[d] = n;
-        }
-        uint32_t stream_c = ORC_STREAM_HGT_COUNT | ((uint32_t)c << 8);
-        uint64_t K = orc_poisson((double)N * lambdas[c], seed, stream_c, gen, NULL);
-        total += K;
-        uint32_t stream_e = ORC_STREAM_HGT | ((uint32_t)c << 8);
-        for (uint64_t e = 0; e < K; e++) {
-            uint32_t ctr[4] = { (uint32_t)e, (uint32_t)(e >> 32), gen, stream_e };
+        const uint32_t cap = (uint32_t)(24.0 * sqrt(lambdas[c]) + 64.0);
+        uint32_t *thr = (uint32_t *)malloc((size_t)cap * sizeof(uint32_t));
+        uint32_t kmin = 0;
+        const uint32_t len = orc_poisson_table(lambdas[c], &kmin, thr, cap);
+        const uint32_t stream_k = ORC_STREAM_HGT_COUNT | ((uint32_t)c << 8);
+        const uint32_t stream_e = ORC_STREAM_HGT | ((uint32_t)c << 8);
+        for (uint64_t d = 0; len && d < N; d++) {
+            uint32_t ctr[4] = { (uint32_t)d, 0u, gen, stream_k };
             uint32_t w[4];
             orc_philox4x32_10(ctr, key, w);
-            uint32_t d = mulhi32(w[0], (uint32_t)N);
-            uint32_t r = mulhi32(w[1], (uint32_t)(N - 1));
-            if (r >= d) r++;
-            uint32_t n = cnt[d];
+            const uint32_t k = orc_poisson_from_table(w[0], kmin, thr, len);
+            total += k;
+            /* the donor's WeightedIndex over its present genes of the compartment (:636-680) */
+            uint32_t n = 0;
+            for (uint64_t g = comp_begin[c]; g < comp_end[c]; g++)
+                if (snap[d * G + g] != 0) list[n++] = (uint32_t)g;
             if (n == 0) continue;                        /* population.rs:672 */
-            uint32_t j = mulhi32(w[2], n);
-            pop[(uint64_t)r * G + list[(uint64_t)d * G + j]] = 1;
+            for (uint32_t j = 0; j < k; j++) {
+                uint32_t ce[4] = { j, (uint32_t)d, gen, stream_e };
+                orc_philox4x32_10(ce, key, w);
+                uint32_t r = mulhi32(w[1], (uint32_t)(N - 1));
+                if (r >= d) r++;                         /* population.rs:618 */
+                pop[(uint64_t)r * G + list[mulhi32(w[2], n)]] = 1;
+            }
         }
+        free(thr);
     }
     free(list);
-    free(cnt);
     free(snap);
     return total;
 }

@@ -63,6 +63,9 @@ uint32_t orc_hs_u32(uint64_t seed, uint32_t stream, uint32_t gen, uint64_t n);
 /* Poisson(mean) from host stream (seed, stream, gen), Knuth product for mean<10
  * else Hoermann PTRS; *n_used returns how many f64 draws were consumed. */
 uint64_t orc_poisson(double mean, uint64_t seed, uint32_t stream, uint32_t gen, uint64_t *n_used);
+/* Poisson by inversion over an integer threshold table (HGT event counts per donor) */
+uint32_t orc_poisson_table(double lambda, uint32_t *kmin_out, uint32_t *thr, uint32_t cap);
+uint32_t orc_poisson_from_table(uint32_t u, uint32_t kmin, const uint32_t *thr, uint32_t len);
 
 /* ---- parameter derivation: main.rs:259-367 ------------------------------ */
 typedef struct {

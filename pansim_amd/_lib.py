@@ -83,6 +83,7 @@ SIGNATURES = {
     "ps_write": (_int, [_vp, C.c_char_p]),
     "ps_sync": (_int, [_vp]),
     "ps_set_tuning": (_int, [_vp, C.c_char_p, C.c_int64]),
+    "ps_poisson_table": (_u32, [_f64, _u32p, _u32p, _u32]),
     "ps_hamming_bitwise_fast": (_int, [_u8p, _u8p, C.c_size_t, C.POINTER(_u32)]),
     "ps_jaccard_distance_fast": (_int, [_u8p, _u8p, C.c_size_t, C.POINTER(_u32), C.POINTER(_u32)]),
     "ps_standard_deviation": (_int, [_f64p, _u64, C.POINTER(_f64), C.POINTER(_f64)]),

@@ -87,36 +87,38 @@ static inline uint32_t hs_u32(uint64_t seed, uint32_t stream, uint32_t gen, uint
     }
 }
 
-// Poisson(mean): Knuth product below 10, Hoermann's PTRS above (the reference uses
-// statrs::Poisson, population.rs:484, :562; only the distribution is contractual).
-static uint64_t hs_poisson(double mean, uint64_t seed, uint32_t stream, uint32_t gen)
+// Poisson(lambda) by inversion over an integer threshold table (include/pansim_hip.h,
+// ps_poisson_table): thr[j] = floor(P(K <= kmin + j) * 2^32) over lambda +- (12 sigma + 12).
+static void hs_poisson_table(double lambda, uint32_t *kmin_out, std::vector<uint32_t> *thr)
 {
-    uint64_t n = 0;
-    if (!(mean > 0.0)) return 0;
-    if (mean < 10.0) {
-        const double lim = std::exp(-mean);
-        double p = 1.0;
-        uint64_t k = 0;
-        do { k++; p *= hs_f64(seed, stream, gen, n++); } while (p > lim);
-        return k - 1;
+    thr->clear();
+    *kmin_out = 0;
+    if (!(lambda > 0.0)) return;
+    const double spread = 12.0 * std::sqrt(lambda) + 12.0;
+    const double lo = std::floor(lambda - spread);
+    const uint32_t kmin = lo > 0.0 ? (uint32_t)lo : 0u;
+    const uint32_t kmax = (uint32_t)std::ceil(lambda + spread);
+    const double loglam = std::log(lambda);
+    double cdf = 0.0;
+    for (uint32_t k = kmin; k <= kmax; k++) {
+        cdf += std::exp((double)k * loglam - lambda - std::lgamma((double)k + 1.0));
+        const double scaled = std::floor(cdf * 4294967296.0);
+        thr->push_back(scaled >= 4294967295.0 ? 4294967295u : (uint32_t)scaled);
     }
-    const double slam = std::sqrt(mean), loglam = std::log(mean);
-    const double b = 0.931 + 2.53 * slam;
-    const double a = -0.059 + 0.02483 * b;
-    const double invalpha = 1.1239 + 1.1328 / (b - 3.4);
-    const double vr = 0.9277 - 3.6224 / (b - 2.0);
-    for (;;) {
-        const double U = hs_f64(seed, stream, gen, n++) - 0.5;
-        const double V = hs_f64(seed, stream, gen, n++);
-        const double us = 0.5 - std::fabs(U);
-        const double kf = std::floor((2.0 * a / us + b) * U + mean + 0.43);
-        if (us >= 0.07 && V <= vr) return (uint64_t)kf;
-        if (kf < 0.0 || (us < 0.013 && V > us)) continue;
-        if (std::log(V) + std::log(invalpha) - std::log(a / (us * us) + b)
-            <= -mean + kf * loglam - std::lgamma(kf + 1.0))
-            return (uint64_t)kf;
-    }
+    *kmin_out = kmin;
 }
+
+extern "C" uint32_t ps_poisson_table(double lambda, uint32_t *kmin_out, uint32_t *thr, uint32_t cap)
+{
+    std::vector<uint32_t> t;
+    uint32_t kmin = 0;
+    hs_poisson_table(lambda, &kmin, &t);
+    if (t.empty() || t.size() > cap || !kmin_out || !thr) return 0;
+    *kmin_out = kmin;
+    memcpy(thr, t.data(), t.size() * sizeof(uint32_t));
+    return (uint32_t)t.size();
+}
+
 
 // ---------------------------------------------------------------------------
 // keyed dense plans
@@ -179,8 +181,8 @@ struct ps_population {
     acc_dims d{};
     uint64_t *G[2] = { nullptr, nullptr };
     uint64_t *I[2] = { nullptr, nullptr };
-    uint16_t *glist = nullptr;           // gene lists of HGT donors, N x G
-    uint8_t *sel_buf = nullptr;          // compact rank/select tables of HGT donors (acc_select_tabs)
+    uint32_t *d_ptab[PS_MAX_COMP] = {};  // Poisson threshold tables of the HGT event counts (ps_set_rates)
+    uint32_t ptab_kmin[PS_MAX_COMP] = {}, ptab_len[PS_MAX_COMP] = {};
     void *hgt_scratch = nullptr;         // slice images of the LDS-partitioned HGT kernel
     uint64_t hgt_scratch_cap = 0;
     uint32_t hgt_slices = 0;             // tuning: event slices of the LDS-partitioned HGT kernel (0 = choose)
@@ -200,7 +202,7 @@ struct ps_population {
     double *d_Dt = nullptr;          // all-pairs Jaccard distances (D-avg), N x N
     uint64_t H_cap = 0;
     int pair_mode = 0;               // 0 auto, 1 sampled kernel, 2 all-pairs kernel (tuning/tests)
-    int hgt_mode = 0;                // 0 auto, 1 global-atomic, 2 LDS-partitioned, 3 test-before-set, 4 rank/select tables, 5 binned
+    int hgt_mode = 0;                // 0 auto, 1 one atomic per event, 2 binned by recipient partition + LDS images
     void *d_pairs = nullptr;         // sorted r1 | r2 | perm | outA | outB
     uint64_t pairs_cap = 0, pairs_cached = 0;
     std::vector<uint32_t> h_r1, h_r2; // the caller's list the device copy was built from
@@ -227,7 +229,7 @@ extern "C" void ps_population_destroy(ps_population *p)
     if (!p) return;
     (void)hipSetDevice(p->device);
     if (p->stream) (void)hipStreamSynchronize(p->stream);
-    void *ptrs[] = { p->state, p->G[0], p->G[1], p->I[0], p->I[1], p->glist, p->sel_buf, p->hgt_scratch, p->cnt, p->d_idx, p->d_idxT, p->d_work,
+    void *ptrs[] = { p->state, p->G[0], p->G[1], p->I[0], p->I[1], p->d_ptab[0], p->d_ptab[1], p->hgt_scratch, p->cnt, p->d_idx, p->d_idxT, p->d_work,
                      p->d_log1p, p->d_num_genes, p->d_logw, p->d_pairs, p->d_H, p->d_Dt };
     for (void *q : ptrs)
         if (q) (void)hipFree(q);
@@ -302,12 +304,8 @@ static int pop_create_impl(const ps_config *cfg, const uint8_t *init_vec, ps_pop
             HIPCHK(hipMalloc(&p->I[k], nI));
         }
         if (C > 65536) return ps_fail(PS_ERR_INVALID, "at most 65536 accessory genes are supported");
-        HIPCHK(hipMalloc(&p->glist, std::max<uint64_t>(N * C, 1) * sizeof(uint16_t)));
-        HIPCHK(hipMalloc(&p->cnt, std::max<uint64_t>(N, 1) * PS_MAX_COMP * sizeof(uint32_t)));
-        {
-            const uint64_t GW8 = ((uint64_t)p->d.GW + 7) & ~7ull, NG8 = (GW8 / 8 + 7) & ~7ull;
-            HIPCHK(hipMalloc(&p->sel_buf, std::max<uint64_t>(N, 1) * (p->d.GW * 8ull + GW8 * 2 + NG8 * 2) + 64));
-        }
+        // events per (compartment, donor) + the dynamic item counter of the HGT kernel
+        HIPCHK(hipMalloc(&p->cnt, (std::max<uint64_t>(N, 1) * PS_MAX_COMP + 64) * sizeof(uint32_t)));
         HIPCHK(hipMalloc(&p->d_log1p, std::max<uint64_t>(C, 1) * sizeof(double)));
         HIPCHK(hipMalloc(&p->d_num_genes, std::max<uint64_t>(N, 1) * sizeof(int32_t)));
         HIPCHK(hipMalloc(&p->d_logw, std::max<uint64_t>(N, 1) * sizeof(double)));
@@ -398,7 +396,7 @@ extern "C" int ps_set_tuning(ps_population *p, const char *key, int64_t value)
         if (value < 2 || value > 4) return ps_fail(PS_ERR_INVALID, "sweep_rows must be 2..4");
         p->sweep_rows = (uint32_t)value;
     } else if (k == "hgt_mode") {
-        if (value < 0 || value > 5) return ps_fail(PS_ERR_INVALID, "hgt_mode must be 0 (auto), 1 (global atomics), 2 (LDS partitions), 3 (test before set), 4 (rank/select tables) or 5 (binned, two passes)");
+        if (value < 0 || value > 2) return ps_fail(PS_ERR_INVALID, "hgt_mode must be 0 (auto), 1 (one atomic per event) or 2 (binned by recipient partition, two passes)");
         p->hgt_mode = (int)value;
     } else if (k == "pair_mode") {
         if (value < 0 || value > 2) return ps_fail(PS_ERR_INVALID, "pair_mode must be 0 (auto), 1 (sampled) or 2 (all pairs)");
@@ -514,6 +512,19 @@ extern "C" int ps_set_rates(ps_population *p, int n_comp, const double *lam_mut,
             p->aplan.comp_end[c] = (uint32_t)comp_end[c];
             p->aplan.flip_thr[c] = acc_flip_threshold(lam_mut[c], comp_end[c] - comp_begin[c]);
             p->aplan.lam_rec[c] = lam_rec[c];
+        }
+        // Poisson threshold tables of the per-donor HGT event counts (population.rs:599)
+        PSCHK(use_device(p));
+        for (int c = 0; c < PS_MAX_COMP; c++) {
+            if (p->d_ptab[c]) { HIPCHK(hipStreamSynchronize(p->stream)); HIPCHK(hipFree(p->d_ptab[c])); }
+            p->d_ptab[c] = nullptr;
+            p->ptab_len[c] = 0;
+            if (c >= n_comp || !(lam_rec[c] > 0.0)) continue;
+            std::vector<uint32_t> thr;
+            hs_poisson_table(lam_rec[c], &p->ptab_kmin[c], &thr);
+            HIPCHK(hipMalloc(&p->d_ptab[c], thr.size() * sizeof(uint32_t)));
+            HIPCHK(hipMemcpy(p->d_ptab[c], thr.data(), thr.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+            p->ptab_len[c] = (uint32_t)thr.size();
         }
     }
     p->rates_set = true;
@@ -723,76 +734,77 @@ static int launch_acc_step(ps_population *p, const uint32_t *d_idx, uint32_t gen
     return PS_OK;
 }
 
+// recipient partitions of the binned HGT: the rows of one partition (plus 1 KB of static LDS of the
+// apply kernel) must fit the LDS of a workgroup
+static uint32_t hgt_partitions(const ps_population *p)
+{
+    const uint64_t row_bytes = (uint64_t)p->d.GW * 8;
+    if (row_bytes == 0 || p->lds_limit < 1024u + row_bytes) return 0;
+    const uint64_t part_cap = (p->lds_limit - 1024u) / row_bytes;
+    return (uint32_t)((p->d.N + part_cap - 1) / part_cap);
+}
+
 static int launch_acc_hgt(ps_population *p, uint32_t gen, hipStream_t st)
 {
     if (p->d.G == 0 || p->d.N < 2) return PS_OK;
     acc_hgt_args a{};
     a.n_comp = (uint32_t)p->aplan.n_comp;
-    uint64_t total = 0;
+    double expected = 0.0;
+    uint32_t max_comp = 1;
     for (int c = 0; c < p->aplan.n_comp; c++) {
         a.gb[c] = p->aplan.comp_begin[c];
-        a.K[c] = 0;
-        if (p->aplan.lam_rec[c] == 0.0) continue;      // population.rs:558
-        a.K[c] = hs_poisson((double)p->d.N * p->aplan.lam_rec[c], p->cfg.seed,
-                            PS_STREAM_HGT_COUNT | ((uint32_t)c << 8), gen);
-        total += a.K[c];
+        a.ge[c] = p->aplan.comp_end[c];
+        a.ptab[c] = nullptr;
+        if (p->aplan.lam_rec[c] == 0.0 || p->ptab_len[c] == 0) continue;      // population.rs:558
+        a.ptab[c] = p->d_ptab[c];
+        a.kmin[c] = p->ptab_kmin[c];
+        a.plen[c] = p->ptab_len[c];
+        expected += (double)p->d.N * p->aplan.lam_rec[c];
+        max_comp = std::max(max_comp, a.ge[c] - a.gb[c]);
     }
-    if (total == 0) return PS_OK;
-    const bool use_select = p->hgt_mode == 4 && p->d.G <= 65535u;
-    // the gene lists ARE the pre-recombination snapshot the donors are read from
-    if (!use_select)
-        acc_gene_lists_kernel<<<dim3(p->d.N, p->aplan.n_comp), 64, 0, st>>>(p->I[p->cur], p->glist, p->cnt,
-                                                                             p->d, p->aplan);
-    a.list = p->glist;
-    a.cnt = p->cnt;
-    a.dstI = p->I[p->cur];
+    if (expected == 0.0) return PS_OK;
     a.d = p->d;
     a.gen = gen;
     a.k0 = (uint32_t)p->cfg.seed;
     a.k1 = (uint32_t)(p->cfg.seed >> 32);
-    // small population and very many events (>= 1e7, cfg3-like rates): tile the recipients through
-    // LDS (<= 8 partitions), which beats the scattered-global-atomic rate; otherwise one global
-    // atomic per event that changes a bit -- that kernel needs no LDS and co-runs with the sweep
+    a.kcnt = p->cnt;
+    a.work_ctr = p->cnt + (uint64_t)PS_MAX_COMP * p->d.N;
+    a.overflow_flag = p->d_flag;
+    const uint32_t items = a.n_comp * p->d.N;
+    const uint32_t list_lds = ((max_comp * 2u + 15u) & ~15u);
+    if (list_lds > p->lds_limit)
+        return ps_fail(PS_ERR_INVALID, "a compartment of %u genes needs %u bytes of LDS (limit %u)", max_comp, list_lds, p->lds_limit);
+    HIPCHK(hipMemsetAsync(a.work_ctr, 0, sizeof(uint32_t), st));
+    acc_hgt_counts_kernel<<<(items + 255) / 256, 256, 0, st>>>(a);
+
+    // Heavy HGT (>= 1e7 expected events, cfg3) with a population whose rows fit <= 8 LDS partitions:
+    // two passes -- the donors' events are binned by recipient partition, then ORed into LDS images
+    // of the partitions and reduced into the matrix (no global atomics at all).  Otherwise one
+    // 64-bit atomicOr per event; that form needs only the donor list in LDS and co-runs with the sweep.
     const uint64_t row_bytes = (uint64_t)p->d.GW * 8;
-    const uint32_t part_cap = (uint32_t)(p->lds_limit / row_bytes);
-    const uint32_t parts = part_cap ? (p->d.N + part_cap - 1) / part_cap : 0;
-    if (use_select) {
-        // heavy HGT: compact rank/select tables (stay in L2 beside the streaming sweep)
-        acc_hgt_select_args sa{};
-        const uint64_t N = p->d.N;
-        sa.t.GW8 = (p->d.GW + 7u) & ~7u;
-        sa.t.NG8 = (sa.t.GW8 / 8u + 7u) & ~7u;
-        sa.t.snap = (uint64_t *)p->sel_buf;
-        sa.t.cum = (uint16_t *)(p->sel_buf + N * p->d.GW * 8ull);
-        sa.t.top = sa.t.cum + N * sa.t.GW8;
-        sa.t.nb = p->cnt;
-        sa.dstI = p->I[p->cur];
-        sa.d = p->d;
-        sa.gen = gen;
-        sa.k0 = a.k0;
-        sa.k1 = a.k1;
-        for (int c = 0; c < PS_MAX_COMP; c++) sa.K[c] = a.K[c];
-        acc_rank_tables_kernel<<<p->d.N, 64, 0, st>>>(p->I[p->cur], sa.t, p->d, p->aplan);
-        for (int c = 0; c < p->aplan.n_comp; c++) {
-            if (a.K[c] == 0) continue;
-            const uint32_t blocks = (uint32_t)std::min<uint64_t>((a.K[c] + 511) / 512, 256 * 8);
-            acc_hgt_select_kernel<<<blocks, 256, 0, st>>>(sa, (uint32_t)c);
-        }
-    } else if ((p->hgt_mode == 5 || (p->hgt_mode == 0 && total >= 10000000)) && parts >= 1 && parts <= 8 && p->d.G <= 65536u) {
-        // heavy HGT, two passes: bin the effective events by recipient partition, then OR the bins
-        // into LDS images of the partitions and reduce the images into the matrix
+    const uint32_t parts = hgt_partitions(p);
+    const bool binned = (p->hgt_mode == 2 || (p->hgt_mode == 0 && expected >= 1.0e7)) && parts >= 1 && parts <= 8
+                        && p->d.G <= 65536u && (uint64_t)p->d.N * ((p->d.N + std::max(parts, 1u) - 1) / std::max(parts, 1u)) < (1ull << 32);
+    if (binned) {
         const uint32_t rows_per_part = (p->d.N + parts - 1) / parts;
         const uint32_t lds = (uint32_t)(rows_per_part * row_bytes);
         const uint32_t n_slices = std::max(1u, p->hgt_slices ? p->hgt_slices : 256u / parts);
-        const uint32_t bin_blocks = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(1024, (total + 16383) / 16384));
-        const uint64_t per_block = (total + bin_blocks - 1) / bin_blocks;
-        const double mean = (double)per_block / parts * ((double)rows_per_part * parts / p->d.N);
-        const uint32_t cap = (uint32_t)(((uint64_t)(mean + 10.0 * std::sqrt(mean) + 64.0) + 63) & ~63ull);
         const uint64_t words = (uint64_t)p->d.N * p->d.GW;
         const uint64_t img_bytes = (uint64_t)n_slices * words * 8;
-        const uint64_t bin_bytes = (uint64_t)bin_blocks * parts * cap * 4;
-        const uint64_t cnt_bytes = ((uint64_t)bin_blocks * parts * 4 + 255) & ~255ull;
-        const uint64_t need = img_bytes + bin_bytes + cnt_bytes;
+        uint64_t bin_words = 0;
+        for (int c = 0; c < p->aplan.n_comp; c++) {
+            a.bin_base[c] = bin_words;
+            a.bin_cap[c] = 0;
+            if (!a.ptab[c]) continue;
+            // k_d <= kmax (the table's last value); a partition receives rows_per_part / (N - 1) of them
+            // (per wave of the donor's 4-wave workgroup: a quarter of them, dealt round-robin)
+            const double kmax = (double)(a.kmin[c] + a.plen[c] - 1u);
+            const double mean = (kmax / 4.0 + 64.0) * (double)rows_per_part / (double)(p->d.N - 1);
+            a.bin_cap[c] = (uint32_t)(((uint64_t)(mean + 10.0 * std::sqrt(mean) + 64.0) + 63) & ~63ull);
+            bin_words += (uint64_t)p->d.N * 4u * parts * a.bin_cap[c];
+        }
+        const uint64_t cnt_bytes = ((uint64_t)items * 4u * parts * 4 + 255) & ~255ull;
+        const uint64_t need = img_bytes + bin_words * 4 + cnt_bytes;
         if (p->hgt_scratch_cap < need) {
             if (p->hgt_scratch) HIPCHK(hipFree(p->hgt_scratch));
             p->hgt_scratch = nullptr;
@@ -800,66 +812,39 @@ static int launch_acc_hgt(ps_population *p, uint32_t gen, hipStream_t st)
             HIPCHK(hipMalloc(&p->hgt_scratch, need));
             p->hgt_scratch_cap = need;
         }
-        acc_hgt_bin_args b{};
         a.scratch = (uint32_t *)p->hgt_scratch;
-        b.h = a;
-        b.bins = (uint32_t *)((uint8_t *)p->hgt_scratch + img_bytes);
-        b.counts = (uint32_t *)((uint8_t *)p->hgt_scratch + img_bytes + bin_bytes);
-        b.parts = parts;
-        b.rows_per_part = rows_per_part;
-        b.cap = cap;
-        b.per_block = per_block;
-        b.overflow_flag = p->d_flag;
-        acc_hgt_bin_kernel<<<bin_blocks, 256, 0, st>>>(b);
+        a.bins = (uint32_t *)((uint8_t *)p->hgt_scratch + img_bytes);
+        a.counts = (uint32_t *)((uint8_t *)p->hgt_scratch + img_bytes + bin_words * 4);
+        a.parts = parts;
+        a.rows_per_part = rows_per_part;
+        a.part_magic = (uint32_t)(4294967296ull / rows_per_part) + 1u;
+        a.srcI = p->I[p->cur];          // the matrix is not edited before the reduce pass: it IS the snapshot
+        a.dstI = p->I[p->cur];
+        const uint32_t grid = std::min(items, 256u * 8u);
+        hipLaunchKernelGGL((acc_hgt_donor_kernel<true>), dim3(grid), dim3(256), list_lds, st, a);
         auto kern = acc_hgt_apply_kernel;
         if (lds > 64 * 1024)
             HIPCHK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(kern, dim3(parts * n_slices), dim3(1024), lds, st, b, bin_blocks, n_slices);
+        hipLaunchKernelGGL(kern, dim3(parts * n_slices), dim3(1024), lds, st, a, n_slices);
         acc_hgt_reduce_kernel<<<(uint32_t)((words + 255) / 256), 256, 0, st>>>((const uint64_t *)p->hgt_scratch,
                                                                               p->I[p->cur], words, n_slices);
-    } else if ((p->hgt_mode == 2 || (p->hgt_mode == 0 && total >= 10000000)) && parts >= 1 && parts <= 8) {
-        const uint32_t rows_per_part = (p->d.N + parts - 1) / parts;
-        const uint32_t lds = (uint32_t)(rows_per_part * row_bytes);
-        const uint32_t n_slices = std::max(1u, p->hgt_slices ? p->hgt_slices : 512u / parts);
-        auto kern = acc_hgt_lds_kernel;
-        if (lds > 64 * 1024)
-            HIPCHK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        const uint64_t words = (uint64_t)p->d.N * p->d.GW;
-        const uint64_t need = (uint64_t)n_slices * words * 8;
-        if (p->hgt_scratch_cap < need) {
-            if (p->hgt_scratch) HIPCHK(hipFree(p->hgt_scratch));
-            p->hgt_scratch = nullptr;
-            p->hgt_scratch_cap = 0;
-            HIPCHK(hipMalloc(&p->hgt_scratch, need));
-            p->hgt_scratch_cap = need;
-        }
-        a.scratch = (uint32_t *)p->hgt_scratch;
-        hipLaunchKernelGGL(kern, dim3(parts * n_slices), dim3(1024), lds, st, a, rows_per_part, n_slices);
-        acc_hgt_reduce_kernel<<<(uint32_t)((words + 255) / 256), 256, 0, st>>>((const uint64_t *)p->hgt_scratch,
-                                                                              p->I[p->cur], words, n_slices);
-    } else if (p->hgt_mode == 3 || (p->hgt_mode == 0 && total >= 10000000)) {
-        for (int c = 0; c < p->aplan.n_comp; c++) {
-            if (a.K[c] == 0) continue;
-            const uint32_t blocks = (uint32_t)std::min<uint64_t>((a.K[c] + 1023) / 1024, 256 * 8);
-            acc_hgt_tbs_kernel<<<blocks, 256, 0, st>>>(a, (uint32_t)c);
-        }
     } else {
-        for (int c = 0; c < p->aplan.n_comp; c++) {
-            if (a.K[c] == 0) continue;
-            // beside a long core sweep (ps_sim sets hgt_events_per_thread) the kernel is launched
-            // narrow -- one-wave workgroups, ~64 events per thread: the same events then disturb the
-            // sweep for longer but far less (cfg2: sweep 0.571 -> 0.550 ms, +4.6 % generations/s);
-            // stand-alone calls use the whole chip
-            uint32_t thr = 256, blocks = (uint32_t)std::min<uint64_t>((a.K[c] + 255) / 256, 256 * 16);
-            if (p->hgt_events_per_thread) {
-                thr = 64;
-                // the same width for every compartment, sized on the generation's total: the launches
-                // run one after the other, so their durations add up to total / width events per thread
-                const uint64_t want = (total + (uint64_t)p->hgt_events_per_thread * 64 - 1) / ((uint64_t)p->hgt_events_per_thread * 64);
-                blocks = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(std::min<uint64_t>(want, (a.K[c] + 63) / 64), 1), 256 * 64);
-            }
-            acc_hgt_kernel<<<blocks, thr, 0, st>>>(a, (uint32_t)c);
+        // donors read a snapshot copy (population.rs:693-695) while recipients are edited in place
+        HIPCHK(hipMemcpyAsync(p->I[1 - p->cur], p->I[p->cur], (size_t)p->d.N * p->d.GW * 8, hipMemcpyDeviceToDevice, st));
+        a.srcI = p->I[1 - p->cur];
+        a.dstI = p->I[p->cur];
+        // beside a long core sweep (ps_sim sets hgt_events_per_thread) the kernel is launched narrow --
+        // one-wave workgroups, a fixed number of events per thread over the generation: the same events
+        // then disturb the sweep for longer but far less; stand-alone calls use the whole chip
+        uint32_t thr = 256, grid = std::min(items, 256u * 8u);
+        if (p->hgt_events_per_thread) {
+            thr = 64;
+            const uint64_t want = (uint64_t)(expected / ((double)p->hgt_events_per_thread * 64.0)) + 1;
+            grid = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(want, 1), std::min(items, 256u * 32u));
         }
+        if (list_lds > 64 * 1024)
+            HIPCHK(hipFuncSetAttribute((const void *)acc_hgt_donor_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)list_lds));
+        hipLaunchKernelGGL((acc_hgt_donor_kernel<false>), dim3(grid), dim3(thr), list_lds, st, a);
     }
     // rebuild the gene-major view from the individual-major one (one ballot per gene word)
     acc_i_to_g_kernel<<<dim3(p->d.W, p->d.GW), 64, 0, st>>>(p->I[p->cur], p->G[p->cur], p->d);
@@ -1732,9 +1717,7 @@ static int sim_create_impl(const ps_sim_params *p, ps_sim *s)
     {
         // take turns only where the binned kernel applies (small populations: the recipients fit 8 LDS
         // partitions); at cfg4 sizes HGT streams from HBM anyway and co-running was 5 % faster
-        const uint64_t row_bytes = (uint64_t)s->acc->d.GW * 8;
-        const uint64_t part_cap = row_bytes ? s->acc->lds_limit / row_bytes : 0;
-        const uint64_t parts = part_cap ? (N + part_cap - 1) / part_cap : 0;
+        const uint32_t parts = hgt_partitions(s->acc);
         s->heavy_hgt = (double)N * s->der.n_recombinations_pan_total >= 1.0e7 && parts >= 1 && parts <= 8;
     }
     if (const char *e = getenv("PANSIM_HEAVY_HGT")) s->heavy_hgt = atoi(e) != 0;

@@ -164,3 +164,28 @@ def test_format_and_small_helpers(pa, orc):
         assert pa.int_to_base(int(k)) == v
     v = KAT["standard_deviation"]
     assert pa.standard_deviation(v["values"]) == (v["std"], v["mean"])
+
+
+def test_poisson_table_matches_oracle_and_poisson(pa, orc):
+    # the library's and the oracle's independent restatements give identical integer tables, and the
+    # table is the Poisson law: mean/variance = lambda, monotone thresholds ending at 2^32 - 1
+    from pansim_amd import _lib
+    for lam in (0.003, 0.7, 3.0, 27.0, 299.99999999999994, 2700.0, 27000.0):
+        kmin_o, thr_o = orc.poisson_table(lam)
+        cap = len(thr_o) + 8
+        thr = np.zeros(cap, np.uint32)
+        kmin = np.zeros(1, np.uint32)
+        n = _lib.load().ps_poisson_table(lam, kmin, thr, cap)
+        assert n == len(thr_o) and int(kmin[0]) == kmin_o
+        assert np.array_equal(thr[:n], thr_o)
+        t = thr_o.astype(np.float64)
+        assert (np.diff(t) >= 0).all() and thr_o[-1] == 2**32 - 1
+        pmf = np.diff(np.concatenate([[0.0], t])) / 2.0**32
+        k = kmin_o + np.arange(len(t))
+        mean = (pmf * k).sum()
+        var = (pmf * (k - mean) ** 2).sum()
+        assert abs(mean - lam) < 1e-6 * max(lam, 1.0) + 1e-8 and abs(var - lam) < 1e-5 * max(lam, 1.0) + 1e-7
+        # draws: u = 0 gives the smallest value with mass, u = 2^32 - 1 the largest
+        assert orc.poisson_from_table(0, kmin_o, thr_o) == kmin_o + int(np.argmax(thr_o > 0))
+        assert orc.poisson_from_table(2**32 - 1, kmin_o, thr_o) == kmin_o + len(thr_o) - 1
+    assert _lib.load().ps_poisson_table(0.0, np.zeros(1, np.uint32), np.zeros(8, np.uint32), 8) == 0
