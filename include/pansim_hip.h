@@ -151,7 +151,8 @@ int ps_sync(ps_population *p);
  * "force_inline_sweep" (0/1: use the queue-free inline block sweep), "pair_mode" (core
  * distances: 0 = choose by cost, 1 = sampled-pair kernel, 2 = all-pairs tiles + lookup),
  * "hgt_mode" (accessory recombination: 0 = choose, 1 = one atomic per event, 2 = two passes: bin
- * by recipient partition, OR in LDS images), "hgt_slices" (binned HGT: event slices, 0 = choose),
+ * by recipient partition, OR in LDS images), "hgt_slices" (binned HGT: event slices, 0 = choose), "hgt_list_in_global" (0/1: donor gene lists in
+ * global scratch instead of LDS),
  * "lds_limit" (bytes of LDS a workgroup may use), "block_waves" (block sweep: waves per
  * workgroup, 0 = choose), "block_batch" (block sweep: segments per wave batch, 0 = choose, 2 or 4),
  * "no_block_preload" (block sweep: parent indices re-read per batch). */

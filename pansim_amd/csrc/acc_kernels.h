@@ -155,6 +155,8 @@ struct acc_hgt_args {
     uint32_t part_magic;           // floor(2^32 / rows_per_part) + 1: rc / rows_per_part = mulhi(rc, magic) for rc < 2^16
     uint32_t *scratch;             // slice images [n_slices][N][2*GW]
     uint32_t *overflow_flag;
+    uint16_t *list_scratch;        // null: donor lists in LDS; else [grid][list_stride] in global memory
+    uint32_t list_stride;
 };
 
 // k_d for every (compartment, donor): kmin + number of thresholds <= u (ps_poisson_table)
@@ -209,23 +211,55 @@ __device__ __forceinline__ uint32_t ps_wave_gene_list(const uint64_t *row, uint3
     return base;
 }
 
-// BIN = false: one 64-bit atomicOr per event (light HGT; co-runs with the core sweep, launched
-//              narrow by ps_sim).  srcI must be a snapshot copy, dstI the live matrix.
-// BIN = true : the events are appended, packed (recipient row inside its partition << 16 | gene),
-//              to the item's bins of the recipients' partitions (wave-aggregated appends through
-//              LDS counters, no global atomics); acc_hgt_apply_kernel ORs them into LDS images.
-template <bool BIN>
-__global__ void __launch_bounds__(256) acc_hgt_donor_kernel(acc_hgt_args a)
+// Light HGT: one 64-bit atomicOr per event.  One wave per workgroup and no static LDS, so that the
+// kernel fits beside whatever the core sweep leaves on a CU; the donor's gene list lives in dynamic
+// LDS or -- when the co-running block sweep owns the CU's LDS (cfg4 population) -- in the
+// workgroup's slice of a global scratch that stays hot in L2.  srcI must be a snapshot copy of the
+// matrix, dstI the live one.  Launched narrow by ps_sim.
+__global__ void __launch_bounds__(64) acc_hgt_donor_wave_kernel(acc_hgt_args a)
+{
+    extern __shared__ __attribute__((aligned(16))) uint16_t lds_list[];
+    uint16_t *glist = a.list_scratch ? a.list_scratch + (uint64_t)blockIdx.x * a.list_stride : lds_list;
+    const acc_dims d = a.d;
+    const uint32_t lane = threadIdx.x;
+    const uint32_t items = a.n_comp * d.N;
+    for (;;) {
+        uint32_t item = 0;
+        if (lane == 0) item = atomicAdd(a.work_ctr, 1u);
+        item = __builtin_amdgcn_readfirstlane(item);
+        if (item >= items) break;
+        const uint32_t c = item / d.N, dn = item % d.N;
+        const uint32_t k = a.kcnt[item];
+        if (k == 0u) continue;
+        __threadfence_block();                             // the previous item's list reads are done
+        const uint32_t n = ps_wave_gene_list(a.srcI + (uint64_t)dn * d.GW, d.GW, a.gb[c], a.ge[c], glist, lane);
+        __threadfence_block();                             // the list is written (it may live in global memory)
+        if (n == 0u) continue;                             // population.rs:672
+        const uint32_t stream = PS_STREAM_HGT | (c << 8);
+        for (uint32_t j = lane; j < k; j += 64u) {
+            const ps_u4 r = ps_philox(j, dn, a.gen, stream, a.k0, a.k1);
+            uint32_t rc = ps_mulhi(r.y, d.N - 1u);
+            rc += (rc >= dn) ? 1u : 0u;                                 // population.rs:618
+            const uint32_t gene = glist[ps_mulhi(r.z, n)];
+            atomicOr((unsigned long long *)&a.dstI[(uint64_t)rc * d.GW + (gene >> 6)], 1ull << (gene & 63u));
+        }
+    }
+}
+
+// Heavy HGT, first pass: the events of an item are appended, packed (recipient row inside its
+// partition << 16 | gene), to bins per recipient partition; acc_hgt_apply_kernel ORs them into LDS
+// images.  Every wave of the 256-thread workgroup owns its bins of the item: the fill counters are
+// wave-uniform registers -- no atomics and no synchronisation between the waves in the event loop.
+__global__ void __launch_bounds__(256) acc_hgt_donor_bin_kernel(acc_hgt_args a)
 {
     extern __shared__ __attribute__((aligned(16))) uint16_t glist[];   // present genes of the item's donor
-    __shared__ uint32_t sh_item, sh_n, fill[8];
+    __shared__ uint32_t sh_item, sh_n;
     const acc_dims d = a.d;
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
     const uint32_t items = a.n_comp * d.N;
     for (;;) {
         __syncthreads();                                   // everybody is done with the previous item
         if (tid == 0) sh_item = atomicAdd(a.work_ctr, 1u);
-        if (BIN && tid < 8u) fill[tid] = 0u;
         __syncthreads();
         const uint32_t item = sh_item;
         if (item >= items) break;
@@ -240,55 +274,41 @@ __global__ void __launch_bounds__(256) acc_hgt_donor_kernel(acc_hgt_args a)
             __syncthreads();
             n = sh_n;
         }
-        if (BIN) {
-            // every wave of the (256-thread) workgroup appends to its OWN bins of the item, one per
-            // recipient partition: the fill counters are wave-uniform registers -- no LDS atomics and
-            // no synchronisation between the waves inside the event loop
-            const uint32_t wv = tid >> 6;
-            const uint32_t cap = a.bin_cap[c];
-            uint32_t *mybins = a.bins + a.bin_base[c] + ((uint64_t)dn * 4u + wv) * a.parts * cap;
-            uint32_t fillq[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
-            if (k != 0u && n != 0u) {                      // population.rs:672
-                const uint32_t stream = PS_STREAM_HGT | (c << 8);
-                const uint32_t rounds = (k + blockDim.x - 1u) / blockDim.x;
-                for (uint32_t it = 0; it < rounds; it++) {
-                    const uint32_t j = it * blockDim.x + tid;
-                    const bool ok = j < k;
-                    const ps_u4 r = ps_philox(j, dn, a.gen, stream, a.k0, a.k1);
-                    uint32_t rc = ps_mulhi(r.y, d.N - 1u);
-                    rc += (rc >= dn) ? 1u : 0u;                         // population.rs:618
-                    const uint32_t gene = glist[ps_mulhi(r.z, n)];
-                    const uint32_t part = ps_mulhi(rc, a.part_magic);   // rc / rows_per_part
-                    const uint32_t packed = ((rc - part * a.rows_per_part) << 16) | gene;
-                    uint32_t pos = 0;
-#pragma unroll
-                    for (uint32_t q = 0; q < 8u; q++) {
-                        if (q < a.parts) {
-                            const uint64_t m = __ballot(ok && part == q);
-                            const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-                            pos = (part == q) ? fillq[q] + rank : pos;
-                            fillq[q] += (uint32_t)__popcll(m);
-                        }
-                    }
-                    if (ok && pos < cap) mybins[(uint64_t)part * cap + pos] = packed;
-                }
-            }
-            uint32_t f = 0;
-#pragma unroll
-            for (uint32_t q = 0; q < 8u; q++) f = (lane == q) ? fillq[q] : f;
-            if (lane < a.parts) {
-                if (f > cap) { atomicOr(a.overflow_flag, 8u); f = cap; }
-                a.counts[((uint64_t)item * 4u + wv) * a.parts + lane] = f;
-            }
-        } else if (k != 0u && n != 0u) {
+        const uint32_t wv = tid >> 6;
+        const uint32_t cap = a.bin_cap[c];
+        uint32_t *mybins = a.bins + a.bin_base[c] + ((uint64_t)dn * 4u + wv) * a.parts * cap;
+        uint32_t fillq[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+        if (k != 0u && n != 0u) {                          // population.rs:672
             const uint32_t stream = PS_STREAM_HGT | (c << 8);
-            for (uint32_t j = tid; j < k; j += blockDim.x) {
+            const uint32_t rounds = (k + blockDim.x - 1u) / blockDim.x;
+            for (uint32_t it = 0; it < rounds; it++) {
+                const uint32_t j = it * blockDim.x + tid;
+                const bool ok = j < k;
                 const ps_u4 r = ps_philox(j, dn, a.gen, stream, a.k0, a.k1);
                 uint32_t rc = ps_mulhi(r.y, d.N - 1u);
                 rc += (rc >= dn) ? 1u : 0u;                             // population.rs:618
                 const uint32_t gene = glist[ps_mulhi(r.z, n)];
-                atomicOr((unsigned long long *)&a.dstI[(uint64_t)rc * d.GW + (gene >> 6)], 1ull << (gene & 63u));
+                const uint32_t part = ps_mulhi(rc, a.part_magic);       // rc / rows_per_part
+                const uint32_t packed = ((rc - part * a.rows_per_part) << 16) | gene;
+                uint32_t pos = 0;
+#pragma unroll
+                for (uint32_t q = 0; q < 8u; q++) {
+                    if (q < a.parts) {
+                        const uint64_t m = __ballot(ok && part == q);
+                        const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                        pos = (part == q) ? fillq[q] + rank : pos;
+                        fillq[q] += (uint32_t)__popcll(m);
+                    }
+                }
+                if (ok && pos < cap) mybins[(uint64_t)part * cap + pos] = packed;
             }
+        }
+        uint32_t f = 0;
+#pragma unroll
+        for (uint32_t q = 0; q < 8u; q++) f = (lane == q) ? fillq[q] : f;
+        if (lane < a.parts) {
+            if (f > cap) { atomicOr(a.overflow_flag, 8u); f = cap; }
+            a.counts[((uint64_t)item * 4u + wv) * a.parts + lane] = f;
         }
     }
 }

@@ -187,6 +187,7 @@ struct ps_population {
     uint64_t hgt_scratch_cap = 0;
     uint32_t hgt_slices = 0;             // tuning: event slices of the LDS-partitioned HGT kernel (0 = choose)
     uint32_t hgt_events_per_thread = 0;  // light HGT kernel: 0 = whole chip, else narrow launch (set by ps_sim)
+    bool hgt_list_in_global = false;     // light HGT kernel: donor lists in global scratch (no LDS beside the block sweep)
     uint32_t *cnt = nullptr;
     int cur = 0;
     ps_acc_plan aplan{};
@@ -411,6 +412,8 @@ extern "C" int ps_set_tuning(ps_population *p, const char *key, int64_t value)
     } else if (k == "block_batch") {
         if (value != 0 && value != 2 && value != 4) return ps_fail(PS_ERR_INVALID, "block_batch must be 0 (choose), 2 or 4");
         p->block_batch = (uint32_t)value;
+    } else if (k == "hgt_list_in_global") {
+        p->hgt_list_in_global = value != 0;
     } else if (k == "no_block_preload") {
         p->no_block_preload = value != 0;
     } else if (k == "block_waves") {
@@ -821,7 +824,7 @@ static int launch_acc_hgt(ps_population *p, uint32_t gen, hipStream_t st)
         a.srcI = p->I[p->cur];          // the matrix is not edited before the reduce pass: it IS the snapshot
         a.dstI = p->I[p->cur];
         const uint32_t grid = std::min(items, 256u * 8u);
-        hipLaunchKernelGGL((acc_hgt_donor_kernel<true>), dim3(grid), dim3(256), list_lds, st, a);
+        hipLaunchKernelGGL(acc_hgt_donor_bin_kernel, dim3(grid), dim3(256), list_lds, st, a);
         auto kern = acc_hgt_apply_kernel;
         if (lds > 64 * 1024)
             HIPCHK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -836,15 +839,30 @@ static int launch_acc_hgt(ps_population *p, uint32_t gen, hipStream_t st)
         // beside a long core sweep (ps_sim sets hgt_events_per_thread) the kernel is launched narrow --
         // one-wave workgroups, a fixed number of events per thread over the generation: the same events
         // then disturb the sweep for longer but far less; stand-alone calls use the whole chip
-        uint32_t thr = 256, grid = std::min(items, 256u * 8u);
+        uint32_t grid = std::min(items, 256u * 32u);
         if (p->hgt_events_per_thread) {
-            thr = 64;
             const uint64_t want = (uint64_t)(expected / ((double)p->hgt_events_per_thread * 64.0)) + 1;
-            grid = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(want, 1), std::min(items, 256u * 32u));
+            grid = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(want, 1), grid);
         }
-        if (list_lds > 64 * 1024)
-            HIPCHK(hipFuncSetAttribute((const void *)acc_hgt_donor_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)list_lds));
-        hipLaunchKernelGGL((acc_hgt_donor_kernel<false>), dim3(grid), dim3(thr), list_lds, st, a);
+        uint32_t dyn_lds = list_lds;
+        if (p->hgt_list_in_global) {
+            // the co-running block sweep owns the CU's LDS: keep the donor lists in a per-workgroup
+            // global scratch instead (hot in L2; reads of a list come from the workgroup that wrote it)
+            const uint64_t need = (uint64_t)grid * max_comp * sizeof(uint16_t);
+            if (p->hgt_scratch_cap < need) {
+                if (p->hgt_scratch) HIPCHK(hipFree(p->hgt_scratch));
+                p->hgt_scratch = nullptr;
+                p->hgt_scratch_cap = 0;
+                HIPCHK(hipMalloc(&p->hgt_scratch, need));
+                p->hgt_scratch_cap = need;
+            }
+            a.list_scratch = (uint16_t *)p->hgt_scratch;
+            a.list_stride = max_comp;
+            dyn_lds = 0;
+        }
+        if (dyn_lds > 64 * 1024)
+            HIPCHK(hipFuncSetAttribute((const void *)acc_hgt_donor_wave_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn_lds));
+        hipLaunchKernelGGL(acc_hgt_donor_wave_kernel, dim3(grid), dim3(64), dyn_lds, st, a);
     }
     // rebuild the gene-major view from the individual-major one (one ballot per gene word)
     acc_i_to_g_kernel<<<dim3(p->d.W, p->d.GW), 64, 0, st>>>(p->I[p->cur], p->G[p->cur], p->d);
@@ -1701,6 +1719,13 @@ static int sim_create_impl(const ps_sim_params *p, ps_sim *s)
     if (p->max_distances > 0) {
         PSCHK(upload_pairs(s->core, p->max_distances, s->r1.data(), s->r2.data()));
         PSCHK(upload_pairs(s->acc, p->max_distances, s->r1.data(), s->r2.data()));
+    }
+    // a block sweep that fills the CU's LDS (cfg4 population) leaves none for the donor lists
+    if (!wave_sweep_eligible(s->core, true, p->HR_rate > 0.0)) {
+        core_block_geom g{};
+        uint32_t lds = 0, nw = 0;
+        if (block_sweep_geometry(s->core, true, true, p->HR_rate > 0.0, &g, &lds, &nw))
+            s->acc->hgt_list_in_global = lds + 16384u > s->core->lds_limit;
     }
     // light HGT co-runs with the sweep: launch it narrow when the sweep is long enough to hide it.
     // The chain of a generation is ~0.3 ms of latency-bound work plus ~2 us per event a thread handles

@@ -201,9 +201,10 @@ def test_acc_operators_match_oracle(pa, orc, N, G, comps, lm, lr):
     orc.recombine_acc(want2, seed, gen, cb, ce, lr)
     got2 = pop.read_matrix()
     assert np.array_equal(got2, want2)
-    for mode in (1, 2):               # atomic and binned HGT kernels apply the same keyed events
+    for mode in (1, 2, 3):            # atomic (lists in LDS / in global scratch) and binned HGT kernels agree
         alt = pa.Population(N, G, 2, False, 0.25, seed, 10)
-        alt.set_tuning("hgt_mode", mode)
+        alt.set_tuning("hgt_mode", min(mode, 2) if mode != 3 else 1)
+        alt.set_tuning("hgt_list_in_global", 1 if mode == 3 else 0)
         alt.set_rates(lm, lr, cb, ce)
         alt.load_matrix(want)
         alt.recombine(gen)
