@@ -148,9 +148,8 @@ struct acc_hgt_args {
     uint32_t *work_ctr;            // dynamic item counter (zeroed before the launch)
     uint32_t gen, k0, k1;
     // binned form (heavy HGT)
-    uint32_t *bins, *counts;       // bins: region of compartment c starts at bin_base[c]; cap bin_cap[c] per (donor, wave, part)
-    uint64_t bin_base[PS_MAX_COMP];
-    uint32_t bin_cap[PS_MAX_COMP];
+    uint32_t *bins, *counts;       // bins[(donor workgroup * parts + part) * bin_cap], counts[donor workgroup * parts + part]
+    uint32_t bin_cap;
     uint32_t parts, rows_per_part;
     uint32_t part_magic;           // floor(2^32 / rows_per_part) + 1: rc / rows_per_part = mulhi(rc, magic) for rc < 2^16
     uint32_t *scratch;             // slice images [n_slices][N][2*GW]
@@ -246,78 +245,62 @@ __global__ void __launch_bounds__(64) acc_hgt_donor_wave_kernel(acc_hgt_args a)
     }
 }
 
-// Heavy HGT, first pass: the events of an item are appended, packed (recipient row inside its
-// partition << 16 | gene), to bins per recipient partition; acc_hgt_apply_kernel ORs them into LDS
-// images.  Every wave of the 256-thread workgroup owns its bins of the item: the fill counters are
-// wave-uniform registers -- no atomics and no synchronisation between the waves in the event loop.
+// Heavy HGT (>= 1e7 expected events per generation), two passes without global atomics.  The
+// recipients are split into partitions whose rows fit an LDS image (cfg3: 4 partitions, cfg4: 202,
+// up to 1024).  First pass: workgroup b serves the items b, b + grid, ... and appends every event,
+// packed (recipient row inside its partition << 16 | gene), to ITS bin of the recipient's partition:
+// bins[(b * parts + part) * cap ...]; the position comes from a per-lane LDS atomic on the
+// workgroup's fill counters (parts * 4 bytes of LDS).  (Wave-aggregated appends -- one ballot per
+// partition -- were slower than one LDS atomic per lane even with 4 partitions.)
 __global__ void __launch_bounds__(256) acc_hgt_donor_bin_kernel(acc_hgt_args a)
 {
-    extern __shared__ __attribute__((aligned(16))) uint16_t glist[];   // present genes of the item's donor
-    __shared__ uint32_t sh_item, sh_n;
+    extern __shared__ __attribute__((aligned(16))) uint32_t sc_lds[];
+    uint32_t *fill = sc_lds;                                           // [parts]
+    uint16_t *glist = (uint16_t *)(sc_lds + ((a.parts + 3u) & ~3u));   // present genes of the item's donor
+    __shared__ uint32_t sh_n;
     const acc_dims d = a.d;
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
     const uint32_t items = a.n_comp * d.N;
-    for (;;) {
-        __syncthreads();                                   // everybody is done with the previous item
-        if (tid == 0) sh_item = atomicAdd(a.work_ctr, 1u);
-        __syncthreads();
-        const uint32_t item = sh_item;
-        if (item >= items) break;
+    const uint32_t cap = a.bin_cap;
+    uint32_t *mybins = a.bins + (uint64_t)blockIdx.x * a.parts * cap;
+    for (uint32_t q = tid; q < a.parts; q += blockDim.x) fill[q] = 0u;
+    for (uint32_t item = blockIdx.x; item < items; item += gridDim.x) {
+        __syncthreads();                                   // previous list is no longer read; fill[] is zeroed
         const uint32_t c = item / d.N, dn = item % d.N;
         const uint32_t k = a.kcnt[item];
-        uint32_t n = 0;
-        if (k != 0u) {
-            if (tid < 64u) {
-                const uint32_t m = ps_wave_gene_list(a.srcI + (uint64_t)dn * d.GW, d.GW, a.gb[c], a.ge[c], glist, lane);
-                if (tid == 0) sh_n = m;
-            }
-            __syncthreads();
-            n = sh_n;
+        if (k == 0u) continue;
+        if (tid < 64u) {
+            const uint32_t m = ps_wave_gene_list(a.srcI + (uint64_t)dn * d.GW, d.GW, a.gb[c], a.ge[c], glist, lane);
+            if (tid == 0) sh_n = m;
         }
-        const uint32_t wv = tid >> 6;
-        const uint32_t cap = a.bin_cap[c];
-        uint32_t *mybins = a.bins + a.bin_base[c] + ((uint64_t)dn * 4u + wv) * a.parts * cap;
-        uint32_t fillq[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
-        if (k != 0u && n != 0u) {                          // population.rs:672
-            const uint32_t stream = PS_STREAM_HGT | (c << 8);
-            const uint32_t rounds = (k + blockDim.x - 1u) / blockDim.x;
-            for (uint32_t it = 0; it < rounds; it++) {
-                const uint32_t j = it * blockDim.x + tid;
-                const bool ok = j < k;
-                const ps_u4 r = ps_philox(j, dn, a.gen, stream, a.k0, a.k1);
-                uint32_t rc = ps_mulhi(r.y, d.N - 1u);
-                rc += (rc >= dn) ? 1u : 0u;                             // population.rs:618
-                const uint32_t gene = glist[ps_mulhi(r.z, n)];
-                const uint32_t part = ps_mulhi(rc, a.part_magic);       // rc / rows_per_part
-                const uint32_t packed = ((rc - part * a.rows_per_part) << 16) | gene;
-                uint32_t pos = 0;
-#pragma unroll
-                for (uint32_t q = 0; q < 8u; q++) {
-                    if (q < a.parts) {
-                        const uint64_t m = __ballot(ok && part == q);
-                        const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-                        pos = (part == q) ? fillq[q] + rank : pos;
-                        fillq[q] += (uint32_t)__popcll(m);
-                    }
-                }
-                if (ok && pos < cap) mybins[(uint64_t)part * cap + pos] = packed;
-            }
+        __syncthreads();
+        const uint32_t n = sh_n;
+        if (n == 0u) continue;                             // population.rs:672
+        const uint32_t stream = PS_STREAM_HGT | (c << 8);
+        for (uint32_t j = tid; j < k; j += blockDim.x) {
+            const ps_u4 r = ps_philox(j, dn, a.gen, stream, a.k0, a.k1);
+            uint32_t rc = ps_mulhi(r.y, d.N - 1u);
+            rc += (rc >= dn) ? 1u : 0u;                                 // population.rs:618
+            const uint32_t gene = glist[ps_mulhi(r.z, n)];
+            const uint32_t part = ps_mulhi(rc, a.part_magic);           // rc / rows_per_part
+            const uint32_t pos = atomicAdd(&fill[part], 1u);
+            if (pos < cap) mybins[(uint64_t)part * cap + pos] = ((rc - part * a.rows_per_part) << 16) | gene;
         }
-        uint32_t f = 0;
-#pragma unroll
-        for (uint32_t q = 0; q < 8u; q++) f = (lane == q) ? fillq[q] : f;
-        if (lane < a.parts) {
-            if (f > cap) { atomicOr(a.overflow_flag, 8u); f = cap; }
-            a.counts[((uint64_t)item * 4u + wv) * a.parts + lane] = f;
-        }
+    }
+    __syncthreads();
+    for (uint32_t q = tid; q < a.parts; q += blockDim.x) {
+        uint32_t f = fill[q];
+        if (f > cap) { atomicOr(a.overflow_flag, 8u); f = cap; }
+        a.counts[(uint64_t)blockIdx.x * a.parts + q] = f;
     }
 }
 
-// heavy HGT, second pass: workgroup (part, slice) ORs the bins of its slice's items into an LDS
-// image of the partition's rows and publishes the image with plain coalesced stores;
-// acc_hgt_reduce_kernel then ORs the slice images into the matrix (64 slices x 40 K words of
-// atomics took longer than the events themselves)
-__global__ void __launch_bounds__(1024) acc_hgt_apply_kernel(acc_hgt_args a, uint32_t n_slices)
+// second pass: workgroup (part, slice) ORs bin `part` of the donor workgroups slice, slice +
+// n_slices, ... into an LDS image of the partition's rows (the four 256-thread quarters walk
+// different bins, four loads in flight per thread) and publishes the image with plain coalesced
+// stores; acc_hgt_reduce_kernel then ORs the slice images into the matrix (merging with atomics
+// took longer than the events themselves)
+__global__ void __launch_bounds__(1024) acc_hgt_apply_kernel(acc_hgt_args a, uint32_t donor_blocks, uint32_t n_slices)
 {
     extern __shared__ uint32_t lrow[];     // [rows_per_part][2*GW] 32-bit words
     const acc_dims d = a.d;
@@ -326,39 +309,20 @@ __global__ void __launch_bounds__(1024) acc_hgt_apply_kernel(acc_hgt_args a, uin
     const uint32_t W32 = 2u * d.GW;
     for (uint32_t w = threadIdx.x; w < a.rows_per_part * W32; w += blockDim.x) lrow[w] = 0u;
     __syncthreads();
-    // sub-item = (item, wave of the donor workgroup).  The four 256-thread quarters of this
-    // workgroup walk sub-items slice*4 + quarter, + 4*n_slices, ...: every slice gets its share of
-    // each compartment (the compartments differ 10-fold in events per donor)
-    const uint32_t subs = a.n_comp * d.N * 4u;
+    const uint32_t cap = a.bin_cap;
     const uint32_t quarter = threadIdx.x >> 8, qt = threadIdx.x & 255u;
-    const uint32_t stride = n_slices * 4u;
-    __shared__ uint32_t cnts[4][64];        // bin sizes of the next 64 sub-items of each quarter
-    for (uint32_t base = slice * 4u; base < subs; base += 64u * stride) {
-        __syncthreads();
-        if (qt < 64u) {
-            const uint32_t si = base + quarter + qt * stride;
-            cnts[quarter][qt] = si < subs ? a.counts[(uint64_t)si * a.parts + part] : 0u;
-        }
-        __syncthreads();
-        for (uint32_t i = 0; i < 64u; i++) {
-            const uint32_t si = base + quarter + i * stride;
-            if (si >= subs) break;
-            const uint32_t n = cnts[quarter][i];
-            if (n == 0u) continue;
-            const uint32_t item = si >> 2, wv = si & 3u;
-            const uint32_t c = item / d.N, dn = item % d.N;
-            const uint32_t *src = a.bins + a.bin_base[c] + (((uint64_t)dn * 4u + wv) * a.parts + part) * a.bin_cap[c];
-            // four loads in flight per thread (the loop is otherwise one global-load latency per entry)
-            for (uint32_t k = qt; k < n; k += 1024u) {
-                uint32_t v[4];
+    for (uint32_t bb = slice + quarter * n_slices; bb < donor_blocks; bb += 4u * n_slices) {
+        const uint32_t n = a.counts[(uint64_t)bb * a.parts + part];
+        const uint32_t *src = a.bins + ((uint64_t)bb * a.parts + part) * cap;
+        for (uint32_t k = qt; k < n; k += 1024u) {
+            uint32_t v[4];
 #pragma unroll
-                for (uint32_t u = 0; u < 4u; u++) v[u] = (k + 256u * u < n) ? src[k + 256u * u] : 0xFFFFFFFFu;
+            for (uint32_t u = 0; u < 4u; u++) v[u] = (k + 256u * u < n) ? src[k + 256u * u] : 0xFFFFFFFFu;
 #pragma unroll
-                for (uint32_t u = 0; u < 4u; u++) {
-                    if (k + 256u * u < n) {
-                        const uint32_t gene = v[u] & 0xFFFFu;
-                        atomicOr(&lrow[(v[u] >> 16) * W32 + (gene >> 5)], 1u << (gene & 31u));
-                    }
+            for (uint32_t u = 0; u < 4u; u++) {
+                if (k + 256u * u < n) {
+                    const uint32_t gene = v[u] & 0xFFFFu;
+                    atomicOr(&lrow[(v[u] >> 16) * W32 + (gene >> 5)], 1u << (gene & 31u));
                 }
             }
         }

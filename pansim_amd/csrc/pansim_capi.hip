@@ -780,33 +780,32 @@ static int launch_acc_hgt(ps_population *p, uint32_t gen, hipStream_t st)
     HIPCHK(hipMemsetAsync(a.work_ctr, 0, sizeof(uint32_t), st));
     acc_hgt_counts_kernel<<<(items + 255) / 256, 256, 0, st>>>(a);
 
-    // Heavy HGT (>= 1e7 expected events, cfg3) with a population whose rows fit <= 8 LDS partitions:
-    // two passes -- the donors' events are binned by recipient partition, then ORed into LDS images
-    // of the partitions and reduced into the matrix (no global atomics at all).  Otherwise one
-    // 64-bit atomicOr per event; that form needs only the donor list in LDS and co-runs with the sweep.
+    // Heavy HGT (>= 1e7 expected events per generation: cfg3, and every generation at the cfg4 / cfg5
+    // populations): two passes without global atomics -- the donors' events are binned by recipient
+    // partition, then ORed into LDS images of the partitions and reduced into the matrix.  Otherwise
+    // one 64-bit atomicOr per event; that form needs no static LDS and co-runs with the sweep.
     const uint64_t row_bytes = (uint64_t)p->d.GW * 8;
     const uint32_t parts = hgt_partitions(p);
-    const bool binned = (p->hgt_mode == 2 || (p->hgt_mode == 0 && expected >= 1.0e7)) && parts >= 1 && parts <= 8
-                        && p->d.G <= 65536u && (uint64_t)p->d.N * ((p->d.N + std::max(parts, 1u) - 1) / std::max(parts, 1u)) < (1ull << 32);
+    const uint32_t rpp = parts ? (p->d.N + parts - 1) / parts : 0;
+    const bool binned = parts >= 1 && parts <= 1024 && rpp >= 2 && p->d.G <= 65536u && (uint64_t)p->d.N * rpp < (1ull << 32)
+                        && (p->hgt_mode == 2 || (p->hgt_mode == 0 && expected >= 1.0e7))
+                        && list_lds + parts * 4u + 64u <= p->lds_limit;
     if (binned) {
         const uint32_t rows_per_part = (p->d.N + parts - 1) / parts;
         const uint32_t lds = (uint32_t)(rows_per_part * row_bytes);
-        const uint32_t n_slices = std::max(1u, p->hgt_slices ? p->hgt_slices : 256u / parts);
+        const uint32_t donor_blocks = std::min(items, 2048u);
+        const uint32_t n_slices = std::max(1u, p->hgt_slices ? p->hgt_slices : (512u + parts - 1) / parts);
         const uint64_t words = (uint64_t)p->d.N * p->d.GW;
         const uint64_t img_bytes = (uint64_t)n_slices * words * 8;
-        uint64_t bin_words = 0;
-        for (int c = 0; c < p->aplan.n_comp; c++) {
-            a.bin_base[c] = bin_words;
-            a.bin_cap[c] = 0;
-            if (!a.ptab[c]) continue;
-            // k_d <= kmax (the table's last value); a partition receives rows_per_part / (N - 1) of them
-            // (per wave of the donor's 4-wave workgroup: a quarter of them, dealt round-robin)
-            const double kmax = (double)(a.kmin[c] + a.plen[c] - 1u);
-            const double mean = (kmax / 4.0 + 64.0) * (double)rows_per_part / (double)(p->d.N - 1);
-            a.bin_cap[c] = (uint32_t)(((uint64_t)(mean + 10.0 * std::sqrt(mean) + 64.0) + 63) & ~63ull);
-            bin_words += (uint64_t)p->d.N * 4u * parts * a.bin_cap[c];
-        }
-        const uint64_t cnt_bytes = ((uint64_t)items * 4u * parts * 4 + 255) & ~255ull;
+        // events of a donor workgroup: Poisson with mean <= sum_c lambda_c * ceil(N / blocks); a partition
+        // receives rows_per_part / (N - 1) of them
+        double per_block = 0.0;
+        for (int c = 0; c < p->aplan.n_comp; c++)
+            if (a.ptab[c]) per_block += p->aplan.lam_rec[c] * (double)((p->d.N + donor_blocks - 1) / donor_blocks);
+        const double mean = per_block * (double)rows_per_part / (double)(p->d.N - 1);
+        const uint32_t cap = (uint32_t)(((uint64_t)(mean + 10.0 * std::sqrt(mean) + 64.0) + 63) & ~63ull);
+        const uint64_t bin_words = (uint64_t)donor_blocks * parts * cap;
+        const uint64_t cnt_bytes = ((uint64_t)donor_blocks * parts * 4 + 255) & ~255ull;
         const uint64_t need = img_bytes + bin_words * 4 + cnt_bytes;
         if (p->hgt_scratch_cap < need) {
             if (p->hgt_scratch) HIPCHK(hipFree(p->hgt_scratch));
@@ -821,14 +820,17 @@ static int launch_acc_hgt(ps_population *p, uint32_t gen, hipStream_t st)
         a.parts = parts;
         a.rows_per_part = rows_per_part;
         a.part_magic = (uint32_t)(4294967296ull / rows_per_part) + 1u;
-        a.srcI = p->I[p->cur];          // the matrix is not edited before the reduce pass: it IS the snapshot
+        a.bin_cap = cap;
+        a.srcI = p->I[p->cur];          // not edited before the reduce pass: it IS the snapshot
         a.dstI = p->I[p->cur];
-        const uint32_t grid = std::min(items, 256u * 8u);
-        hipLaunchKernelGGL(acc_hgt_donor_bin_kernel, dim3(grid), dim3(256), list_lds, st, a);
+        const uint32_t dlds = ((parts + 3u) & ~3u) * 4u + list_lds;
+        if (dlds > 64 * 1024)
+            HIPCHK(hipFuncSetAttribute((const void *)acc_hgt_donor_bin_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dlds));
+        hipLaunchKernelGGL(acc_hgt_donor_bin_kernel, dim3(donor_blocks), dim3(256), dlds, st, a);
         auto kern = acc_hgt_apply_kernel;
         if (lds > 64 * 1024)
             HIPCHK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(kern, dim3(parts * n_slices), dim3(1024), lds, st, a, n_slices);
+        hipLaunchKernelGGL(kern, dim3(parts * n_slices), dim3(1024), lds, st, a, donor_blocks, n_slices);
         acc_hgt_reduce_kernel<<<(uint32_t)((words + 255) / 256), 256, 0, st>>>((const uint64_t *)p->hgt_scratch,
                                                                               p->I[p->cur], words, n_slices);
     } else {
@@ -1740,10 +1742,10 @@ static int sim_create_impl(const ps_sim_params *p, ps_sim *s)
     }
     HIPCHK(hipEventCreateWithFlags(&s->ev_hgt, hipEventDisableTiming));
     {
-        // take turns only where the binned kernel applies (small populations: the recipients fit 8 LDS
-        // partitions); at cfg4 sizes HGT streams from HBM anyway and co-running was 5 % faster
+        // take turns where the binned HGT kernels are used (>= 1e7 expected events): their LDS images
+        // could not share a CU with the sweep anyway
         const uint32_t parts = hgt_partitions(s->acc);
-        s->heavy_hgt = (double)N * s->der.n_recombinations_pan_total >= 1.0e7 && parts >= 1 && parts <= 8;
+        s->heavy_hgt = (double)N * s->der.n_recombinations_pan_total >= 1.0e7 && parts >= 1 && parts <= 1024;
     }
     if (const char *e = getenv("PANSIM_HEAVY_HGT")) s->heavy_hgt = atoi(e) != 0;
     HIPCHK(hipHostMalloc(&s->h_num_genes, N * sizeof(int32_t), hipHostMallocMapped));

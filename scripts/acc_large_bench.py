@@ -13,7 +13,7 @@ import pansim_amd as pa  # noqa: E402
 
 N, G = int(sys.argv[1]) if len(sys.argv) > 1 else 65536, 4000
 idx = np.random.default_rng(0).integers(0, N, N).astype(np.uint32)
-for mode in (0, 1):
+for mode in (0, 1, 2):
     acc = pa.Population(N, G, 2, False, 0.25, 0, 2000)
     acc.set_tuning("hgt_mode", mode)
     acc.set_rates([3600.0, 400000.0], [2700.0, 299.99999999999994], [0, 3600], [3600, 4000])

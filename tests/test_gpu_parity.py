@@ -201,10 +201,15 @@ def test_acc_operators_match_oracle(pa, orc, N, G, comps, lm, lr):
     orc.recombine_acc(want2, seed, gen, cb, ce, lr)
     got2 = pop.read_matrix()
     assert np.array_equal(got2, want2)
-    for mode in (1, 2, 3):            # atomic (lists in LDS / in global scratch) and binned HGT kernels agree
+    # every HGT form applies the same keyed events: atomics (donor lists in LDS / in global scratch)
+    # and the binned two-pass form with one recipient partition and with ~N/21 partitions
+    row_bytes = 8 * ((G + 63) // 64)
+    for tune in ({"hgt_mode": 1}, {"hgt_mode": 1, "hgt_list_in_global": 1}, {"hgt_mode": 2},
+                 {"hgt_mode": 2, "lds_limit": min(160 * 1024, max(1024 + 21 * row_bytes, 2 * G + 8192))},
+                 {"hgt_mode": 2, "hgt_slices": 3}):
         alt = pa.Population(N, G, 2, False, 0.25, seed, 10)
-        alt.set_tuning("hgt_mode", min(mode, 2) if mode != 3 else 1)
-        alt.set_tuning("hgt_list_in_global", 1 if mode == 3 else 0)
+        for key, val in tune.items():
+            alt.set_tuning(key, val)
         alt.set_rates(lm, lr, cb, ce)
         alt.load_matrix(want)
         alt.recombine(gen)
