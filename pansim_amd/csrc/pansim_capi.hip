@@ -794,7 +794,8 @@ static int launch_acc_hgt(ps_population *p, uint32_t gen, hipStream_t st)
         const uint32_t rows_per_part = (p->d.N + parts - 1) / parts;
         const uint32_t lds = (uint32_t)(rows_per_part * row_bytes);
         const uint32_t donor_blocks = std::min(items, 2048u);
-        const uint32_t n_slices = std::max(1u, p->hgt_slices ? p->hgt_slices : (512u + parts - 1) / parts);
+        // ~1024 apply workgroups, at most 64 slice images (measured: cfg3 64 of 32/64/128, cfg4 5 of 2/3/5)
+        const uint32_t n_slices = std::max(1u, p->hgt_slices ? p->hgt_slices : std::min(64u, (1024u + parts - 1) / parts));
         const uint64_t words = (uint64_t)p->d.N * p->d.GW;
         const uint64_t img_bytes = (uint64_t)n_slices * words * 8;
         // events of a donor workgroup: Poisson with mean <= sum_c lambda_c * ceil(N / blocks); a partition
