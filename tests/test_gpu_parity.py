@@ -727,3 +727,23 @@ def test_long_run_stays_bit_exact(pa, orc, monkeypatch, kw, extra, gens, env):
         assert np.array_equal(sim.pan_genome.read_matrix(), ref.acc)
         assert np.array_equal(sim.core_genome.read_matrix(), ref.core)
     sim.close()
+
+
+def test_hgt_binned_auto_many_partitions(pa, orc):
+    # 1.2e7 expected events at N = 3000: the binned form is chosen by itself, with the real LDS
+    # limit (10 recipient partitions of 300 rows), and must still equal the oracle bit for bit
+    N, G = 3000, 4000
+    cb, ce = [0, 3600], [3600, 4000]
+    lr = [3600.0, 400.0]
+    rng = np.random.default_rng(5)
+    m0 = _rand_acc(rng, N, G, 0.3)
+    m0[7, :] = 0
+    pop = pa.Population(N, G, 2, False, 0.3, 11, 0)
+    pop.set_rates([0.0, 0.0], lr, cb, ce)
+    pop.load_matrix(m0)
+    pop.recombine(4)
+    want = m0.copy()
+    K = orc.recombine_acc(want, 11, 4, cb, ce, lr)
+    assert K > 1.1e7
+    assert np.array_equal(pop.read_matrix(), want)
+    pop.close()
