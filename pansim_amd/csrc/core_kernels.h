@@ -853,24 +853,34 @@ __device__ __forceinline__ void ps_nibble_pack8(const uint32_t *v, uint32_t (&ou
 template <int A>
 __global__ void __launch_bounds__(1024) core_pair_counts_tiled(
     const uint8_t *state, uint32_t N, uint32_t pitch, uint32_t rows, const uint32_t *r1,
-    const uint32_t *r2, const uint32_t *perm /* output slot of pair k, or null */, uint64_t P,
-    uint32_t *out, uint32_t W /* dwords per individual per tile */, uint32_t tiles_per_range,
-    uint32_t a_eff /* pairs per thread, <= A */)
+    const uint32_t *r2, const uint32_t *perm /* output slot of pair k, or null */,
+    const uint32_t *tstart, const uint32_t *tcount, uint32_t T_threads,
+    uint32_t *out, uint32_t W /* dwords per individual per tile */, uint32_t tiles_per_range)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t T[];
     const uint32_t RS4 = (W >> 2) + 1u;      // row stride in 16-byte units (odd: spreads the banks)
     const uint32_t tid = threadIdx.x;
-    // a thread owns a_eff CONSECUTIVE pairs of the list sorted by first individual: the first
-    // individual's string is re-read only when it changes (about once per thread)
-    const uint64_t kbase = ((uint64_t)blockIdx.y * blockDim.x + tid) * a_eff;
+    // Thread g owns pairs [tstart[g], tstart[g] + tcount[g]) of the list sorted by first individual,
+    // all with the SAME first individual (the host splits every run evenly over ceil(run / A)
+    // threads).  The first individual's 16-byte chunk is read once per chunk index and the compare
+    // loop has no data-dependent branch, so the second individuals' reads are issued in batches.
+    const uint32_t g = blockIdx.y * blockDim.x + tid;
+    const uint32_t start = g < T_threads ? tstart[g] : 0u;
+    const uint32_t count = g < T_threads ? tcount[g] : 0u;
+    const uint32_t ri = count ? r1[start] * RS4 : 0u;
+    // pairs of this wave beyond the lane's own count compare the row with itself (adds nothing);
+    // the loop stops at the wave's largest count
+    uint32_t wmax = count;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) wmax = max(wmax, (uint32_t)__shfl_xor((int)wmax, off, 64));
+    wmax = __builtin_amdgcn_readfirstlane(wmax);
     // per-pair counts of this workgroup's site range, two 16-bit counters per register (the host
     // keeps a range below 65536 / 2 sites)
-    uint32_t pij[A], acc[A / 2];
+    uint32_t pj[A], acc[A / 2];
 #pragma unroll
     for (int q = 0; q < A; q++) {
-        const uint64_t k = kbase + q;
         if (!(q & 1)) acc[q >> 1] = 0;
-        pij[q] = ((uint32_t)q < a_eff && k < P) ? (r1[k] * RS4) | ((r2[k] * RS4) << 16) : 0u;   // same row twice: adds nothing
+        pj[q] = ((uint32_t)q < count) ? r2[start + q] * RS4 : ri;
     }
     const uint4 *T4 = (const uint4 *)T;
     for (uint32_t t = 0; t < tiles_per_range; t++) {
@@ -906,27 +916,28 @@ __global__ void __launch_bounds__(1024) core_pair_counts_tiled(
         }
         __syncthreads();
         for (uint32_t w4 = 0; w4 < (W >> 2); w4++) {
-            uint4 x = make_uint4(0, 0, 0, 0);
-            uint32_t cur = 0xFFFFFFFFu;
+            const uint4 x = T4[ri + w4];
 #pragma unroll
-            for (int q = 0; q < A; q++) {
-                if ((uint32_t)q < a_eff) {
-                    const uint32_t ri = pij[q] & 0xFFFFu, rj = pij[q] >> 16;
-                    if (ri != cur) { x = T4[ri + w4]; cur = ri; }
-                    const uint4 y = T4[rj + w4];
-                    const uint32_t c = __popc(x.x ^ y.x) + __popc(x.y ^ y.y) + __popc(x.z ^ y.z) + __popc(x.w ^ y.w);
-                    acc[q >> 1] += (q & 1) ? (c << 16) : c;
+            for (int q0 = 0; q0 < A; q0 += 4) {
+                if ((uint32_t)q0 < wmax) {
+                    uint4 y[4];
+#pragma unroll
+                    for (int u = 0; u < 4; u++) y[u] = T4[pj[q0 + u] + w4];
+#pragma unroll
+                    for (int u = 0; u < 4; u++) {
+                        const uint32_t c = __popc(x.x ^ y[u].x) + __popc(x.y ^ y[u].y) + __popc(x.z ^ y[u].z) + __popc(x.w ^ y[u].w);
+                        acc[(q0 + u) >> 1] += ((q0 + u) & 1) ? (c << 16) : c;
+                    }
                 }
-                // keep at most 4 pairs' LDS reads in flight (the scheduler would hoist all A of them)
-                if ((q & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+                // keep one batch of 4 reads in flight (the scheduler would hoist all A of them)
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
     }
 #pragma unroll
     for (int q = 0; q < A; q++) {
-        const uint64_t k = kbase + q;
         const uint32_t c = (q & 1) ? (acc[q >> 1] >> 16) : (acc[q >> 1] & 0xFFFFu);
-        if ((uint32_t)q < a_eff && k < P && c) atomicAdd(&out[perm ? perm[k] : k], c);
+        if ((uint32_t)q < count && c) atomicAdd(&out[perm ? perm[start + q] : start + q], c);
     }
 }
 
