@@ -864,7 +864,9 @@ __global__ void __launch_bounds__(1024) core_pair_counts_tiled(
     // all with the SAME first individual (the host splits every run evenly over ceil(run / A)
     // threads).  The first individual's 16-byte chunk is read once per chunk index and the compare
     // loop has no data-dependent branch, so the second individuals' reads are issued in batches.
-    const uint32_t g = blockIdx.y * blockDim.x + tid;
+    // blockIdx.x = pair block, blockIdx.y = site range: the pair blocks of one site range are
+    // dispatched together, so that all but the first read their tiles from L2 / Infinity Cache
+    const uint32_t g = blockIdx.x * blockDim.x + tid;
     const uint32_t start = g < T_threads ? tstart[g] : 0u;
     const uint32_t count = g < T_threads ? tcount[g] : 0u;
     const uint32_t ri = count ? r1[start] * RS4 : 0u;
@@ -884,7 +886,7 @@ __global__ void __launch_bounds__(1024) core_pair_counts_tiled(
     }
     const uint4 *T4 = (const uint4 *)T;
     for (uint32_t t = 0; t < tiles_per_range; t++) {
-        const uint32_t s0 = (blockIdx.x * tiles_per_range + t) * W * 8u;
+        const uint32_t s0 = (blockIdx.y * tiles_per_range + t) * W * 8u;
         if (s0 >= rows) break;
         __syncthreads();
         // work item = (4 consecutive individuals, 16 consecutive sites): 16 independent dword

@@ -1220,7 +1220,7 @@ static int pair_counts_device(ps_population *p, uint64_t P, const uint32_t *d_r1
             ranges = std::max(ranges, (n_tiles + max_tpr - 1) / max_tpr);
             const uint32_t tpr = (n_tiles + ranges - 1) / ranges;
             ranges = (n_tiles + tpr - 1) / tpr;
-            hipLaunchKernelGGL(kern, dim3(ranges, pair_blocks), dim3(PT), lds, st, p->state, N, p->pitch,
+            hipLaunchKernelGGL(kern, dim3(pair_blocks, ranges), dim3(PT), lds, st, p->state, N, p->pitch,
                                rows, d_r1, d_r2, d_perm, d_r1 + 5 * P, d_r1 + 6 * P, p->pair_threads, d_a, W, tpr);
         } else {
             const uint32_t slices = std::max(1u, std::min(rows, 64u));
