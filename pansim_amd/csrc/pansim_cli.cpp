@@ -7,6 +7,7 @@
 #include <cstring>
 #include <map>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/pansim_hip.h"
@@ -93,6 +94,38 @@ static std::string fmt(double v)
     char buf[512];
     ps_fmt_f64(v, buf, sizeof buf);
     return buf;
+}
+
+// "<core>\t<acc>\n" per pair (main.rs:471-482).  The shortest-round-trip formatting of 2 P doubles
+// is the whole cost of the file at cfg5 (33.5 M lines), so chunks of pairs are formatted by the
+// host's threads into buffers that are then written in order.
+static void write_pairs_tsv(FILE *f, const std::vector<double> &cd, const std::vector<double> &ad)
+{
+    const uint64_t P = cd.size();
+    const uint64_t chunk = 1u << 16;
+    const uint64_t nchunks = (P + chunk - 1) / chunk;
+    const uint64_t hw = std::thread::hardware_concurrency();
+    const unsigned nthreads = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(std::min<uint64_t>(hw, nchunks), 32));
+    for (uint64_t c0 = 0; c0 < nchunks; c0 += nthreads) {
+        const unsigned n = (unsigned)std::min<uint64_t>(nthreads, nchunks - c0);
+        std::vector<std::string> out(n);
+        std::vector<std::thread> pool;
+        for (unsigned t = 0; t < n; t++)
+            pool.emplace_back([&, t] {
+                const uint64_t a = (c0 + t) * chunk, b = std::min(P, a + chunk);
+                std::string &o = out[t];
+                o.reserve((size_t)(b - a) * 40);
+                char buf[512];
+                for (uint64_t k = a; k < b; k++) {
+                    o.append(buf, (size_t)ps_fmt_f64(cd[k], buf, sizeof buf));
+                    o.push_back('\t');
+                    o.append(buf, (size_t)ps_fmt_f64(ad[k], buf, sizeof buf));
+                    o.push_back('\n');
+                }
+            });
+        for (auto &th : pool) th.join();
+        for (unsigned t = 0; t < n; t++) fwrite(out[t].data(), 1, out[t].size(), f);
+    }
 }
 
 #define CK(call)                                                        \
@@ -210,7 +243,7 @@ int main(int argc, char **argv)
             CK(ps_pairwise_distances(acc, P, r1, r2, ad.data()));
             FILE *f = fopen((outpref + ".tsv").c_str(), "w");
             if (!f) die(1, "Error: cannot create " + outpref + ".tsv");
-            for (uint64_t k = 0; k < P; k++) fprintf(f, "%s\t%s\n", fmt(cd[k]).c_str(), fmt(ad[k]).c_str());
+            write_pairs_tsv(f, cd, ad);
             fclose(f);
             std::vector<double> freqs(G + p.core_genes);
             CK(ps_gene_frequencies(acc, freqs.data()));
