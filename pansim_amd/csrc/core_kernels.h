@@ -833,6 +833,24 @@ __global__ void __launch_bounds__(256) core_csv_kernel(const uint8_t *state, uin
 // LDS reads.  Each pair keeps its partial count in a register across the tiles
 // of the block's site range; one atomicAdd per (range, pair).
 // ---------------------------------------------------------------------------
+// acc + popcount(x ^ y) over 16 bytes as a chain of four v_bcnt_u32_b32 (the instruction adds its
+// second operand: no separate v_add3)
+__device__ __forceinline__ uint32_t ps_bcnt_add(uint32_t v, uint32_t acc)
+{
+    uint32_t r;   // (the compiler re-associates popcount + add chains into v_bcnt x, 0 plus v_add3 trees)
+    asm("v_bcnt_u32_b32 %0, %1, %2" : "=v"(r) : "v"(v), "v"(acc));
+    return r;
+}
+
+__device__ __forceinline__ uint32_t ps_popc_acc4(const uint4 &x, const uint4 &y, uint32_t acc)
+{
+    acc = ps_bcnt_add(x.x ^ y.x, acc);
+    acc = ps_bcnt_add(x.y ^ y.y, acc);
+    acc = ps_bcnt_add(x.z ^ y.z, acc);
+    acc = ps_bcnt_add(x.w ^ y.w, acc);
+    return acc;
+}
+
 // Nibble strings of 4 individuals from 8 site rows: v[b] holds the bytes (alleles < 16) of
 // individuals 4*qd .. 4*qd+3 at site b; out[j] gets site b of individual j in bits 4b..4b+3.
 // Two rows share a byte (v_lshl_or), then a 4 x 4 byte transpose (8 v_perm).
@@ -927,8 +945,8 @@ __global__ void __launch_bounds__(1024) core_pair_counts_tiled(
                     for (int u = 0; u < 4; u++) y[u] = T4[pj[q0 + u] + w4];
 #pragma unroll
                     for (int u = 0; u < 4; u++) {
-                        const uint32_t c = __popc(x.x ^ y[u].x) + __popc(x.y ^ y[u].y) + __popc(x.z ^ y[u].z) + __popc(x.w ^ y[u].w);
-                        acc[(q0 + u) >> 1] += ((q0 + u) & 1) ? (c << 16) : c;
+                        if ((q0 + u) & 1) acc[(q0 + u) >> 1] += ps_popc_acc4(x, y[u], 0u) << 16;
+                        else acc[(q0 + u) >> 1] = ps_popc_acc4(x, y[u], acc[(q0 + u) >> 1]);
                     }
                 }
                 // keep one batch of 4 reads in flight (the scheduler would hoist all A of them)
@@ -1018,8 +1036,7 @@ __global__ void __launch_bounds__(256) core_allpairs_kernel(const uint8_t *state
                 const uint4 xa = TA[(ty + 16u * a) * RS4 + w4];
 #pragma unroll
                 for (int b = 0; b < 8; b++)
-                    acc[a][b] += __popc(xa.x ^ xb[b].x) + __popc(xa.y ^ xb[b].y) + __popc(xa.z ^ xb[b].z)
-                                 + __popc(xa.w ^ xb[b].w);
+                    acc[a][b] = ps_popc_acc4(xa, xb[b], acc[a][b]);
             }
         }
     }
