@@ -1746,11 +1746,6 @@ static int sim_create_impl(const ps_sim_params *p, ps_sim *s)
         for (int c = 0; c < d.n_comp; c++) lrec[c] = (p->HGT_rate > 0.0) ? d.n_recombinations_pan[c] : 0.0; // :462
         PSCHK(ps_set_rates(s->acc, d.n_comp, d.n_pan_mutations, lrec, d.comp_begin, d.comp_end));
     }
-    // Inside the generation loop the sweep shares the GPU with the accessory chain of the next
-    // generation: 6 resident workgroups per CU leave that chain 8 wave slots and 40 KB of LDS on
-    // every CU (the sweep's rows are assigned dynamically, so lower residency costs no tail).
-    // Measured at cfg2: 8 -> 1320-1370, 7 -> 1490, 6 -> 1620-1690, 5 -> 1620-1635 generations/s.
-    if (!getenv("PANSIM_SWEEP_BLOCKS_PER_CU")) s->core->sweep_blocks_per_cu = 6;
     s->r1.resize(p->max_distances);
     s->r2.resize(p->max_distances);
     PSCHK(ps_sample_pairs(p->seed, N, p->max_distances, s->r1.data(), s->r2.data())); // main.rs:413-427
@@ -1797,6 +1792,21 @@ static int sim_create_impl(const ps_sim_params *p, ps_sim *s)
         s->heavy_hgt = (double)N * s->der.n_recombinations_pan_total >= 1.0e7 && parts >= 1 && parts <= 1024;
     }
     if (const char *e = getenv("PANSIM_HEAVY_HGT")) s->heavy_hgt = atoi(e) != 0;
+    // Inside the generation loop the sweep shares the GPU with the accessory chain of the next
+    // generation: 7 resident workgroups per CU leave that chain 4 wave slots and 20 KB of LDS on
+    // every CU (the sweep's rows are assigned dynamically, so lower residency costs no tail).
+    // cfg2, with the narrow one-wave HGT kernel: 8 -> chain starves (1285), 7 -> 1830, 6 -> 1808,
+    // 5 -> 1680 generations/s (before that kernel 6 was the optimum: 7 -> 1490, 6 -> 1620-1690).
+    // When HGT and sweep take turns the sweep has the chip to itself: 8 (cfg3: 1292 / 1322 / 1352 at 6 / 7 / 8).
+    // A large accessory genome needs more room: the HGT kernel's donor list (2 bytes per gene of the
+    // largest compartment) must fit the LDS the sweep leaves (pan_genes 20000: 1463 / 1664 / 1684 at 7 / 6 / 5).
+    if (!getenv("PANSIM_SWEEP_BLOCKS_PER_CU")) {
+        uint64_t max_comp = 0;
+        for (int c = 0; c < d.n_comp; c++) max_comp = std::max<uint64_t>(max_comp, d.comp_end[c] - d.comp_begin[c]);
+        const uint64_t list_lds = 2 * max_comp;
+        if (list_lds > 36 * 1024) s->acc->hgt_list_in_global = true;
+        s->core->sweep_blocks_per_cu = s->heavy_hgt ? 8 : (list_lds <= 16 * 1024 ? 7 : 6);
+    }
     HIPCHK(hipHostMalloc(&s->h_num_genes, N * sizeof(int32_t), hipHostMallocMapped));
     HIPCHK(hipHostMalloc(&s->h_logw, N * sizeof(double), hipHostMallocMapped));
     HIPCHK(hipHostGetDevicePointer((void **)&s->m_num_genes, s->h_num_genes, 0));
