@@ -1773,7 +1773,7 @@ static int sim_create_impl(const ps_sim_params *p, ps_sim *s)
     }
     // light HGT co-runs with the sweep: launch it narrow when the sweep is long enough to hide it.
     // The chain of a generation is ~0.3 ms of latency-bound work plus ~1 us per event a thread handles
-    // in sequence; it is given half of what the sweep (estimated at 4.2 TB/s) leaves, at most 128
+    // in sequence; it is given half of what the sweep (estimated at 4.2 TB/s) leaves, at most 112
     // events per thread (cfg2, generations/s at 32 / 64 / 128 / 192 / 256 / 384 events per thread:
     // 1690 / 1736 / 1781 / 1775 / 1727 / 1480).  A short sweep leaves the accessory chain critical,
     // which wants the whole chip (0).  An adaptive controller (widen when the core stream is found
@@ -1781,7 +1781,7 @@ static int sim_create_impl(const ps_sim_params *p, ps_sim *s)
     {
         const double sweep_ms = 2.0 * (double)N * (double)s->core->cfg.ncols / 4.2e12 * 1e3;
         const double ept = (sweep_ms - 0.3) / 1.0e-3 * 0.5;
-        s->acc->hgt_events_per_thread = ept >= 16.0 ? (uint32_t)std::min(ept, 128.0) : 0u;
+        s->acc->hgt_events_per_thread = ept >= 16.0 ? (uint32_t)std::min(ept, 112.0) : 0u;   // (at 7 sweep blocks per CU: 96 / 112 / 128 / 160 / 192 -> 1785 / 1815 / 1821 / 1826 / 1700)
         if (const char *e = getenv("PANSIM_HGT_EVENTS_PER_THREAD")) s->acc->hgt_events_per_thread = (uint32_t)atoi(e);
     }
     HIPCHK(hipEventCreateWithFlags(&s->ev_hgt, hipEventDisableTiming));
