@@ -149,7 +149,8 @@ int ps_sync(ps_population *p);
  * (site rows a wave of that sweep takes per iteration, 2..4),
  * "force_block_sweep" (0/1: use the block sweep even when a row fits one wavefront),
  * "force_inline_sweep" (0/1: use the queue-free inline block sweep), "pair_mode" (core
- * distances: 0 = choose by cost, 1 = sampled-pair kernel, 2 = all-pairs tiles + lookup),
+ * distances: 0 = choose by cost, 1 = sampled-pair kernel, 2 = all-pairs tiles + lookup, 3 = sampled-pair
+ * kernel in its nibble form even for one-hot matrices),
  * "hgt_mode" (accessory recombination: 0 = choose, 1 = one atomic per event, 2 = two passes: bin
  * by recipient partition, OR in LDS images), "hgt_slices" (binned HGT: event slices, 0 = choose), "hgt_list_in_global" (0/1: donor gene lists in
  * global scratch instead of LDS),

@@ -871,9 +871,9 @@ __device__ __forceinline__ void ps_nibble_pack8(const uint32_t *v, uint32_t (&ou
 template <int A>
 __global__ void __launch_bounds__(1024) core_pair_counts_tiled(
     const uint8_t *state, uint32_t N, uint32_t pitch, uint32_t rows, const uint32_t *r1,
-    const uint32_t *r2, const uint32_t *perm /* output slot of pair k, or null */,
+    const uint32_t *r2, uint32_t P,
     const uint32_t *tstart, const uint32_t *tcount, uint32_t T_threads,
-    uint32_t *out, uint32_t W /* dwords per individual per tile */, uint32_t tiles_per_range)
+    uint32_t *out /* part[range][P] */, uint32_t W /* dwords per individual per tile */, uint32_t tiles_per_range)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t T[];
     const uint32_t RS4 = (W >> 2) + 1u;      // row stride in 16-byte units (odd: spreads the banks)
@@ -954,11 +954,157 @@ __global__ void __launch_bounds__(1024) core_pair_counts_tiled(
             }
         }
     }
+    // partial counts of this site range, in sorted pair order: part[range][P] (every sorted position
+    // belongs to exactly one thread, so plain stores; core_pair_reduce_kernel sums the ranges --
+    // one atomicAdd per (range, pair) was 2.6e7 atomics = 1.3 ms at cfg2)
+    uint32_t *part = out + (size_t)blockIdx.y * P;
 #pragma unroll
     for (int q = 0; q < A; q++) {
         const uint32_t c = (q & 1) ? (acc[q >> 1] >> 16) : (acc[q >> 1] & 0xFFFFu);
-        if ((uint32_t)q < count && c) atomicAdd(&out[perm ? perm[start + q] : start + q], c);
+        if ((uint32_t)q < count) part[start + q] = c;
     }
+}
+
+// ---------------------------------------------------------------------------
+// One-hot matrices (every byte is 1, 2, 4 or 8 -- the simulator's own states): two bits per site.
+// core_pack2_kernel writes the whole matrix once as tiles packed2[tile][individual][W] (16 sites per
+// dword, code = (b >> 1) - (b >> 3): 1,2,4,8 -> 0,1,2,3); core_pair_counts_packed2 then copies a
+// tile into LDS with plain 16-byte loads and counts differing sites: for d = x ^ y a site differs
+// iff one of its two bits is set, popcount((d | d >> 1) & 0x5555...).  The reference's byte
+// popcount of one-hot alleles is twice that (distances.rs:22-52), which is what is accumulated
+// into `out`.  Compared with the nibble form: half the LDS bytes per pair (the compare is LDS
+// bound) and the matrix is packed once instead of once per pair block.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t ps_code2(uint32_t v)     // four bytes -> four 2-bit codes, one per byte
+{
+    return ((v >> 1) & 0x7F7F7F7Fu) - ((v >> 3) & 0x1F1F1F1Fu);
+}
+
+// grid.x = tile; a workgroup packs 16*W sites x all N individuals through LDS and streams the tile out
+__global__ void __launch_bounds__(1024) core_pack2_kernel(const uint8_t *state, uint32_t N, uint32_t pitch,
+                                                          uint32_t rows, uint32_t *packed, uint32_t W)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t T[];      // [N][W]
+    const uint32_t tid = threadIdx.x;
+    const uint32_t s0 = blockIdx.x * W * 16u;
+    const uint32_t quads = (N + 3u) >> 2;
+    // work item = (4 consecutive individuals, 16 consecutive sites) -> one dword per individual
+    for (uint32_t it = tid; it < quads * W; it += blockDim.x) {
+        const uint32_t qd = it % quads, w = it / quads;
+        const uint32_t sb = min(s0 + 16u * w, rows - 1u);
+        const bool item_valid = s0 + 16u * w < rows;
+        const uint8_t *base = state + (size_t)sb * pitch + 4u * qd;
+        uint32_t v[16];
+#pragma unroll
+        for (int b = 0; b < 16; b++)
+            v[b] = *(const uint32_t *)(base + (size_t)min((uint32_t)b, rows - 1u - sb) * pitch);
+        if (sb + 16u > rows || !item_valid) {
+#pragma unroll
+            for (int b = 0; b < 16; b++)
+                if (!item_valid || sb + b >= rows) v[b] = 0u;
+        }
+        uint32_t t[4];
+#pragma unroll
+        for (int m = 0; m < 4; m++)      // byte j of t[m]: sites 4m .. 4m+3 of individual j
+            t[m] = ps_code2(v[4 * m]) | (ps_code2(v[4 * m + 1]) << 2) | (ps_code2(v[4 * m + 2]) << 4) | (ps_code2(v[4 * m + 3]) << 6);
+        const uint32_t a01 = __builtin_amdgcn_perm(t[1], t[0], 0x05010400u), b01 = __builtin_amdgcn_perm(t[1], t[0], 0x07030602u);
+        const uint32_t a23 = __builtin_amdgcn_perm(t[3], t[2], 0x05010400u), b23 = __builtin_amdgcn_perm(t[3], t[2], 0x07030602u);
+        const uint32_t o[4] = { __builtin_amdgcn_perm(a23, a01, 0x05040100u), __builtin_amdgcn_perm(a23, a01, 0x07060302u),
+                                __builtin_amdgcn_perm(b23, b01, 0x05040100u), __builtin_amdgcn_perm(b23, b01, 0x07060302u) };
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+            if (4u * qd + j < N) T[(4u * qd + j) * W + w] = o[j];
+    }
+    __syncthreads();
+    uint4 *dst = (uint4 *)(packed + (size_t)blockIdx.x * N * W);
+    for (uint32_t k = tid; k < N * (W >> 2); k += blockDim.x) dst[k] = ((const uint4 *)T)[k];
+}
+
+template <int A>
+__global__ void __launch_bounds__(1024) core_pair_counts_packed2(
+    const uint32_t *packed, uint32_t N, uint32_t n_tiles, const uint32_t *r1, const uint32_t *r2,
+    uint32_t P, const uint32_t *tstart, const uint32_t *tcount,
+    uint32_t T_threads, uint32_t *out /* part[range][P] */, uint32_t W, uint32_t tiles_per_range)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t T[];
+    const uint32_t RS4 = (W >> 2) + 1u;      // LDS row stride in 16-byte units (odd: spreads the banks)
+    const uint32_t tid = threadIdx.x;
+    // thread table, wave-uniform loop bound and pair order: see core_pair_counts_tiled
+    const uint32_t g = blockIdx.x * blockDim.x + tid;
+    const uint32_t start = g < T_threads ? tstart[g] : 0u;
+    const uint32_t count = g < T_threads ? tcount[g] : 0u;
+    const uint32_t ri = count ? r1[start] * RS4 : 0u;
+    uint32_t wmax = count;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) wmax = max(wmax, (uint32_t)__shfl_xor((int)wmax, off, 64));
+    wmax = __builtin_amdgcn_readfirstlane(wmax);
+    uint32_t pj[A], acc[A / 2];              // 16-bit halves: the host keeps a range below 65536 sites
+#pragma unroll
+    for (int q = 0; q < A; q++) {
+        if (!(q & 1)) acc[q >> 1] = 0;
+        pj[q] = ((uint32_t)q < count) ? r2[start + q] * RS4 : ri;
+    }
+    uint4 *T4 = (uint4 *)T;
+    for (uint32_t t = 0; t < tiles_per_range; t++) {
+        const uint32_t tile = blockIdx.y * tiles_per_range + t;
+        if (tile >= n_tiles) break;
+        __syncthreads();
+        // copy the packed tile into LDS, eight 16-byte loads in flight per thread (a load-store loop
+        // would pay one global-load latency per iteration: 8 x ~2 us per tile, as long as the compare)
+        const uint4 *src = (const uint4 *)(packed + (size_t)tile * N * W);
+        const uint32_t w4s = W >> 2, total = N * w4s;
+        const uint32_t sh = 31u - (uint32_t)__builtin_clz(w4s);          // w4s is a power of two
+        for (uint32_t k0 = tid; k0 < total; k0 += 8u * blockDim.x) {
+            uint4 buf[8];
+#pragma unroll
+            for (uint32_t u = 0; u < 8u; u++) buf[u] = src[min(k0 + u * blockDim.x, total - 1u)];
+#pragma unroll
+            for (uint32_t u = 0; u < 8u; u++) {
+                const uint32_t k = k0 + u * blockDim.x;
+                if (k < total) T4[(k >> sh) * RS4 + (k & (w4s - 1u))] = buf[u];
+            }
+        }
+        __syncthreads();
+        for (uint32_t w4 = 0; w4 < w4s; w4++) {
+            const uint4 x = T4[ri + w4];
+#pragma unroll
+            for (int q0 = 0; q0 < A; q0 += 4) {
+                if ((uint32_t)q0 < wmax) {
+                    uint4 y[4];
+#pragma unroll
+                    for (int u = 0; u < 4; u++) y[u] = T4[pj[q0 + u] + w4];
+#pragma unroll
+                    for (int u = 0; u < 4; u++) {
+                        uint32_t c = 0;
+                        uint32_t d;
+                        d = x.x ^ y[u].x; c = ps_bcnt_add((d | (d >> 1)) & 0x55555555u, c);
+                        d = x.y ^ y[u].y; c = ps_bcnt_add((d | (d >> 1)) & 0x55555555u, c);
+                        d = x.z ^ y[u].z; c = ps_bcnt_add((d | (d >> 1)) & 0x55555555u, c);
+                        d = x.w ^ y[u].w; c = ps_bcnt_add((d | (d >> 1)) & 0x55555555u, c);
+                        acc[(q0 + u) >> 1] += ((q0 + u) & 1) ? (c << 16) : c;
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+    uint32_t *part = out + (size_t)blockIdx.y * P;       // see core_pair_counts_tiled
+#pragma unroll
+    for (int q = 0; q < A; q++) {
+        const uint32_t c = (q & 1) ? (acc[q >> 1] >> 16) : (acc[q >> 1] & 0xFFFFu);
+        if ((uint32_t)q < count) part[start + q] = 2u * c;
+    }
+}
+
+// out[perm[k]] = sum over the site ranges of part[range][k]
+__global__ void __launch_bounds__(256) core_pair_reduce_kernel(const uint32_t *part, uint32_t ranges, uint32_t P,
+                                                               const uint32_t *perm, uint32_t *out)
+{
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= P) return;
+    uint32_t s = 0;
+    for (uint32_t r = 0; r < ranges; r++) s += part[(size_t)r * P + k];
+    out[perm ? perm[k] : k] = s;
 }
 
 // ---------------------------------------------------------------------------

@@ -177,6 +177,11 @@ struct ps_population {
     uint32_t pitch = 0, cpr = 0;
     ps_core_plan cplan{};
     bool nibble_safe = true;
+    bool onehot_safe = true;         // every byte is 1, 2, 4 or 8 (true for simulated states; checked on load)
+    uint32_t *d_pack2 = nullptr;     // 2-bit packed copy of the matrix for the sampled-pair distances
+    uint32_t *d_pair_part = nullptr; // partial pair counts per site range (tiled distance kernels)
+    uint64_t pair_part_cap = 0;
+    uint64_t pack2_cap = 0;
     // accessory: bit-packed, two views, ping-pong
     acc_dims d{};
     uint64_t *G[2] = { nullptr, nullptr };
@@ -232,7 +237,7 @@ extern "C" void ps_population_destroy(ps_population *p)
     (void)hipSetDevice(p->device);
     if (p->stream) (void)hipStreamSynchronize(p->stream);
     void *ptrs[] = { p->state, p->G[0], p->G[1], p->I[0], p->I[1], p->d_ptab[0], p->d_ptab[1], p->hgt_scratch, p->cnt, p->d_idx, p->d_idxT, p->d_work,
-                     p->d_log1p, p->d_num_genes, p->d_logw, p->d_pairs, p->d_H, p->d_Dt };
+                     p->d_log1p, p->d_num_genes, p->d_logw, p->d_pairs, p->d_H, p->d_Dt, p->d_pack2, p->d_pair_part };
     for (void *q : ptrs)
         if (q) (void)hipFree(q);
     if (p->h_flag) (void)hipHostFree(p->h_flag);
@@ -401,7 +406,7 @@ extern "C" int ps_set_tuning(ps_population *p, const char *key, int64_t value)
         if (value < 0 || value > 2) return ps_fail(PS_ERR_INVALID, "hgt_mode must be 0 (auto), 1 (one atomic per event) or 2 (binned by recipient partition, two passes)");
         p->hgt_mode = (int)value;
     } else if (k == "pair_mode") {
-        if (value < 0 || value > 2) return ps_fail(PS_ERR_INVALID, "pair_mode must be 0 (auto), 1 (sampled) or 2 (all pairs)");
+        if (value < 0 || value > 3) return ps_fail(PS_ERR_INVALID, "pair_mode must be 0 (auto), 1 (sampled), 2 (all pairs) or 3 (sampled, nibble form even for one-hot matrices)");
         p->pair_mode = (int)value;
     } else if (k == "force_block_sweep") {
         p->force_block_sweep = value != 0;
@@ -443,9 +448,14 @@ extern "C" int ps_load_matrix(ps_population *p, const uint8_t *rows)
     HIPCHK(hipMemcpyAsync(d_rows, rows, N * C, hipMemcpyHostToDevice, p->stream));
     if (p->cfg.core) {
         bool safe = true;
-        for (uint64_t k = 0; k < N * C; k++)
-            if (rows[k] > 15) { safe = false; break; }
+        bool onehot = true;
+        for (uint64_t k = 0; k < N * C; k++) {
+            const uint8_t b = rows[k];
+            if (b > 15) { safe = false; onehot = false; break; }
+            if (b != 1 && b != 2 && b != 4 && b != 8) onehot = false;
+        }
         p->nibble_safe = safe;
+        p->onehot_safe = onehot;
         dim3 grid((uint32_t)((C + 63) / 64), (uint32_t)((p->pitch + 63) / 64));
         core_transpose_kernel<true><<<grid, 256, 0, p->stream>>>(p->state, d_rows, (uint32_t)N,
                                                                  p->pitch, C);
@@ -1165,6 +1175,20 @@ static int upload_pairs(ps_population *p, uint64_t P, const uint32_t *r1, const 
     return PS_OK;
 }
 
+// partial counts of the tiled distance kernels, part[range][P]
+static int pair_partials(ps_population *p, uint64_t words, uint32_t **out)
+{
+    if (p->pair_part_cap < words) {
+        if (p->d_pair_part) HIPCHK(hipFree(p->d_pair_part));
+        p->d_pair_part = nullptr;
+        p->pair_part_cap = 0;
+        HIPCHK(hipMalloc(&p->d_pair_part, words * sizeof(uint32_t)));
+        p->pair_part_cap = words;
+    }
+    *out = p->d_pair_part;
+    return PS_OK;
+}
+
 static int pair_counts_device(ps_population *p, uint64_t P, const uint32_t *d_r1, const uint32_t *d_r2,
                               const uint32_t *d_perm, uint32_t *d_a, uint32_t *d_b, hipStream_t st)
 {
@@ -1182,7 +1206,7 @@ static int pair_counts_device(ps_population *p, uint64_t P, const uint32_t *d_r1
         // worse constant (it re-packs the matrix once per 32768 pairs): measured crossover at
         // N = 1000 is P ~ 250 k = half of all pairs
         const double all_pairs = 0.5 * (double)N * (double)N;
-        const bool use_all = p->nibble_safe && p->pair_mode != 1 && (uint64_t)N * N * 4 <= (8ull << 30)
+        const bool use_all = p->nibble_safe && p->pair_mode != 1 && p->pair_mode != 3 && (uint64_t)N * N * 4 <= (8ull << 30)
                              && (p->pair_mode == 2 || (double)P * 2.0 > all_pairs || !W);
         if (use_all) {
             const uint32_t WA = 32u, ntile = (N + 127u) / 128u;
@@ -1203,6 +1227,39 @@ static int pair_counts_device(ps_population *p, uint64_t P, const uint32_t *d_r1
             core_allpairs_kernel<<<dim3(tile_pairs, ranges), 256, lds, st>>>(p->state, N, p->pitch, rows, p->d_H, WA,
                                                                           cpr, ntile);
             core_pair_lookup_kernel<<<(uint32_t)((P + 255) / 256), 256, 0, st>>>(p->d_H, N, d_r1, d_r2, d_perm, P, d_a);
+        } else if (p->onehot_safe && W && p->pair_mode != 3) {
+            // one-hot matrix: pack it once at 2 bits per site, then compare from packed tiles
+            constexpr int A = 32;
+            constexpr uint32_t PT = 1024;
+            const uint32_t n_tiles = (rows + W * 16 - 1) / (W * 16);
+            const uint64_t need = (uint64_t)n_tiles * N * W;
+            if (p->pack2_cap < need) {
+                if (p->d_pack2) HIPCHK(hipFree(p->d_pack2));
+                p->d_pack2 = nullptr;
+                p->pack2_cap = 0;
+                HIPCHK(hipMalloc(&p->d_pack2, need * sizeof(uint32_t)));
+                p->pack2_cap = need;
+            }
+            const uint32_t pack_lds = N * W * 4u;
+            if (pack_lds > 64 * 1024)
+                HIPCHK(hipFuncSetAttribute((const void *)core_pack2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pack_lds));
+            hipLaunchKernelGGL(core_pack2_kernel, dim3(n_tiles), dim3(PT), pack_lds, st, p->state, N, p->pitch, rows, p->d_pack2, W);
+            const uint32_t lds = N * ((W >> 2) + 1u) * 16u;
+            auto kern = core_pair_counts_packed2<A>;
+            if (lds > 64 * 1024)
+                HIPCHK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            const uint32_t pair_blocks = std::max(1u, (p->pair_threads + PT - 1) / PT);
+            uint32_t ranges = std::max(1u, std::min(n_tiles, (256u * 4u + pair_blocks - 1) / pair_blocks));
+            // the kernel counts a range in 16 bits: fewer than 65536 sites per range
+            const uint32_t max_tpr = std::max(1u, 65535u / (W * 16u));
+            ranges = std::max(ranges, (n_tiles + max_tpr - 1) / max_tpr);
+            const uint32_t tpr = (n_tiles + ranges - 1) / ranges;
+            ranges = (n_tiles + tpr - 1) / tpr;
+            uint32_t *part = nullptr;
+            PSCHK(pair_partials(p, (uint64_t)ranges * P, &part));
+            hipLaunchKernelGGL(kern, dim3(pair_blocks, ranges), dim3(PT), lds, st, p->d_pack2, N, n_tiles, d_r1, d_r2,
+                               (uint32_t)P, d_r1 + 5 * P, d_r1 + 6 * P, p->pair_threads, part, W, tpr);
+            core_pair_reduce_kernel<<<(uint32_t)((P + 255) / 256), 256, 0, st>>>(part, ranges, (uint32_t)P, d_perm, d_a);
         } else if (p->nibble_safe && W) {
             constexpr int A = 32;
             constexpr uint32_t PT = 1024;
@@ -1220,8 +1277,11 @@ static int pair_counts_device(ps_population *p, uint64_t P, const uint32_t *d_r1
             ranges = std::max(ranges, (n_tiles + max_tpr - 1) / max_tpr);
             const uint32_t tpr = (n_tiles + ranges - 1) / ranges;
             ranges = (n_tiles + tpr - 1) / tpr;
+            uint32_t *part = nullptr;
+            PSCHK(pair_partials(p, (uint64_t)ranges * P, &part));
             hipLaunchKernelGGL(kern, dim3(pair_blocks, ranges), dim3(PT), lds, st, p->state, N, p->pitch,
-                               rows, d_r1, d_r2, d_perm, d_r1 + 5 * P, d_r1 + 6 * P, p->pair_threads, d_a, W, tpr);
+                               rows, d_r1, d_r2, (uint32_t)P, d_r1 + 5 * P, d_r1 + 6 * P, p->pair_threads, part, W, tpr);
+            core_pair_reduce_kernel<<<(uint32_t)((P + 255) / 256), 256, 0, st>>>(part, ranges, (uint32_t)P, d_perm, d_a);
         } else {
             const uint32_t slices = std::max(1u, std::min(rows, 64u));
             const uint32_t rps = (rows + slices - 1) / slices;

@@ -272,12 +272,13 @@ def test_pairwise_core(pa, orc, N, L, P):
 
 @pytest.mark.parametrize("N,L,P", [(100, 1203, 5000), (1000, 777, 40000), (300, 5000, 1000), (1500, 333, 2000)])
 def test_pairwise_core_kernels_agree(pa, orc, N, L, P):
-    # sampled-pair kernel and all-pairs tiles + lookup give the same integers
+    # sampled-pair kernels (2-bit packed form for one-hot matrices, nibble form) and all-pairs
+    # tiles + lookup give the same integers
     rng = np.random.default_rng(N + L)
     m = _rand_core(rng, N, L)
     r1, r2 = orc.sample_pairs(5, N, P)
     want = orc.pairwise_hamming_counts(m, 0, L, r1, r2)
-    for mode in (1, 2):
+    for mode in (1, 2, 3):
         pop = pa.Population(N, L, 4, True, 0.0, 0, 0)
         pop.set_tuning("pair_mode", mode)
         pop.load_matrix(m)
