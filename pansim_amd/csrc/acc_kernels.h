@@ -158,10 +158,16 @@ struct acc_hgt_args {
     uint32_t list_stride;
 };
 
-// k_d for every (compartment, donor): kmin + number of thresholds <= u (ps_poisson_table)
-__global__ void __launch_bounds__(256) acc_hgt_counts_kernel(acc_hgt_args a)
+// k_d for every (compartment, donor): kmin + number of thresholds <= u (ps_poisson_table).
+// The light form also takes its snapshot copy of the matrix here (copy_src -> copy_dst, grid-stride)
+// instead of a separate blit beside the sweep.
+__global__ void __launch_bounds__(256) acc_hgt_counts_kernel(acc_hgt_args a, const uint64_t *copy_src, uint64_t *copy_dst)
 {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (copy_dst) {
+        const uint64_t words = (uint64_t)a.d.N * a.d.GW;
+        for (uint64_t w = t; w < words; w += (uint64_t)gridDim.x * blockDim.x) copy_dst[w] = copy_src[w];
+    }
     if (t >= a.n_comp * a.d.N) return;
     const uint32_t c = t / a.d.N, dn = t % a.d.N;
     uint32_t k = 0;

@@ -789,7 +789,6 @@ static int launch_acc_hgt(ps_population *p, uint32_t gen, hipStream_t st)
     if (list_lds > p->lds_limit)
         return ps_fail(PS_ERR_INVALID, "a compartment of %u genes needs %u bytes of LDS (limit %u)", max_comp, list_lds, p->lds_limit);
     HIPCHK(hipMemsetAsync(a.work_ctr, 0, sizeof(uint32_t), st));
-    acc_hgt_counts_kernel<<<(items + 255) / 256, 256, 0, st>>>(a);
 
     // Heavy HGT (>= 1e7 expected events per generation: cfg3, and every generation at the cfg4 / cfg5
     // populations): two passes without global atomics -- the donors' events are binned by recipient
@@ -801,6 +800,12 @@ static int launch_acc_hgt(ps_population *p, uint32_t gen, hipStream_t st)
     const bool binned = parts >= 1 && parts <= 1024 && rpp >= 2 && p->d.G <= 65536u && (uint64_t)p->d.N * rpp < (1ull << 32)
                         && (p->hgt_mode == 2 || (p->hgt_mode == 0 && expected >= 1.0e7))
                         && list_lds + parts * 4u + 64u <= p->lds_limit;
+    // event counts per donor; the light form's snapshot copy rides along (donors read the
+    // pre-recombination matrix, population.rs:693-695, while recipients are edited in place)
+    {
+        const uint32_t blocks = std::max((items + 255) / 256, binned ? 1u : 64u);
+        acc_hgt_counts_kernel<<<blocks, 256, 0, st>>>(a, binned ? nullptr : p->I[p->cur], binned ? nullptr : p->I[1 - p->cur]);
+    }
     if (binned) {
         const uint32_t rows_per_part = (p->d.N + parts - 1) / parts;
         const uint32_t lds = (uint32_t)(rows_per_part * row_bytes);
@@ -846,9 +851,7 @@ static int launch_acc_hgt(ps_population *p, uint32_t gen, hipStream_t st)
         acc_hgt_reduce_kernel<<<(uint32_t)((words + 255) / 256), 256, 0, st>>>((const uint64_t *)p->hgt_scratch,
                                                                               p->I[p->cur], words, n_slices);
     } else {
-        // donors read a snapshot copy (population.rs:693-695) while recipients are edited in place
-        HIPCHK(hipMemcpyAsync(p->I[1 - p->cur], p->I[p->cur], (size_t)p->d.N * p->d.GW * 8, hipMemcpyDeviceToDevice, st));
-        a.srcI = p->I[1 - p->cur];
+        a.srcI = p->I[1 - p->cur];          // the snapshot written by acc_hgt_counts_kernel
         a.dstI = p->I[p->cur];
         // beside a long core sweep (ps_sim sets hgt_events_per_thread) the kernel is launched narrow --
         // one-wave workgroups, a fixed number of events per thread over the generation: the same events
