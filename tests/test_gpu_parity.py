@@ -748,3 +748,20 @@ def test_hgt_binned_auto_many_partitions(pa, orc):
     assert K > 1.1e7
     assert np.array_equal(pop.read_matrix(), want)
     pop.close()
+
+
+def test_spec_regression_vectors_on_gpu(pa):
+    # the frozen vectors of tests/golden/spec_regression.json, reproduced by the HIP path alone
+    import json, os, zlib
+    fx = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "spec_regression.json")))
+    crc = lambda a: zlib.crc32(np.ascontiguousarray(a).view(np.uint8))
+    for s in fx["sims"]:
+        sim = pa.Simulation(pa.make_params(seed=s["seed"], n_gen=len(s["generations"]), max_distances=10,
+                                           **s["params"], **s["extra"]))
+        for g, want in enumerate(s["generations"]):
+            sim.run(1)
+            sim.sync()
+            assert crc(sim.last_parents()) == want["parents_crc"]
+            assert crc(sim.core_genome.read_matrix()) == want["core_crc"]
+            assert crc(sim.pan_genome.read_matrix()) == want["acc_crc"]
+        sim.close()

@@ -208,3 +208,26 @@ def test_selection_coefficients(orc):
     assert abs(pos.mean() - 0.1) < 0.01                     # Exp(10) mean
     assert (neg >= -1.0).all()                              # redrawn while > 1.0 (main.rs:309-311)
     assert abs(-neg.mean() - (0.2 - 1.0 * math.exp(-5) / (1 - math.exp(-5)))) < 0.02
+
+
+def test_spec_regression_vectors(orc):
+    # the build's own keyed specification, frozen by tests/golden/make_spec_regression.py: a change
+    # of a stream, counter layout or threshold rule must be deliberate (regenerate the fixture)
+    import json, os, sys, zlib
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, here)
+    from orc_sim import OracleSim
+    fx = json.load(open(os.path.join(here, "golden", "spec_regression.json")))
+    crc = lambda a: zlib.crc32(np.ascontiguousarray(a).view(np.uint8))
+    for t in fx["poisson_tables"]:
+        kmin, thr = orc.poisson_table(t["lambda"])
+        assert (kmin, len(thr), int(thr[0]), int(thr[len(thr) // 2]), int(thr[-1]), crc(thr)) == \
+               (t["kmin"], t["len"], t["first"], t["middle"], t["last"], t["crc"])
+    for s in fx["sims"]:
+        sim = OracleSim(seed=s["seed"], **s["params"], **s["extra"])
+        for g, want in enumerate(s["generations"]):
+            sim.generation(g)
+            assert (crc(sim.last_idx), crc(sim.core), crc(sim.acc)) == (want["parents_crc"], want["core_crc"], want["acc_crc"])
+        assert [int(x) for x in sim.last_idx[:8]] == s["first_parents"]
+        assert [int(x) for x in sim.core[0, :16]] == s["core_row0"]
+        assert [int(x) for x in sim.acc[0, :16]] == s["acc_row0"]
