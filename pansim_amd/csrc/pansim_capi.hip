@@ -1729,6 +1729,7 @@ struct ps_sim {
     uint32_t *m_idx[PS_RING] = {};         // device alias of h_idx
     hipEvent_t ev_idx[PS_RING] = {}, ev_core[PS_RING] = {};
     hipEvent_t ev_hgt = nullptr;
+    hipEvent_t ev_gap[PS_RING][2] = {};   // timestamped events around the sweep when timing is off
     bool heavy_hgt = false;             // expected HGT events per generation >= 1e7: HGT and sweep take turns
     bool slot_used[PS_RING] = {};
     int32_t *h_num_genes = nullptr, *m_num_genes = nullptr;   // pinned + its device alias
@@ -1754,6 +1755,7 @@ extern "C" void ps_sim_destroy(ps_sim *s)
         if (s->ev_idx[k]) (void)hipEventDestroy(s->ev_idx[k]);
         if (s->ev_core[k]) (void)hipEventDestroy(s->ev_core[k]);
         if (k == 0 && s->ev_hgt) (void)hipEventDestroy(s->ev_hgt);
+        for (int j = 0; j < 2; j++) if (s->ev_gap[k][j]) (void)hipEventDestroy(s->ev_gap[k][j]);
     }
     if (s->h_num_genes) (void)hipHostFree(s->h_num_genes);
     if (s->h_logw) (void)hipHostFree(s->h_logw);
@@ -1962,11 +1964,23 @@ static int sim_one_generation(ps_sim *s, uint32_t gen)
         PSCHK(take(&t0));
         PSCHK(take(&t1));
         HIPCHK(hipEventRecord(t0, sc));
+    } else {
+        // Two timestamped events around every sweep even when nobody reads them (a ring of 2 per
+        // slot): with them consecutive sweeps do not chain back to back and the accessory kernels of
+        // the next generation get their CU slots sooner -- measured 1815 / 1806 generations/s with the
+        // events against 1784 / 1754 without (cfg2, 300 generations).
+        if (!s->ev_gap[slot][0]) {
+            HIPCHK(hipEventCreate(&s->ev_gap[slot][0]));
+            HIPCHK(hipEventCreate(&s->ev_gap[slot][1]));
+        }
+        HIPCHK(hipEventRecord(s->ev_gap[slot][0], sc));
     }
     PSCHK(step_device(core, s->d_idx[slot], gen, true, true, p.HR_rate > 0.0, sc));
     if (s->timing) {
         HIPCHK(hipEventRecord(t1, sc));
         s->tev.emplace_back(t0, t1);
+    } else {
+        HIPCHK(hipEventRecord(s->ev_gap[slot][1], sc));
     }
     HIPCHK(hipEventRecord(s->ev_core[slot], sc));
     // HGT is enqueued after the sweep so that the sweep's launch is not queued behind it
