@@ -28,13 +28,13 @@ for N, L in ((2048, 600000), (8192, 150000), (65536, 18000)):
     print(json.dumps({"op": "core.step block sweep", "N": N, "L": L, "ms": dt * 1e3, "GBps": 2.0 * N * L / dt / 1e9}), flush=True)
     core.close()
 # whole loop at N=8192 (cfg5 population) with a short genome
-sim = pa.Simulation(pa.make_params(pop_size=8192, core_size=150000, seed=0, n_gen=10, max_distances=100000))
-sim.run(2)
+sim = pa.Simulation(pa.make_params(pop_size=8192, core_size=150000, seed=0, n_gen=40, max_distances=100000))
+sim.run(10)            # (the first generations allocate the HGT scratch)
 sim.sync()
 t0 = time.perf_counter()
-sim.run(5)
+sim.run(30)
 sim.sync()
-dt = (time.perf_counter() - t0) / 5
+dt = (time.perf_counter() - t0) / 30
 print(json.dumps({"op": "generation loop", "N": 8192, "L": 150000, "ms_per_gen": dt * 1e3}), flush=True)
 t0 = time.perf_counter()
 c, a = sim.final_distances()
