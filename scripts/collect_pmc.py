@@ -15,18 +15,20 @@ import json
 import sys
 
 src, dst = sys.argv[1], sys.argv[2]
+kname = sys.argv[3] if len(sys.argv) > 3 else "core_sweep_wave_kernel"      # kernel name filter
+workload = sys.argv[4] if len(sys.argv) > 4 else "N=1000 L=1200000 lam_mut=60000 lam_hr=3000"
 agg = collections.defaultdict(list)
 dur = []
 for f in glob.glob(src + "/pmc_*/**/*_counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
-        if "core_sweep_wave_kernel" in r["Kernel_Name"]:
+        if kname in r["Kernel_Name"]:
             agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
 for f in glob.glob(src + "/pmc_*/**/*_kernel_trace.csv", recursive=True):
     for r in csv.DictReader(open(f)):
-        if "core_sweep_wave_kernel" in r["Kernel_Name"]:
+        if kname in r["Kernel_Name"]:
             dur.append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
 mean = {k: sum(v) / len(v) for k, v in agg.items()}
-out = {"kernel": "core_sweep_wave_kernel<3,true,true,true>", "workload": "N=1000 L=1200000 lam_mut=60000 lam_hr=3000",
+out = {"kernel": kname + "<gather,mutate,HR>", "workload": workload,
        "counters_mean_per_launch": mean, "launches_per_counter": {k: len(v) for k, v in agg.items()},
        "mean_kernel_us_under_pmc": sum(dur) / max(len(dur), 1)}
 if "FETCH_SIZE" in mean and "WRITE_SIZE" in mean:
