@@ -107,5 +107,48 @@ for t in range(trials):
             bad += 1
             print("SWEEP ERROR", t, N, L, lm, lh, tune, e, flush=True)
     core.close()
+    # ---- whole generation loop (every 5th trial): random parameters, 4 generations without host sync
+    if t % 5 == 0:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        from orc_sim import OracleSim
+        N = int(rng.choice([2, 9, 64, 200, 1030, 2100]))
+        L = int(rng.choice([1, 17, 300, 1500]))
+        cg = int(rng.choice([0, 5, 40]))
+        pg = cg + int(rng.choice([0, 1, 64, 500]))
+        if pg == 0:
+            pg, cg = 10, 10
+        kw = dict(pop_size=N, core_size=L, pan_genes=pg, core_genes=cg, HR_rate=float(rng.choice([0.0, 0.05, 0.6])),
+                  HGT_rate=float(rng.choice([0.0, 0.05, 0.6])), avg_gene_freq=float(rng.choice([0.3, 0.5, 0.9])))
+        extra = {}
+        if rng.random() < 0.4:
+            extra["prop_positive"] = float(rng.choice([0.0, 0.3, 1.0]))
+        if rng.random() < 0.3:
+            extra["competition_strength"] = float(rng.choice([0.5, 30.0]))
+        if rng.random() < 0.3:
+            extra["no_control_genome_size"] = True
+        seed = int(rng.integers(0, 2**40))
+        for k in ("PANSIM_HEAVY_HGT", "PANSIM_HGT_MODE"):
+            os.environ.pop(k, None)
+        if rng.random() < 0.4:
+            os.environ["PANSIM_HEAVY_HGT"] = "1"
+            os.environ["PANSIM_HGT_MODE"] = str(int(rng.integers(0, 3)))
+        try:
+            prm = pa.make_params(seed=seed, n_gen=4, max_distances=50, **kw, **extra)
+            if pa.validate(prm)[0] and N >= 2:
+                sim = pa.Simulation(prm)
+                ref = OracleSim(seed=seed, **kw, **extra)
+                sim.run(4)
+                sim.sync()
+                for g in range(4):
+                    ref.generation(g)
+                if not (np.array_equal(sim.last_parents(), ref.last_idx) and np.array_equal(sim.core_genome.read_matrix(), ref.core)
+                        and np.array_equal(sim.pan_genome.read_matrix(), ref.acc)):
+                    bad += 1
+                    print("LOOP MISMATCH", t, kw, extra, os.environ.get("PANSIM_HEAVY_HGT"), os.environ.get("PANSIM_HGT_MODE"), flush=True)
+                sim.close()
+        except (pa.PansimError, AssertionError) as e:
+            print("LOOP skipped", t, kw, extra, str(e)[:80], flush=True)
+        for k in ("PANSIM_HEAVY_HGT", "PANSIM_HGT_MODE"):
+            os.environ.pop(k, None)
 print("trials", trials, "mismatches", bad)
 sys.exit(1 if bad else 0)
