@@ -758,7 +758,7 @@ static uint32_t hgt_partitions(const ps_population *p)
     return (uint32_t)((p->d.N + part_cap - 1) / part_cap);
 }
 
-static int launch_acc_hgt(ps_population *p, uint32_t gen, hipStream_t st)
+static int launch_acc_hgt(ps_population *p, uint32_t gen, hipStream_t st, hipEvent_t wait_before_apply = nullptr)
 {
     if (p->d.G == 0 || p->d.N < 2) return PS_OK;
     acc_hgt_args a{};
@@ -844,6 +844,7 @@ static int launch_acc_hgt(ps_population *p, uint32_t gen, hipStream_t st)
         if (dlds > 64 * 1024)
             HIPCHK(hipFuncSetAttribute((const void *)acc_hgt_donor_bin_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dlds));
         hipLaunchKernelGGL(acc_hgt_donor_bin_kernel, dim3(donor_blocks), dim3(256), dlds, st, a);
+        if (wait_before_apply) HIPCHK(hipStreamWaitEvent(st, wait_before_apply, 0));
         auto kern = acc_hgt_apply_kernel;
         if (lds > 64 * 1024)
             HIPCHK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -1862,7 +1863,8 @@ static int sim_create_impl(const ps_sim_params *p, ps_sim *s)
     // every CU (the sweep's rows are assigned dynamically, so lower residency costs no tail).
     // cfg2, with the narrow one-wave HGT kernel: 8 -> chain starves (1285), 7 -> 1830, 6 -> 1808,
     // 5 -> 1680 generations/s (before that kernel 6 was the optimum: 7 -> 1490, 6 -> 1620-1690).
-    // When HGT and sweep take turns the sweep has the chip to itself: 8 (cfg3: 1292 / 1322 / 1352 at 6 / 7 / 8).
+    // (When HGT and sweep take turns, 8 was best while the whole HGT waited for the sweep: 1292 / 1322 / 1352
+    // at 6 / 7 / 8; with the bin pass running beside the sweep's tail, 7: 1388 / 1411 / 1386.)
     // A large accessory genome needs more room: the HGT kernel's donor list (2 bytes per gene of the
     // largest compartment) must fit the LDS the sweep leaves (pan_genes 20000: 1463 / 1664 / 1684 at 7 / 6 / 5).
     if (!getenv("PANSIM_SWEEP_BLOCKS_PER_CU")) {
@@ -1870,7 +1872,7 @@ static int sim_create_impl(const ps_sim_params *p, ps_sim *s)
         for (int c = 0; c < d.n_comp; c++) max_comp = std::max<uint64_t>(max_comp, d.comp_end[c] - d.comp_begin[c]);
         const uint64_t list_lds = 2 * max_comp;
         if (list_lds > 36 * 1024) s->acc->hgt_list_in_global = true;
-        s->core->sweep_blocks_per_cu = s->heavy_hgt ? 8 : (list_lds <= 16 * 1024 ? 7 : 6);
+        s->core->sweep_blocks_per_cu = list_lds <= 16 * 1024 ? 7 : 6;
     }
     HIPCHK(hipHostMalloc(&s->h_num_genes, N * sizeof(int32_t), hipHostMallocMapped));
     HIPCHK(hipHostMalloc(&s->h_logw, N * sizeof(double), hipHostMallocMapped));
@@ -1946,8 +1948,9 @@ static int sim_one_generation(ps_sim *s, uint32_t gen)
     const bool heavy_hgt = p.HGT_rate > 0.0 && s->heavy_hgt;
     if (heavy_hgt) {
         const int prev = (slot + PS_RING - 1) % PS_RING;
-        if (s->slot_used[prev]) HIPCHK(hipStreamWaitEvent(sa, s->ev_core[prev], 0));
-        PSCHK(launch_acc_hgt(acc, gen, sa));
+        // only the LDS-image passes (apply, reduce) wait for the previous sweep: the bin pass -- LDS-local
+        // gathers, streaming appends -- runs beside its tail (cfg3: 1359 -> 1411 generations/s)
+        PSCHK(launch_acc_hgt(acc, gen, sa, s->slot_used[prev] ? s->ev_core[prev] : nullptr));
         HIPCHK(hipEventRecord(s->ev_hgt, sa));
         HIPCHK(hipStreamWaitEvent(sc, s->ev_hgt, 0));
     }
