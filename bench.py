@@ -10,6 +10,13 @@ BY SITE.  Weak scaling: every rank holds 1.2 M sites of a core genom
 n_gpus x 1.2 M sites; the accessory matrix is replicated and every rank draws the same parents
 from the same seeded stream, so a generation needs no data-path collective.  `value` counts
 1.2 M-site shard-generations per second summed over ranks (at n_gpus = 1: plain generations/s).
+`--scaling strong` (not the driver's contract) keeps --core_size as the whole genome and splits it
+over the ranks: BASELINE configs[3] is `--pop_size 65536 --scaling strong`.
+
+The JSON line also carries `roofline` (fused sweep: algorithmic bytes / HIP-event launch time against
+8 TB/s, PMC traffic from profiles/), `cpu_baseline` (the reference algorithm restated in C on the
+host cores: all cores, one thread, and its distance phase), `mpairs_per_s` / `distance_ms` /
+`pair_sites_per_s` for the sampled-pair distance phase.
 """
 import argparse
 import json
