@@ -1114,19 +1114,30 @@ static int upload_pairs(ps_population *p, uint64_t P, const uint32_t *r1, const 
     const uint64_t N = p->cfg.pop_size;
     p->h_r1.assign(r1, r1 + P);
     p->h_r2.assign(r2, r2 + P);
-    std::vector<uint32_t> start(N + 1, 0), s1(P), s2(P), perm(P);
-    for (uint64_t k = 0; k < P; k++) start[r1[k] + 1]++;
-    for (uint64_t i = 0; i < N; i++) start[i + 1] += start[i];
-    for (uint64_t k = 0; k < P; k++) {
-        const uint32_t pos = start[r1[k]]++;
-        s1[pos] = r1[k];
-        s2[pos] = r2[k];
-        perm[pos] = (uint32_t)k;
+    // the sorted order and the thread table only serve the tiled kernel: the core matrix with a
+    // population that fits its LDS tile (elsewhere -- accessory pairs, cfg5's all-pairs tiles -- the
+    // caller's order is uploaded as it is)
+    const bool tiled_possible = p->cfg.core && (uint64_t)N * (4 + 4) * 4 <= p->lds_limit;
+    std::vector<uint32_t> s1(P), s2(P), perm(P);
+    if (tiled_possible) {
+        std::vector<uint32_t> start(N + 1, 0);
+        for (uint64_t k = 0; k < P; k++) start[r1[k] + 1]++;
+        for (uint64_t i = 0; i < N; i++) start[i + 1] += start[i];
+        for (uint64_t k = 0; k < P; k++) {
+            const uint32_t pos = start[r1[k]]++;
+            s1[pos] = r1[k];
+            s2[pos] = r2[k];
+            perm[pos] = (uint32_t)k;
+        }
+    } else {
+        memcpy(s1.data(), r1, P * 4);
+        memcpy(s2.data(), r2, P * 4);
+        for (uint64_t k = 0; k < P; k++) perm[k] = (uint32_t)k;
     }
     // thread table of the tiled kernel: every run of equal first individual is split evenly over
     // ceil(run / 32) threads, so that a thread's pairs share their first individual
     std::vector<uint32_t> tstart, tcount;
-    for (uint64_t r0 = 0; r0 < P;) {
+    for (uint64_t r0 = 0; tiled_possible && r0 < P;) {
         uint64_t r1e = r0;
         while (r1e < P && s1[r1e] == s1[r0]) r1e++;
         const uint64_t run = r1e - r0, nthr = (run + 31) / 32;
