@@ -297,6 +297,22 @@ def test_pairwise_core_arbitrary_bytes(pa, orc):
     assert np.array_equal(pop.pairwise_distances(P, r1, r2), orc.pairwise_distances(m, True, 0, r1, r2))
 
 
+@pytest.mark.parametrize("N,L,P", [(130, 700, 3000), (1000, 513, 20000)])
+def test_pairwise_core_nibble_bytes(pa, orc, N, L, P):
+    # bytes below 16 that are not one-hot (0, 3, 5, 15 ...): the nibble kernels, sampled and all-pairs
+    rng = np.random.default_rng(N + L)
+    m = rng.integers(0, 16, (N, L)).astype(np.uint8)
+    r1, r2 = orc.sample_pairs(2, N, P)
+    want = orc.pairwise_hamming_counts(m, 0, L, r1, r2)
+    for mode in (0, 1, 2):
+        pop = pa.Population(N, L, 4, True, 0.0, 0, 0)
+        pop.set_tuning("pair_mode", mode)
+        pop.load_matrix(m)
+        (cnt,) = pop.pairwise_counts(r1, r2)
+        assert np.array_equal(cnt, want)
+        pop.close()
+
+
 def test_pairwise_kat(pa):
     # SURVEY 8(c) H1 -> 0.1111111111111111 ; J1 -> 0.6 / 0.4285714285714286 / 0.0014962593516208988
     x = [1, 2, 4, 8, 1, 2, 4, 8, 1]
