@@ -98,10 +98,20 @@ __global__ void __launch_bounds__(64) acc_step_kernel(acc_step_args a)
     const uint32_t pw = p >> 6, pb = p & 63u;
     uint64_t rowword = 0;
     ps_u4 rnd = { 0, 0, 0, 0 };
-    for (uint32_t b = 0; b < 64; b++) {
+    for (uint32_t b0 = 0; b0 < 64; b0 += 16) {
+    if (gw * 64u + b0 >= d.G) break;
+    // the parent words of 16 genes are fetched together (one dependent load per gene made the kernel
+    // 64 global-load latencies long: 0.13 ms beside the sweep)
+    uint64_t pword[16];
+#pragma unroll
+    for (uint32_t u = 0; u < 16; u++)
+        pword[u] = a.srcG[(uint64_t)min(gw * 64u + b0 + u, d.G - 1u) * d.W + pw];
+#pragma unroll
+    for (uint32_t u = 0; u < 16; u++) {
+        const uint32_t b = b0 + u;
         const uint32_t g = gw * 64u + b;
         if (g >= d.G) break;
-        uint32_t bit = (uint32_t)((a.srcG[(uint64_t)g * d.W + pw] >> pb) & 1ull);
+        uint32_t bit = (uint32_t)((pword[u] >> pb) & 1ull);
         if (DO_MUT) {
             if ((b & 3u) == 0u)
                 rnd = ps_philox(g >> 2, i, a.gen, PS_STREAM_ACC_MUT, a.k0, a.k1);
@@ -118,6 +128,7 @@ __global__ void __launch_bounds__(64) acc_step_kernel(acc_step_args a)
         const uint64_t gword = __ballot(bit);
         if (lane == 0) a.dstG[(uint64_t)g * d.W + w] = gword;
         rowword |= (uint64_t)bit << b;
+    }
     }
     if (valid) a.dstI[(uint64_t)i * d.GW + gw] = rowword;
 }
