@@ -150,7 +150,9 @@ int ps_sync(ps_population *p);
  * "force_block_sweep" (0/1: use the block sweep even when a row fits one wavefront),
  * "force_inline_sweep" (0/1: use the queue-free inline block sweep), "pair_mode" (core
  * distances: 0 = choose by cost, 1 = sampled-pair kernel, 2 = all-pairs tiles + lookup, 3 = sampled-pair
- * kernel in its nibble form even for one-hot matrices),
+ * kernel in its nibble form even for one-hot matrices, 4 = transposed bit strings streamed per pair -- the
+ * sampled form of populations too wide for an LDS tile), "pair_ranges" (site ranges of the tiled
+ * sampled-pair kernels, 0 = choose; the 16-bit counter cap still applies),
  * "hgt_mode" (accessory recombination: 0 = choose, 1 = one atomic per event, 2 = two passes: bin
  * by recipient partition, OR in LDS images), "hgt_slices" (binned HGT: event slices, 0 = choose), "hgt_list_in_global" (0/1: donor gene lists in
  * global scratch instead of LDS),

@@ -1208,6 +1208,114 @@ __global__ void core_pair_lookup_kernel(const uint32_t *H, uint32_t N, const uin
     out[perm ? perm[k] : k] = fwd ? H[(size_t)i * N + j] : H[(size_t)j * N + i];
 }
 
+// ---------------------------------------------------------------------------
+// Transposed form for populations too wide for an LDS tile of all N individuals (cfg4: N = 65536).
+// core_packT_kernel rewrites the site-major matrix once per call as individual-major bit strings
+// packT[individual][WT] (one-hot matrices: 2 bits per site, 16 sites per dword, code as in
+// core_pack2_kernel; other nibble-safe matrices: 4 bits per site), then core_pair_counts_rows streams
+// the two strings of every sampled pair -- regime (i) of SURVEY 8(d), "no reuse", but on strings 4x
+// (2x) smaller than the reference's byte rows: HBM traffic N*L + N*L/4 for the transposition plus
+// P * 2 * L/4 for the pairs (cfg4: 98 GB + 60 GB instead of 240 GB of byte rows that the site-major
+// layout cannot even stream).
+// Tile of a workgroup: 256 individuals x 32 dwords.  Work item = (4 consecutive individuals, 16 or 8
+// consecutive sites), as in core_pack2_kernel: a wave reads 256 contiguous bytes of 16 (8) site rows;
+// the four dwords of an item go to LDS as one 16-byte store (word-major tile T[word][individual]), and
+// the tile leaves as 128 contiguous bytes per individual.
+// ---------------------------------------------------------------------------
+#define PS_PT_IB 256u   // individuals per tile
+#define PS_PT_WB 32u    // dwords per individual per tile
+template <bool NIB>
+__global__ void __launch_bounds__(256) core_packT_kernel(const uint8_t *state, uint32_t N, uint32_t pitch, uint32_t rows,
+                                                         uint32_t *packT, uint32_t WT)
+{
+    constexpr uint32_t SPW = NIB ? 8u : 16u;          // sites per dword
+    constexpr uint32_t RS = PS_PT_IB + 4u;            // LDS row stride in dwords (16-byte aligned, banks shifted by 4 per word)
+    __shared__ __attribute__((aligned(16))) uint32_t T[PS_PT_WB * RS];   // T[w][individual]
+    const uint32_t tid = threadIdx.x;
+    // consecutive workgroups take consecutive individual blocks of the same 512 (256) site rows
+    const uint32_t nib = (N + PS_PT_IB - 1u) / PS_PT_IB;
+    const uint32_t i0 = (blockIdx.x % nib) * PS_PT_IB, w0 = (blockIdx.x / nib) * PS_PT_WB;
+    // 64 quads x 32 words = 2048 items, 8 per thread; consecutive lanes take consecutive quads
+    for (uint32_t it = tid; it < (PS_PT_IB / 4u) * PS_PT_WB; it += 256u) {
+        const uint32_t qd = it & 63u, w = it >> 6;
+        const uint32_t s_first = (w0 + w) * SPW;
+        const bool item_valid = s_first < rows;
+        const uint32_t sb = min(s_first, rows - 1u);
+        const uint32_t col = min(i0 + 4u * qd, pitch - 4u);       // (columns beyond N are padding zeros or unused)
+        const uint8_t *base = state + (size_t)sb * pitch + col;
+        uint32_t v[SPW];
+#pragma unroll
+        for (uint32_t b = 0; b < SPW; b++)
+            v[b] = *(const uint32_t *)(base + (size_t)min(b, rows - 1u - sb) * pitch);
+        if (!item_valid || sb + SPW > rows) {
+#pragma unroll
+            for (uint32_t b = 0; b < SPW; b++)
+                if (!item_valid || sb + b >= rows) v[b] = 0u;
+        }
+        uint32_t o[4];
+        if (NIB) {
+            ps_nibble_pack8(v, o);
+        } else {
+            uint32_t t[4];
+#pragma unroll
+            for (int m = 0; m < 4; m++)      // byte j of t[m]: sites 4m .. 4m+3 of individual j
+                t[m] = ps_code2(v[4 * m]) | (ps_code2(v[4 * m + 1]) << 2) | (ps_code2(v[4 * m + 2]) << 4) | (ps_code2(v[4 * m + 3]) << 6);
+            const uint32_t a01 = __builtin_amdgcn_perm(t[1], t[0], 0x05010400u), b01 = __builtin_amdgcn_perm(t[1], t[0], 0x07030602u);
+            const uint32_t a23 = __builtin_amdgcn_perm(t[3], t[2], 0x05010400u), b23 = __builtin_amdgcn_perm(t[3], t[2], 0x07030602u);
+            o[0] = __builtin_amdgcn_perm(a23, a01, 0x05040100u);
+            o[1] = __builtin_amdgcn_perm(a23, a01, 0x07060302u);
+            o[2] = __builtin_amdgcn_perm(b23, b01, 0x05040100u);
+            o[3] = __builtin_amdgcn_perm(b23, b01, 0x07060302u);
+        }
+        *(uint4 *)(T + w * RS + 4u * qd) = make_uint4(o[0], o[1], o[2], o[3]);
+    }
+    __syncthreads();
+    // 8 lanes write the 128 bytes of one individual; 32 individuals per pass of the workgroup
+    const uint32_t k4 = tid & 7u;
+    for (uint32_t ind = tid >> 3; ind < PS_PT_IB; ind += 32u) {
+        if (i0 + ind >= N) break;
+        const uint32_t *src = T + (4u * k4) * RS + ind;
+        const uint4 o = make_uint4(src[0], src[RS], src[2u * RS], src[3u * RS]);
+        *(uint4 *)(packT + (size_t)(i0 + ind) * WT + w0 + 4u * k4) = o;
+    }
+}
+
+// one wave per pair: both strings streamed with 16-byte loads, four of each in flight per lane
+template <bool NIB>
+__global__ void __launch_bounds__(256) core_pair_counts_rows(const uint32_t *packT, uint32_t WT, const uint32_t *r1,
+                                                             const uint32_t *r2, const uint32_t *perm, uint64_t P,
+                                                             uint32_t *out)
+{
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint64_t nwaves = (uint64_t)gridDim.x * (blockDim.x >> 6);
+    const uint32_t n4 = WT >> 2;
+    auto cnt = [](const uint4 &x, const uint4 &y, uint32_t c) -> uint32_t {
+        if (NIB) return ps_popc_acc4(x, y, c);
+        uint32_t d;
+        d = x.x ^ y.x; c = ps_bcnt_add((d | (d >> 1)) & 0x55555555u, c);
+        d = x.y ^ y.y; c = ps_bcnt_add((d | (d >> 1)) & 0x55555555u, c);
+        d = x.z ^ y.z; c = ps_bcnt_add((d | (d >> 1)) & 0x55555555u, c);
+        d = x.w ^ y.w; c = ps_bcnt_add((d | (d >> 1)) & 0x55555555u, c);
+        return c;
+    };
+    for (uint64_t k = (uint64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); k < P; k += nwaves) {
+        const uint4 *x = (const uint4 *)(packT + (size_t)r1[k] * WT), *y = (const uint4 *)(packT + (size_t)r2[k] * WT);
+        uint32_t c = 0, w = lane;
+        for (; w + 192u < n4; w += 256u) {
+            uint4 xa[4], ya[4];
+#pragma unroll
+            for (uint32_t u = 0; u < 4u; u++) { xa[u] = x[w + 64u * u]; ya[u] = y[w + 64u * u]; }
+#pragma unroll
+            for (uint32_t u = 0; u < 4u; u++) c = cnt(xa[u], ya[u], c);
+        }
+        for (; w < n4; w += 64u) c = cnt(x[w], y[w], c);
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) c += __shfl_xor(c, off, 64);
+        // one-hot: a differing site counts 2 in the reference's byte popcount (distances.rs:22-52)
+        if (lane == 0) out[perm ? perm[k] : k] = NIB ? c : 2u * c;
+    }
+}
+
 // generic form (any N, any byte values): one thread per pair, blockIdx.y splits the sites
 __global__ void __launch_bounds__(256) core_pair_counts_simple(
     const uint8_t *state, uint32_t pitch, uint32_t rows, const uint32_t *r1, const uint32_t *r2,

@@ -208,10 +208,12 @@ struct ps_population {
     double *d_Dt = nullptr;          // all-pairs Jaccard distances (D-avg), N x N
     uint64_t H_cap = 0;
     int pair_mode = 0;               // 0 auto, 1 sampled kernel, 2 all-pairs kernel (tuning/tests)
+    uint32_t pair_ranges = 0;        // tests: site ranges of the tiled sampled-pair kernels (0 = choose); the 16-bit cap still applies
     int hgt_mode = 0;                // 0 auto, 1 one atomic per event, 2 binned by recipient partition + LDS images
     void *d_pairs = nullptr;         // sorted r1 | r2 | perm | outA | outB | tstart | tcount
     uint32_t pair_threads = 0;       // entries of the thread table (tiled distance kernel)
     uint64_t pairs_cap = 0, pairs_cached = 0;
+    bool pairs_tiled = false;        // the cached list is sorted and has a thread table (tiled distance kernels)
     std::vector<uint32_t> h_r1, h_r2; // the caller's list the device copy was built from
     uint32_t lds_limit = 160 * 1024;
     uint32_t sweep_blocks_per_cu = 8;   // wave-per-row sweep: resident 256-thread blocks per CU (capped by LDS)
@@ -406,8 +408,11 @@ extern "C" int ps_set_tuning(ps_population *p, const char *key, int64_t value)
         if (value < 0 || value > 2) return ps_fail(PS_ERR_INVALID, "hgt_mode must be 0 (auto), 1 (one atomic per event) or 2 (binned by recipient partition, two passes)");
         p->hgt_mode = (int)value;
     } else if (k == "pair_mode") {
-        if (value < 0 || value > 3) return ps_fail(PS_ERR_INVALID, "pair_mode must be 0 (auto), 1 (sampled), 2 (all pairs) or 3 (sampled, nibble form even for one-hot matrices)");
+        if (value < 0 || value > 4) return ps_fail(PS_ERR_INVALID, "pair_mode must be 0 (auto), 1 (sampled), 2 (all pairs), 3 (sampled, nibble form even for one-hot matrices) or 4 (transposed bit strings, streamed per pair)");
         p->pair_mode = (int)value;
+    } else if (k == "pair_ranges") {
+        if (value < 0 || value > 65535) return ps_fail(PS_ERR_INVALID, "pair_ranges must be 0 (choose)..65535");
+        p->pair_ranges = (uint32_t)value;
     } else if (k == "force_block_sweep") {
         p->force_block_sweep = value != 0;
     } else if (k == "force_inline_sweep") {
@@ -428,6 +433,7 @@ extern "C" int ps_set_tuning(ps_population *p, const char *key, int64_t value)
     } else if (k == "lds_limit") {
         if (value < 1024 || value > 160 * 1024) return ps_fail(PS_ERR_INVALID, "lds_limit must be 1 KiB..160 KiB");
         p->lds_limit = (uint32_t)value;
+        p->pairs_cached = 0;          // the cached pair list is sorted / has a thread table depending on the LDS tile
     } else {
         return ps_fail(PS_ERR_INVALID, "unknown tuning key %s", key);
     }
@@ -1108,16 +1114,18 @@ static int ensure_pairs(ps_population *p, uint64_t P)
 static int upload_pairs(ps_population *p, uint64_t P, const uint32_t *r1, const uint32_t *r2)
 {
     PSCHK(ensure_pairs(p, P));
-    if (p->pairs_cached == P && p->h_r1.size() == P && memcmp(p->h_r1.data(), r1, P * 4) == 0
-        && memcmp(p->h_r2.data(), r2, P * 4) == 0)
-        return PS_OK;
     const uint64_t N = p->cfg.pop_size;
-    p->h_r1.assign(r1, r1 + P);
-    p->h_r2.assign(r2, r2 + P);
     // the sorted order and the thread table only serve the tiled kernel: the core matrix with a
     // population that fits its LDS tile (elsewhere -- accessory pairs, cfg5's all-pairs tiles -- the
     // caller's order is uploaded as it is)
     const bool tiled_possible = p->cfg.core && (uint64_t)N * (4 + 4) * 4 <= p->lds_limit;
+    if (p->pairs_cached == P && p->pairs_tiled == tiled_possible && p->h_r1.size() == P
+        && memcmp(p->h_r1.data(), r1, P * 4) == 0 && memcmp(p->h_r2.data(), r2, P * 4) == 0)
+        return PS_OK;
+    p->pairs_cached = 0;
+    p->pairs_tiled = tiled_possible;
+    p->h_r1.assign(r1, r1 + P);
+    p->h_r2.assign(r2, r2 + P);
     std::vector<uint32_t> s1(P), s2(P), perm(P);
     if (tiled_possible) {
         std::vector<uint32_t> start(N + 1, 0);
@@ -1221,8 +1229,40 @@ static int pair_counts_device(ps_population *p, uint64_t P, const uint32_t *d_r1
         // worse constant (it re-packs the matrix once per 32768 pairs): measured crossover at
         // N = 1000 is P ~ 250 k = half of all pairs
         const double all_pairs = 0.5 * (double)N * (double)N;
-        const bool use_all = p->nibble_safe && p->pair_mode != 1 && p->pair_mode != 3 && (uint64_t)N * N * 4 <= (8ull << 30)
+        const bool all_fits = p->nibble_safe && (uint64_t)N * N * 4 <= (8ull << 30);
+        // Populations too wide for an LDS tile (W == 0): the transposed form (pack once, stream two bit
+        // strings per pair: ~1.25 * N * L + P * L / 2 (nibbles: P * L) bytes at ~5 TB/s) against the
+        // all-pairs tiles (~0.9e15 pair-sites/s, N = 8192: 45 ms; crossover there at P ~ 350 k)
+        const double t_rows = (1.25 * (double)N * rows + (double)P * rows * (p->onehot_safe ? 0.5 : 1.0)) / 5.0e12;
+        const double t_all = all_pairs * rows / 0.9e15;
+        const bool use_rows = p->nibble_safe && p->pair_mode != 2
+                              && (p->pair_mode == 4 || (!W && (p->pair_mode == 1 || p->pair_mode == 3 || !all_fits || t_rows < t_all)));
+        const bool use_all = !use_rows && all_fits && p->pair_mode != 1 && p->pair_mode != 3
                              && (p->pair_mode == 2 || (double)P * 2.0 > all_pairs || !W);
+        if (use_rows) {
+            const bool nib = !p->onehot_safe;
+            const uint32_t spw = nib ? 8u : 16u;
+            const uint32_t WT = ((rows + spw - 1u) / spw + PS_PT_WB - 1u) / PS_PT_WB * PS_PT_WB;
+            const uint64_t need = (uint64_t)N * WT;
+            if (p->pack2_cap < need) {
+                if (p->d_pack2) HIPCHK(hipFree(p->d_pack2));
+                p->d_pack2 = nullptr;
+                p->pack2_cap = 0;
+                HIPCHK(hipMalloc(&p->d_pack2, need * sizeof(uint32_t)));
+                p->pack2_cap = need;
+            }
+            const uint64_t ptiles = (uint64_t)((N + PS_PT_IB - 1u) / PS_PT_IB) * (WT / PS_PT_WB);
+            if (ptiles > 0x7FFFFFFFull) return ps_fail(PS_ERR_INVALID, "matrix too large for the transposed distance form");
+            const dim3 pgrid((uint32_t)ptiles);
+            const uint32_t blocks = (uint32_t)std::min<uint64_t>((P + 3) / 4, 256u * 8u * 4u);
+            if (nib) {
+                core_packT_kernel<true><<<pgrid, 256, 0, st>>>(p->state, N, p->pitch, rows, p->d_pack2, WT);
+                core_pair_counts_rows<true><<<blocks, 256, 0, st>>>(p->d_pack2, WT, d_r1, d_r2, d_perm, P, d_a);
+            } else {
+                core_packT_kernel<false><<<pgrid, 256, 0, st>>>(p->state, N, p->pitch, rows, p->d_pack2, WT);
+                core_pair_counts_rows<false><<<blocks, 256, 0, st>>>(p->d_pack2, WT, d_r1, d_r2, d_perm, P, d_a);
+            }
+        } else
         if (use_all) {
             const uint32_t WA = 32u, ntile = (N + 127u) / 128u;
             const uint32_t lds = 2u * 128u * ((WA >> 2) + 1u) * 16u;
@@ -1264,7 +1304,7 @@ static int pair_counts_device(ps_population *p, uint64_t P, const uint32_t *d_r1
             if (lds > 64 * 1024)
                 HIPCHK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             const uint32_t pair_blocks = std::max(1u, (p->pair_threads + PT - 1) / PT);
-            uint32_t ranges = std::max(1u, std::min(n_tiles, (256u * 4u + pair_blocks - 1) / pair_blocks));
+            uint32_t ranges = std::max(1u, std::min(n_tiles, p->pair_ranges ? p->pair_ranges : (256u * 4u + pair_blocks - 1) / pair_blocks));
             // the kernel counts a range in 16 bits: fewer than 65536 sites per range
             const uint32_t max_tpr = std::max(1u, 65535u / (W * 16u));
             ranges = std::max(ranges, (n_tiles + max_tpr - 1) / max_tpr);
@@ -1286,9 +1326,10 @@ static int pair_counts_device(ps_population *p, uint64_t P, const uint32_t *d_r1
             // every workgroup re-packs its site tiles: 1024 threads of the thread table per pair block
             const uint32_t pair_blocks = std::max(1u, (p->pair_threads + PT - 1) / PT);
             // enough site ranges to fill the chip a few times over
-            uint32_t ranges = std::max(1u, std::min(n_tiles, (256u * 4u + pair_blocks - 1) / pair_blocks));
-            // the kernel counts a range in 16 bits: at most 2 * sites per range < 65536
-            const uint32_t max_tpr = std::max(1u, 32767u / (W * 8u));
+            uint32_t ranges = std::max(1u, std::min(n_tiles, p->pair_ranges ? p->pair_ranges : (256u * 4u + pair_blocks - 1) / pair_blocks));
+            // the kernel counts a range in 16 bits; a nibble pair differs in up to 4 bits per site
+            // (only one-hot bytes are limited to 2): 4 * sites per range < 65536
+            const uint32_t max_tpr = std::max(1u, 16383u / (W * 8u));
             ranges = std::max(ranges, (n_tiles + max_tpr - 1) / max_tpr);
             const uint32_t tpr = (n_tiles + ranges - 1) / ranges;
             ranges = (n_tiles + tpr - 1) / tpr;
@@ -1747,6 +1788,7 @@ struct ps_sim {
     int32_t *h_num_genes = nullptr, *m_num_genes = nullptr;   // pinned + its device alias
     double *h_logw = nullptr, *m_logw = nullptr, *h_avg = nullptr;
     double *d_avg = nullptr;
+    double *d_log1p = nullptr;          // ln(1 + s_g) of THIS run (the accessory handle's own table belongs to its Population API)
     uint64_t step_count = 0;
     bool need_logw = false;
     // sweep timing
@@ -1773,6 +1815,7 @@ extern "C" void ps_sim_destroy(ps_sim *s)
     if (s->h_logw) (void)hipHostFree(s->h_logw);
     if (s->h_avg) (void)hipHostFree(s->h_avg);
     if (s->d_avg) (void)hipFree(s->d_avg);
+    if (s->d_log1p) (void)hipFree(s->d_log1p);
     for (auto &pr : s->tev) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
     for (auto e : s->ev_pool) (void)hipEventDestroy(e);
     ps_population_destroy(s->core);
@@ -1894,7 +1937,8 @@ static int sim_create_impl(const ps_sim_params *p, ps_sim *s)
     if (G) {
         std::vector<double> l1p(G);
         for (uint64_t g = 0; g < G; g++) l1p[g] = std::log(1.0 + s->sel[g] * 1.0);
-        HIPCHK(hipMemcpy(s->acc->d_log1p, l1p.data(), G * sizeof(double), hipMemcpyHostToDevice));
+        HIPCHK(hipMalloc(&s->d_log1p, G * sizeof(double)));
+        HIPCHK(hipMemcpy(s->d_log1p, l1p.data(), G * sizeof(double), hipMemcpyHostToDevice));
     }
     return PS_OK;
 }
@@ -1931,7 +1975,7 @@ static int sim_one_generation(ps_sim *s, uint32_t gen)
     // main.rs:442-443: device half of sample_indices ...
     // the kernel writes its 12*N bytes straight into host-mapped pinned memory (no copy kernels)
     if (s->need_logw)
-        acc_fitness_kernel<<<(uint32_t)((N + 255) / 256), 256, 0, sa>>>(acc->I[acc->cur], acc->d_log1p, 1,
+        acc_fitness_kernel<<<(uint32_t)((N + 255) / 256), 256, 0, sa>>>(acc->I[acc->cur], s->d_log1p, 1,
                                                                      s->m_num_genes, s->m_logw, acc->d);
     else
         acc_gene_count_rows_kernel<<<(uint32_t)((N + 3) / 4), 256, 0, sa>>>(acc->I[acc->cur], s->m_num_genes,

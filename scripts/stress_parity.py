@@ -1,154 +1,16 @@
 #!/usr/bin/env python3
-"""Randomised GPU-vs-oracle stress of the operators whose kernels have host-chosen geometry
-(distances: thread table, 2-bit / nibble / all-pairs forms; HGT: atomic / binned forms, partitions;
-core sweep: wave / block / inline forms and their launch parameters).
+"""Randomised GPU-vs-oracle stress (tests/stress_trials.py) as a long run.
 Usage: python scripts/stress_parity.py [trials] [seed]   (on an MI355X; exits non-zero on a mismatch)"""
 import os
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-import numpy as np  # noqa: E402
-
-import pansim_amd as pa  # noqa: E402
-from oracle import oracle as o  # noqa: E402
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from stress_trials import run  # noqa: E402
 
 trials = int(sys.argv[1]) if len(sys.argv) > 1 else 100
-rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
-bad = 0
-for t in range(trials):
-    # ---- distances
-    N = int(rng.choice([2, 3, 17, 64, 100, 257, 1000, 1100, 1500, 3000]))
-    L = int(rng.choice([1, 7, 16, 129, 512, 777, 2049]))
-    P = int(rng.choice([1, 2, 33, 500, 4000]))
-    m = (1 << rng.integers(0, 4, (N, L))).astype(np.uint8)
-    if rng.random() < 0.15:
-        m[rng.integers(0, N), rng.integers(0, L)] = int(rng.choice([0, 3, 5, 15, 16, 200]))     # not one-hot / not a nibble
-    r1 = rng.integers(0, N, P).astype(np.uint32)
-    r2 = rng.integers(0, N, P).astype(np.uint32)
-    if rng.random() < 0.3:
-        r1[:] = r1[0]                                  # one long run of equal first individuals
-    want = o.pairwise_hamming_counts(m, 0, L, r1, r2)
-    pop = pa.Population(N, L, 4, True, 0.0, 0, 0)
-    pop.set_tuning("pair_mode", int(rng.integers(0, 4)))
-    pop.load_matrix(m)
-    (got,) = pop.pairwise_counts(r1, r2)
-    if not np.array_equal(got, want):
-        bad += 1
-        print("DISTANCE MISMATCH", t, N, L, P, flush=True)
-    pop.close()
-    # ---- HGT
-    N = int(rng.choice([2, 5, 50, 130, 700, 2500]))
-    G = int(rng.choice([1, 63, 64, 65, 300, 1000, 4000]))
-    g1 = int(rng.integers(0, G + 1))
-    comps = [(0, g1), (g1, G)] if 0 < g1 < G else [(0, G)]
-    cb, ce = [c[0] for c in comps], [c[1] for c in comps]
-    lr = [float(rng.choice([0.0, 0.5, 3.0, 40.0, 700.0])) for _ in comps]
-    a = (rng.random((N, G)) < rng.choice([0.0, 0.05, 0.3, 0.9])).astype(np.uint8)
-    seed, gen = int(rng.integers(0, 2**40)), int(rng.integers(0, 2**31))
-    want = a.copy()
-    o.recombine_acc(want, seed, gen, cb, ce, lr)
-    acc = pa.Population(N, G, 2, False, 0.3, seed, 0)
-    acc.set_tuning("hgt_mode", int(rng.integers(0, 3)))
-    if rng.random() < 0.3:
-        acc.set_tuning("hgt_list_in_global", 1)
-    if rng.random() < 0.4:
-        row_bytes = 8 * ((G + 63) // 64)
-        acc.set_tuning("lds_limit", int(min(160 * 1024, max(1024 + int(rng.integers(2, 40)) * row_bytes, 2 * G + 8192))))
-    if rng.random() < 0.3:
-        acc.set_tuning("hgt_slices", int(rng.integers(1, 9)))
-    acc.set_rates([0.0] * len(comps), lr, cb, ce)
-    acc.load_matrix(a)
-    acc.recombine(gen)
-    if not np.array_equal(acc.read_matrix(), want):
-        bad += 1
-        print("HGT MISMATCH", t, N, G, comps, lr, flush=True)
-    acc.close()
-    # ---- core sweep (fused gather + mutate + HR) under random kernel geometries
-    N = int(rng.choice([2, 30, 100, 1000, 1024, 1025, 1500, 2048, 5000, 9000, 20000]))
-    L = int(rng.choice([1, 3, 10, 40]))
-    LG = int(rng.choice([L, 50 * L, 1200000]))
-    off = int(rng.integers(0, LG - L + 1))
-    lm = float(rng.choice([0.0, 0.2, 0.05 * LG, 0.2 * LG]))
-    lh = float(rng.choice([0.0, 0.1, 0.02 * LG, 0.2 * LG])) if N > 1 else 0.0
-    m = (1 << rng.integers(0, 4, (N, L))).astype(np.uint8)
-    sample = rng.integers(0, N, N).astype(np.uint32)
-    seed, gen = int(rng.integers(0, 2**40)), int(rng.integers(0, 2**31))
-    plan = o.core_plan(lm, lh, LG)
-    want = o.next_generation(m, sample)
-    o.mutate_core(want, off, seed, gen, plan)
-    o.recombine_core(want, off, seed, gen, plan)
-    core = pa.Population(N, L, 4, True, 0.0, seed, 0, col_offset=off, global_cols=LG)
-    tune = {}
-    if rng.random() < 0.4:
-        tune["force_block_sweep"] = 1
-    if rng.random() < 0.3:
-        tune["block_waves"] = int(rng.choice([4, 8, 16]))
-    if rng.random() < 0.3:
-        tune["block_batch"] = 2
-    if rng.random() < 0.2:
-        tune["no_block_preload"] = 1
-    if rng.random() < 0.2:
-        tune["force_inline_sweep"] = 1
-    if rng.random() < 0.3:
-        tune["sweep_rows"] = int(rng.integers(2, 5))
-        tune["sweep_blocks_per_cu"] = int(rng.integers(1, 9))
-    for k, v in tune.items():
-        core.set_tuning(k, v)
-    core.set_rates([lm], [lh])
-    core.load_matrix(m)
-    try:
-        core.step(gen, sample, True)
-        if not np.array_equal(core.read_matrix(), want):
-            bad += 1
-            print("SWEEP MISMATCH", t, N, L, LG, off, lm, lh, tune, flush=True)
-    except pa.PansimError as e:
-        if e.code != -1:       # (a geometry that does not fit is refused with PS_ERR_INVALID, never wrong)
-            bad += 1
-            print("SWEEP ERROR", t, N, L, lm, lh, tune, e, flush=True)
-    core.close()
-    # ---- whole generation loop (every 5th trial): random parameters, 4 generations without host sync
-    if t % 5 == 0:
-        sys.path.insert(0, os.path.join(ROOT, "tests"))
-        from orc_sim import OracleSim
-        N = int(rng.choice([2, 9, 64, 200, 1030, 2100]))
-        L = int(rng.choice([1, 17, 300, 1500]))
-        cg = int(rng.choice([0, 5, 40]))
-        pg = cg + int(rng.choice([0, 1, 64, 500]))
-        if pg == 0:
-            pg, cg = 10, 10
-        kw = dict(pop_size=N, core_size=L, pan_genes=pg, core_genes=cg, HR_rate=float(rng.choice([0.0, 0.05, 0.6])),
-                  HGT_rate=float(rng.choice([0.0, 0.05, 0.6])), avg_gene_freq=float(rng.choice([0.3, 0.5, 0.9])))
-        extra = {}
-        if rng.random() < 0.4:
-            extra["prop_positive"] = float(rng.choice([0.0, 0.3, 1.0]))
-        if rng.random() < 0.3:
-            extra["competition_strength"] = float(rng.choice([0.5, 30.0]))
-        if rng.random() < 0.3:
-            extra["no_control_genome_size"] = True
-        seed = int(rng.integers(0, 2**40))
-        for k in ("PANSIM_HEAVY_HGT", "PANSIM_HGT_MODE"):
-            os.environ.pop(k, None)
-        if rng.random() < 0.4:
-            os.environ["PANSIM_HEAVY_HGT"] = "1"
-            os.environ["PANSIM_HGT_MODE"] = str(int(rng.integers(0, 3)))
-        try:
-            prm = pa.make_params(seed=seed, n_gen=4, max_distances=50, **kw, **extra)
-            if pa.validate(prm)[0] and N >= 2:
-                sim = pa.Simulation(prm)
-                ref = OracleSim(seed=seed, **kw, **extra)
-                sim.run(4)
-                sim.sync()
-                for g in range(4):
-                    ref.generation(g)
-                if not (np.array_equal(sim.last_parents(), ref.last_idx) and np.array_equal(sim.core_genome.read_matrix(), ref.core)
-                        and np.array_equal(sim.pan_genome.read_matrix(), ref.acc)):
-                    bad += 1
-                    print("LOOP MISMATCH", t, kw, extra, os.environ.get("PANSIM_HEAVY_HGT"), os.environ.get("PANSIM_HGT_MODE"), flush=True)
-                sim.close()
-        except (pa.PansimError, AssertionError) as e:
-            print("LOOP skipped", t, kw, extra, str(e)[:80], flush=True)
-        for k in ("PANSIM_HEAVY_HGT", "PANSIM_HGT_MODE"):
-            os.environ.pop(k, None)
+seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+bad = run(trials, seed, lambda *a, **k: print(*a, flush=True))
 print("trials", trials, "mismatches", bad)
 sys.exit(1 if bad else 0)

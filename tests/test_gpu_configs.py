@@ -1,0 +1,155 @@
+"""GPU parity at the populations of BASELINE configs[3] (--pop_size 65536) and configs[4]
+(--pop_size 8192 --max_distances 33554432 --print_matrices): whole generations through ps_sim_run,
+the distance phase in its large-N forms and the CLI, each against the CPU oracle.  The core genome is
+a site slice keyed at its global offset (a shard of the 1.2 M sites), so the oracle finishes in
+seconds; the accessory matrix, the parents and the pair list are full size.
+Reference paths: population.rs:270-465 (selection, gather), :486-751 (gain/loss, HR, HGT),
+:753-837 (distances), main.rs:413-427, :467-499, :550-553."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_config4_population_generations_match_oracle(pa, orc):
+    # BASELINE configs[3]: --pop_size 65536 --core_size 1200000 --pan_genes 6000 (defaults otherwise).
+    # Shard 12500 of 25000 = sites [600000, 600048); 2 generations: 2e8 HGT events each through the binned
+    # HGT kernels (202 recipient partitions), acc_step at W = 1024 words, the block sweep with the LDS full,
+    # the turn-taking schedule of the loop; then the distance phase of 100 000 pairs at N = 65536.
+    from orc_sim import OracleSim
+    kw = dict(pop_size=65536, core_size=1200000, pan_genes=6000, core_genes=2000)
+    sim = pa.Simulation(pa.make_params(seed=0, n_gen=2, max_distances=100000, shard_rank=12500, shard_count=25000, **kw))
+    assert sim.core_genome.ncols == 48
+    ref = OracleSim(seed=0, site_begin=600000, site_end=600048, **kw)
+    for g in range(2):
+        sim.run(1)
+        sim.sync()
+        ref.generation(g)
+        assert np.array_equal(sim.last_parents(), ref.last_idx), "parents differ at generation %d" % g
+    assert np.array_equal(sim.core_genome.read_matrix(), ref.core)
+    assert np.array_equal(sim.pan_genome.read_matrix(), ref.acc)
+    r1, r2 = orc.sample_pairs(0, 65536, 100000)
+    assert np.array_equal(sim.range1, r1) and np.array_equal(sim.range2, r2)
+    (cnt,) = sim.core_genome.pairwise_counts(r1, r2)
+    assert np.array_equal(cnt, orc.pairwise_hamming_counts(ref.core, 0, 48, r1, r2))
+    acc_d = sim.pan_genome.pairwise_distances(r1.size, r1, r2)
+    assert np.array_equal(acc_d, orc.pairwise_distances(ref.acc, False, 2000, r1, r2))
+    assert np.array_equal(sim.pan_genome.gene_frequencies(), orc.gene_frequencies(ref.acc, 2000))
+    sim.close()
+
+
+@pytest.mark.parametrize("mode", [0, 4])
+def test_large_population_sampled_pairs(pa, orc, mode):
+    # N = 65536 with enough sites for several tiles of the transposed form (and a ragged tail): the
+    # sampled-pair kernel that serves populations too wide for an LDS tile (population.rs:787-837)
+    N, L, P = 65536, 1100, 30000
+    rng = np.random.default_rng(65536)
+    base = (1 << rng.integers(0, 4, L)).astype(np.uint8)
+    m = np.tile(base, (N, 1))
+    mut = rng.random((N, L)) < 0.05
+    m[mut] = (1 << rng.integers(0, 4, int(mut.sum()))).astype(np.uint8)
+    r1, r2 = orc.sample_pairs(7, N, P)
+    r2[:5] = r1[:5]                                   # a pair of an individual with itself counts 0
+    want = orc.pairwise_hamming_counts(m, 0, L, r1, r2)
+    pop = pa.Population(N, L, 4, True, 0.0, 0, 0)
+    pop.set_tuning("pair_mode", mode)
+    pop.load_matrix(m)
+    (cnt,) = pop.pairwise_counts(r1, r2)
+    assert np.array_equal(cnt, want)
+    assert (cnt[:5] == 0).all() and cnt.max() > 0
+    pop.close()
+
+
+def test_config5_population_all_pairs_distances(pa, orc):
+    # BASELINE configs[4]: --pop_size 8192 --max_distances 2^22 (the run itself uses 2^25; the kernels
+    # are the same: all-pairs tiles + lookup, chosen by cost), 2000-site shard at its global offset,
+    # 2 generations, then core counts and accessory distances of all 4.2 M sampled pairs
+    from orc_sim import OracleSim
+    kw = dict(pop_size=8192, core_size=1200000, pan_genes=6000, core_genes=2000)
+    P = 1 << 22
+    sim = pa.Simulation(pa.make_params(seed=0, n_gen=2, max_distances=P, shard_rank=300, shard_count=600, **kw))
+    assert sim.core_genome.ncols == 2000
+    ref = OracleSim(seed=0, site_begin=600000, site_end=602000, **kw)
+    sim.run(2)
+    sim.sync()
+    for g in range(2):
+        ref.generation(g)
+    assert np.array_equal(sim.last_parents(), ref.last_idx)
+    assert np.array_equal(sim.core_genome.read_matrix(), ref.core)
+    assert np.array_equal(sim.pan_genome.read_matrix(), ref.acc)
+    r1, r2 = orc.sample_pairs(0, 8192, P)
+    assert np.array_equal(sim.range1, r1) and np.array_equal(sim.range2, r2)
+    (cnt,) = sim.core_genome.pairwise_counts(r1, r2)
+    assert np.array_equal(cnt, orc.pairwise_hamming_counts(ref.core, 0, 2000, r1, r2))
+    acc_d = sim.pan_genome.pairwise_distances(P, r1, r2)
+    assert np.array_equal(acc_d, orc.pairwise_distances(ref.acc, False, 2000, r1, r2))
+    sim.close()
+
+
+def test_config5_cli_print_matrices(pa, orc, tmp_path):
+    # `pansim --pop_size 8192 --max_distances <2^20> --print_matrices` on a short genome: the six output
+    # files byte for byte (main.rs:321-331, :467-499, :531-553; population.rs:865-897)
+    import ctypes as C
+    from orc_sim import OracleSim
+    exe = os.path.join(ROOT, "pansim_amd", "pansim")
+    N, L, P, cg = 8192, 300, 1 << 20, 50
+    kw = dict(pop_size=N, core_size=L, pan_genes=250, core_genes=cg)
+    args = []
+    for k, v in kw.items():
+        args += ["--" + k, str(v)]
+    r = subprocess.run([exe, *args, "--n_gen", "2", "--seed", "4", "--max_distances", str(P), "--outpref",
+                        str(tmp_path / "run"), "--print_matrices", "--print_dist", "--print_selection"],
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr
+    ref = OracleSim(seed=4, **kw)
+    r1, r2 = orc.sample_pairs(4, N, P)
+    per_gen = []
+    for g in range(2):
+        ref.generation(g)
+        cd = orc.pairwise_distances(ref.core, True, cg, r1, r2)
+        ad = orc.pairwise_distances(ref.acc, False, cg, r1, r2)
+        row = []
+        for d in (cd, ad):
+            s, m = C.c_double(), C.c_double()
+            orc.lib().orc_standard_deviation(d, d.size, C.byref(s), C.byref(m))
+            row += [m.value, s.value]
+        per_gen.append(row)
+    want = "".join("%s\t%s\n" % (orc.fmt_f64(c), orc.fmt_f64(a)) for c, a in zip(cd, ad))
+    assert (tmp_path / "run.tsv").read_text() == want
+    want = "".join("%s\n" % orc.fmt_f64(x) for x in orc.gene_frequencies(ref.acc, cg))
+    assert (tmp_path / "run_freqs.txt").read_text() == want
+    want = "".join("\t".join(orc.fmt_f64(x) for x in row) + "\n" for row in per_gen)
+    assert (tmp_path / "run_per_gen.tsv").read_text() == want
+    want = "\n".join(orc.fmt_f64(x) for x in ref.sel) + "\n"
+    assert (tmp_path / "run_selection.tsv").read_text() == want
+    orc.lib().orc_write_matrix(ref.core, N, L, 1, cg, str(tmp_path / "want").encode())
+    orc.lib().orc_write_matrix(ref.acc, N, 200, 0, cg, str(tmp_path / "want").encode())
+    for suffix in ("_core_genome.csv", "_pangenome.csv"):
+        assert (tmp_path / ("run" + suffix)).read_bytes() == (tmp_path / ("want" + suffix)).read_bytes()
+
+
+@pytest.mark.parametrize("N,G,cg", [(1000, 4000, 2000), (8200, 130, 7), (9000, 64, 0)])
+def test_average_distance_large_populations(pa, orc, N, G, cg):
+    # D-avg (population.rs:753-784): the N x N matrix form at the cfg2 population and the streaming
+    # kernel that serves N > 8192, both against the oracle's left-to-right fold
+    rng = np.random.default_rng(N + G)
+    m = (rng.random((N, G)) < 0.3).astype(np.uint8)
+    m[5] = m[6]                                       # a zero distance inside the fold
+    pop = pa.Population(N, G, 2, False, 0.3, 0, cg)
+    pop.load_matrix(m)
+    assert np.array_equal(pop.average_distance(), orc.average_distance(m, False, cg))
+    pop.close()
+
+
+def test_randomised_stress_subset(pa, orc):
+    # a time-boxed subset of scripts/stress_parity.py (the long run): random geometries of the distance,
+    # HGT and sweep kernels and short generation loops, every result compared with the oracle
+    from stress_trials import run
+    lines = []
+    bad = run(40, seed=20261003, log=lambda *a: lines.append(" ".join(map(str, a))))
+    assert bad == 0, "\n".join(lines)

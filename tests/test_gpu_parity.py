@@ -313,6 +313,66 @@ def test_pairwise_core_nibble_bytes(pa, orc, N, L, P):
         pop.close()
 
 
+def test_pairwise_nibble_counter_cap(pa, orc):
+    # worst case of the nibble kernel's 16-bit range counters: rows of 0x0F against rows of 0x00 differ in
+    # 4 bits per site, so a range may hold at most 16383 sites (a cap sized for one-hot bytes -- 2 bits per
+    # site -- let 79 tiles x 256 sites x 4 bits = 80896 carry into the neighbouring pair's counter)
+    N, L, P = 130, 40000, 4000
+    m = np.zeros((N, L), np.uint8)
+    m[::2, :] = 0x0F
+    r1, r2 = orc.sample_pairs(3, N, P)
+    want = orc.pairwise_hamming_counts(m, 0, L, r1, r2)
+    assert want.max() == 4 * L
+    for ranges in (1, 2, 0):
+        pop = pa.Population(N, L, 4, True, 0.0, 0, 0)
+        pop.set_tuning("pair_mode", 1)
+        pop.set_tuning("pair_ranges", ranges)
+        pop.load_matrix(m)
+        assert np.array_equal(pop.pairwise_counts(r1, r2)[0], want)
+        pop.close()
+
+
+def test_pair_list_cache_follows_lds_limit(pa, orc):
+    # the cached device copy of a pair list is sorted (with a thread table) only when the tiled kernel can
+    # run; changing "lds_limit" between two calls with the same list must rebuild it
+    N, L, P = 1000, 600, 5000
+    rng = np.random.default_rng(8)
+    m = _rand_core(rng, N, L)
+    r1, r2 = orc.sample_pairs(4, N, P)
+    want = orc.pairwise_hamming_counts(m, 0, L, r1, r2)
+    pop = pa.Population(N, L, 4, True, 0.0, 0, 0)
+    pop.load_matrix(m)
+    pop.set_tuning("pair_mode", 1)
+    pop.set_tuning("lds_limit", 16 * 1024)     # no LDS tile for N = 1000: caller's order, no thread table
+    assert np.array_equal(pop.pairwise_counts(r1, r2)[0], want)
+    pop.set_tuning("lds_limit", 160 * 1024)    # tiled kernel: needs the sorted list
+    assert np.array_equal(pop.pairwise_counts(r1, r2)[0], want)
+    pop.set_tuning("lds_limit", 16 * 1024)
+    assert np.array_equal(pop.pairwise_counts(r1, r2)[0], want)
+    pop.close()
+
+
+def test_population_api_does_not_disturb_sim_fitness_table(pa, orc):
+    # ps_sim keeps its own ln(1+s) table: a Population-API call on the sim's accessory handle with other
+    # selection coefficients must not change the parents the loop draws afterwards
+    from orc_sim import OracleSim
+    kw = dict(pop_size=90, core_size=600, pan_genes=300, core_genes=100)
+    extra = dict(prop_positive=0.4)
+    sim = pa.Simulation(pa.make_params(seed=5, n_gen=4, max_distances=100, **kw, **extra))
+    ref = OracleSim(seed=5, **kw, **extra)
+    sim.run(2)
+    sim.sync()
+    other = np.linspace(-0.5, 0.5, sim.pan_genome.ncols)
+    sim.pan_genome.fitness_terms(other)
+    sim.run(2)
+    sim.sync()
+    for g in range(4):
+        ref.generation(g)
+    assert np.array_equal(sim.last_parents(), ref.last_idx)
+    assert np.array_equal(sim.pan_genome.read_matrix(), ref.acc)
+    sim.close()
+
+
 def test_pairwise_kat(pa):
     # SURVEY 8(c) H1 -> 0.1111111111111111 ; J1 -> 0.6 / 0.4285714285714286 / 0.0014962593516208988
     x = [1, 2, 4, 8, 1, 2, 4, 8, 1]
