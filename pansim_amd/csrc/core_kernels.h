@@ -197,12 +197,35 @@ __device__ __forceinline__ uint32_t ps_candidates_swar(const ps_u4 &l1, uint32_t
            | (ps_bytes_lt(l1.w, c4) >> 3);
 }
 
+// four zero-extended bytes -> one dword (two v_perm + v_or; the compiler's own form masks every byte again)
+__device__ __forceinline__ uint32_t ps_pack4(uint32_t b0, uint32_t b1, uint32_t b2, uint32_t b3)
+{
+    return __builtin_amdgcn_perm(b1, b0, 0x0c0c0400u) | __builtin_amdgcn_perm(b3, b2, 0x04000c0cu);
+}
+
+// child bytes (alleles, bits 0-3) with the low nibbles of the level-1 bytes in bits 4-7
+__device__ __forceinline__ uint32_t ps_stash(uint32_t d, uint32_t l1)
+{
+    return ((l1 & 0x0F0F0F0Fu) << 4) | d;
+}
+
+__device__ __forceinline__ uint4 ps_strip(uint4 v, bool on)
+{
+    const uint32_t m = on ? 0x0F0F0F0Fu : 0xFFFFFFFFu;
+    return make_uint4(v.x & m, v.y & m, v.z & m, v.w & m);
+}
+
 #ifdef PS_STAMP
 #define PS_T(k) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); st_acc[k] += t_ - st_last; st_last = t_; } while (0)
 #else
 #define PS_T(k) do { } while (0)
 #endif
-template <uint32_t PS_ROWS, bool DO_GATHER, bool DO_MUT, bool DO_HR>
+// STASH (host: every candidate byte is below 16, i.e. bC <= 15 -- the default rates): the low nibble of
+// a cell's level-1 byte rides in the high nibble of its child byte in LDS (alleles only use bits 0-3),
+// so a queue entry is just (bit position | lane << 5 | row << 11) -- one v_add per pushed candidate instead
+// of the v_perm byte extraction -- and the dense pass, with every lane busy, decodes the cell address and
+// reads the byte back from the row.  The nibbles are stripped when the row leaves LDS.
+template <uint32_t PS_ROWS, bool DO_GATHER, bool DO_MUT, bool DO_HR, bool STASH>
 __global__ void __launch_bounds__(256, PS_ROWS >= 4 ? 6 : 8) core_sweep_wave_kernel(core_sweep_args a)
 {
 #ifdef PS_STAMP
@@ -217,9 +240,12 @@ __global__ void __launch_bounds__(256, PS_ROWS >= 4 ? 6 : 8) core_sweep_wave_ker
     uint8_t *rowbuf = lds + wave * (PS_ROWS * 1024u + PS_QCAP * 4u);
     uint32_t *q = (uint32_t *)(rowbuf + PS_ROWS * 1024u);
     const ps_core_plan pl = a.plan;
-    const bool events = pl.has_events && (DO_MUT || DO_HR);
+    // (the host launches the mutate / HR variants only for plans that have events: the per-row code below
+    // is straight-line -- no wave-uniform branches around the Philox call, the LDS stores or the tail rows)
+    constexpr bool events = DO_MUT || DO_HR;
     const bool has_chunk = lane < a.cpr;
     const uint32_t i0 = lane * 16u;
+    const uint32_t ld_off = has_chunk ? i0 : 0u;      // lanes past the row load its first bytes; nothing of theirs is stored
     const uint32_t nvalid = (i0 >= a.N) ? 0u : min(16u, a.N - i0);
     uint32_t vperm = 0;
 #pragma unroll
@@ -269,71 +295,85 @@ __global__ void __launch_bounds__(256, PS_ROWS >= 4 ? 6 : 8) core_sweep_wave_ker
         if (batch >= b_hi) break;
         const uint32_t r0 = batch * PS_ROWS;
         const uint32_t nr = min(PS_ROWS, a.rows - r0);
+        // rows past the end of the last batch are processed as copies of the last row and never stored
         uint4 v[PS_ROWS];
 #pragma unroll
-        for (uint32_t rr = 0; rr < PS_ROWS; rr++) {
-            v[rr] = make_uint4(0, 0, 0, 0);
-            if (rr < nr && has_chunk) v[rr] = *(const uint4 *)(a.state + (size_t)(r0 + rr) * a.pitch + i0);
-        }
+        for (uint32_t rr = 0; rr < PS_ROWS; rr++)
+            v[rr] = *(const uint4 *)(a.state + (size_t)min(r0 + rr, a.rows - 1u) * a.pitch + ld_off);
         if (DO_GATHER) {
 #pragma unroll
-            for (uint32_t rr = 0; rr < PS_ROWS; rr++)
-                if (rr < nr && has_chunk) *(uint4 *)(rowbuf + rr * 1024u + i0) = v[rr];
+            for (uint32_t rr = 0; rr < PS_ROWS; rr++) *(uint4 *)(rowbuf + rr * 1024u + i0) = v[rr];
             ps_wave_sync();
         }
         PS_T(0);   // global load + LDS stage
 
+        // Phase 1, row by row: child bytes, level-1 words, candidate masks.  (Interleaving the rows -- all
+        // gathers and Philox chains of a batch in one straight-line block -- needs 71 VGPRs: 7 waves per
+        // SIMD instead of 8, and the kernel, which is latency bound, loses more than the overlap gains:
+        // 0.543 against 0.530 ms.)
         uint32_t qn = 0;        // wave-uniform number of queued candidate cells
+        uint32_t cm[PS_ROWS];
+        ps_u4 l1[PS_ROWS];      // (only the non-STASH push loop reads it back)
 #pragma unroll
         for (uint32_t rr = 0; rr < PS_ROWS; rr++) {
-            if (rr < nr) {
-                uint8_t *row = rowbuf + rr * 1024u;
-                const uint32_t site = a.site_offset + r0 + rr;
-                uint4 d = v[rr];
-                if (DO_GATHER) {
-                    uint32_t w[4];
+            uint8_t *row = rowbuf + rr * 1024u;
+            uint4 d = v[rr];
+            if (DO_GATHER) {
+                uint32_t w[4];
 #pragma unroll
-                    for (int j = 0; j < 4; j++) {
-                        uint32_t x = 0;
+                for (int j = 0; j < 4; j++)
+                    w[j] = ps_pack4(row[pidx[4 * j]], row[pidx[4 * j + 1]], row[pidx[4 * j + 2]], row[pidx[4 * j + 3]]);
+                d = make_uint4(w[0], w[1], w[2], w[3]);
+            }
+            PS_T(1);   // gather
+            cm[rr] = 0;
+            l1[rr] = ps_u4{ 0, 0, 0, 0 };
+            if (events) {
+                l1[rr] = ps_philox(a.site_offset + min(r0 + rr, a.rows - 1u), lane, a.gen, PS_STREAM_CORE_L1, a.k0, a.k1);
+                cm[rr] = ps_candidates_swar(l1[rr], c4) & vperm;
+                if (STASH) {
+                    d.x = ps_stash(d.x, l1[rr].x); d.y = ps_stash(d.y, l1[rr].y);
+                    d.z = ps_stash(d.z, l1[rr].z); d.w = ps_stash(d.w, l1[rr].w);
+                }
+            }
+            PS_T(2);   // level-1 Philox + detection
+            // the LDS row becomes the child row; every gather read precedes this store
+            if (DO_GATHER) ps_wave_sync();
+            if (DO_GATHER || events) *(uint4 *)(row + i0) = d;
+            __builtin_amdgcn_sched_barrier(0);      // keep the rows apart (see above)
+        }
+        if (events) {
+            // Phase 2: compact every candidate cell of the PS_ROWS rows into the wave queue.  ONE loop for all
+            // rows -- its trip count is the largest number of candidates any lane holds in any single row
+            // (about 4-5), not the sum over the rows, and the rows' ballots inside a trip are independent.
+            for (;;) {
+                uint32_t any = cm[0];
 #pragma unroll
-                        for (int b = 0; b < 4; b++) x |= (uint32_t)row[pidx[4 * j + b]] << (8 * b);
-                        w[j] = x;
-                    }
-                    d = make_uint4(w[0], w[1], w[2], w[3]);
-                }
-                PS_T(1);   // gather
-                uint32_t cm = 0;
-                ps_u4 l1 = { 0, 0, 0, 0 };
-                if (events) {
-                    l1 = ps_philox(site, lane, a.gen, PS_STREAM_CORE_L1, a.k0, a.k1);
-                    cm = ps_candidates_swar(l1, c4) & vperm;
-                }
-                PS_T(2);   // level-1 Philox + detection
-                // the LDS row becomes the child row; every gather read precedes this store
-                if (DO_GATHER) ps_wave_sync();
-                if (has_chunk && (DO_GATHER || events)) *(uint4 *)(row + i0) = d;
-                if (events) {
-                    // compact every candidate cell of the row into the wave queue
-                    for (;;) {
-                        const bool act = cm != 0u;
-                        const uint64_t bal = __ballot(act);
-                        if (bal == 0ull) break;
-                        if (act) {
-                            const uint32_t p = __builtin_ctz(cm);
-                            cm &= cm - 1u;
+                for (uint32_t rr = 1; rr < PS_ROWS; rr++) any |= cm[rr];
+                if (__ballot(any != 0u) == 0ull) break;
+#pragma unroll
+                for (uint32_t rr = 0; rr < PS_ROWS; rr++) {
+                    const bool act = cm[rr] != 0u;
+                    const uint64_t bal = __ballot(act);
+                    if (act) {
+                        const uint32_t p = __builtin_ctz(cm[rr]);
+                        cm[rr] &= cm[rr] - 1u;
+                        const uint32_t pos = qn + ps_lane_prefix(bal);
+                        if (STASH) {
+                            if (pos < PS_QCAP) q[pos] = (lane << 5) | (rr << 11) | p;
+                        } else {
                             const uint32_t b = p >> 3, j = 7u - (p & 7u);
                             const uint32_t sel = ((j & 1u) * 4u + b) | 0x0c0c0c00u;
-                            const uint32_t byte = (j & 2u) ? __builtin_amdgcn_perm(l1.w, l1.z, sel)
-                                                           : __builtin_amdgcn_perm(l1.y, l1.x, sel);
-                            const uint32_t pos = qn + ps_lane_prefix(bal);
+                            const uint32_t byte = (j & 2u) ? __builtin_amdgcn_perm(l1[rr].w, l1[rr].z, sel)
+                                                           : __builtin_amdgcn_perm(l1[rr].y, l1[rr].x, sel);
                             if (pos < PS_QCAP) q[pos] = (i0 + 4u * j + b) | (rr << 10) | (byte << 12);
                         }
-                        qn += (uint32_t)__popcll(bal);
                     }
+                    qn += (uint32_t)__popcll(bal);
                 }
-                PS_T(3);   // queue push
             }
         }
+        PS_T(3);   // queue push
         ps_wave_sync();
 
         if (events) {
@@ -348,7 +388,13 @@ __global__ void __launch_bounds__(256, PS_ROWS >= 4 ? 6 : 8) core_sweep_wave_ker
             for (uint32_t base = 0; base < qn; base += 64u) {
                 const uint32_t e = base + lane;
                 const bool valid = e < qn;
-                const uint32_t ent = valid ? q[e] : 0u;
+                uint32_t ent = valid ? q[e] : 0u;
+                if (STASH) {
+                    // (bit position p = 8b + 7 - j of cell 4j + b | lane << 5 | row << 11) -> byte address in rowbuf
+                    const uint32_t p = ent & 31u;
+                    const uint32_t addr = ((ent >> 5) << 4) + 4u * (7u - (p & 7u)) + (p >> 3);
+                    ent = addr | ((uint32_t)(rowbuf[addr] >> 4) << 12);
+                }
                 const uint32_t byte = (ent >> 12) & 0xFFu;
                 uint32_t allele = 0;
                 if (use_lut) {
@@ -395,7 +441,7 @@ __global__ void __launch_bounds__(256, PS_ROWS >= 4 ? 6 : 8) core_sweep_wave_ker
                         const uint32_t ent = q[e];
                         if (ent >> 31) {
                             const uint32_t donor = (ent >> 12) & 1023u;
-                            q[e] = (ent & 4095u) | ((uint32_t)rowbuf[(ent & 3072u) | donor] << 12) | 0x80000000u;
+                            q[e] = (ent & 4095u) | (((uint32_t)rowbuf[(ent & 3072u) | donor] & 15u) << 12) | 0x80000000u;
                         }
                     }
                 }
@@ -416,7 +462,8 @@ __global__ void __launch_bounds__(256, PS_ROWS >= 4 ? 6 : 8) core_sweep_wave_ker
 #pragma unroll
             for (uint32_t rr = 0; rr < PS_ROWS; rr++) {
                 if (rr < nr) {
-                    const uint4 o = (DO_GATHER || events) ? *(const uint4 *)(rowbuf + rr * 1024u + i0) : v[rr];
+                    uint4 o = (DO_GATHER || events) ? *(const uint4 *)(rowbuf + rr * 1024u + i0) : v[rr];
+                    if (STASH && events) { o.x &= 0x0F0F0F0Fu; o.y &= 0x0F0F0F0Fu; o.z &= 0x0F0F0F0Fu; o.w &= 0x0F0F0F0Fu; }
                     *(uint4 *)(a.state + (size_t)(r0 + rr) * a.pitch + i0) = o;
                 }
             }
@@ -460,7 +507,7 @@ struct core_block_geom {
     uint32_t SB;       // segments per wave batch (template parameter PS_SB: 4, or 2 when LDS is short)
 };
 
-template <uint32_t PS_SB, bool PRE, bool DO_GATHER, bool DO_MUT, bool DO_HR>
+template <uint32_t PS_SB, bool PRE, bool DO_GATHER, bool DO_MUT, bool DO_HR, bool STASH>
 __global__ void __launch_bounds__(1024) core_sweep_block_kernel(core_sweep_args a, core_block_geom g)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
@@ -513,6 +560,10 @@ __global__ void __launch_bounds__(1024) core_sweep_block_kernel(core_sweep_args 
         for (uint32_t o = tid * 16u; o < nr * a.pitch; o += blockDim.x * 16u)
             *(uint4 *)(stage + o) = *(const uint4 *)(src + o);
     }
+    // every load issued so far (parent indices, first row group) has landed: tell the compiler's wait-count
+    // model so, or it flushes vmcnt in the batch loop's preheader on EVERY row group -- right behind the
+    // prefetch loads of the next group, which then stop being a prefetch
+    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
     ps_block_sync_lds();
     for (; r0 < a.rows; r0 += gstride) {
         const uint32_t nr = min(g.R, a.rows - r0);
@@ -532,31 +583,28 @@ __global__ void __launch_bounds__(1024) core_sweep_block_kernel(core_sweep_args 
         uint32_t rr0 = first_rr, sg0 = first_sg;
         for (uint32_t item0 = wave * PS_SB; item0 < items; item0 += nw * PS_SB) {
             uint32_t s_base[PS_SB], s_site[PS_SB];   // wave-uniform per slot: LDS offset of the row, site
+            uint32_t s_seg[PS_SB];                   // STASH: LDS offset of the slot's segment
             uint32_t qn = 0;
             uint32_t rr = rr0, sg = sg0;
 #pragma unroll
             for (uint32_t s = 0; s < PS_SB; s++) {
                 s_base[s] = rr * a.pitch;
+                s_seg[s] = rr * a.pitch + sg * 1024u;
                 s_site[s] = a.site_offset + r0 + rr;
                 if (item0 + s < items) {
                     const uint32_t chunk = sg * 64u + lane;
                     const bool has_chunk = chunk < a.cpr;
                     const uint32_t i0 = chunk * 16u;
                     uint8_t *row = rowS + s_base[s];
+                    uint32_t w[4] = { 0u, 0u, 0u, 0u };
                     if (DO_GATHER) {
                         const uint8_t *par = rowA + s_base[s];
                         if (has_chunk) {
-                            uint32_t w[4];
                             if (PRE) {
 #pragma unroll
                                 for (int j = 0; j < 4; j++) {
-                                    uint32_t x = 0;
-#pragma unroll
-                                    for (int b = 0; b < 4; b++) {
-                                        const uint32_t pk = pid[s][(4 * j + b) >> 1];
-                                        x |= (uint32_t)par[(b & 1) ? (pk >> 16) : (pk & 0xFFFFu)] << (8 * b);
-                                    }
-                                    w[j] = x;
+                                    const uint32_t pk0 = pid[s][2 * j], pk1 = pid[s][2 * j + 1];
+                                    w[j] = ps_pack4(par[pk0 & 0xFFFFu], par[pk0 >> 16], par[pk1 & 0xFFFFu], par[pk1 >> 16]);
                                 }
                             } else {
                                 // idxT[k][chunk]: consecutive lanes read consecutive words; entries beyond N
@@ -564,17 +612,15 @@ __global__ void __launch_bounds__(1024) core_sweep_block_kernel(core_sweep_args 
                                 const uint32_t *ip = a.idxT + chunk;
 #pragma unroll
                                 for (int j = 0; j < 4; j++) {
-                                    uint32_t x = 0;
-#pragma unroll
-                                    for (int b = 0; b < 4; b++) {
-                                        x |= (uint32_t)par[*ip] << (8 * b);
-                                        ip += a.cpr;
-                                    }
-                                    w[j] = x;
+                                    w[j] = ps_pack4(par[ip[0]], par[ip[a.cpr]], par[ip[2u * a.cpr]], par[ip[3u * a.cpr]]);
+                                    ip += 4u * a.cpr;
                                 }
                             }
-                            *(uint4 *)(row + i0) = make_uint4(w[0], w[1], w[2], w[3]);
+                            if (!(STASH && events)) *(uint4 *)(row + i0) = make_uint4(w[0], w[1], w[2], w[3]);
                         }
+                    } else if (STASH && events && has_chunk) {
+                        const uint4 cur = *(const uint4 *)(row + i0);
+                        w[0] = cur.x; w[1] = cur.y; w[2] = cur.z; w[3] = cur.w;
                     }
                     if (events) {
                         const uint32_t nvalid = (i0 >= a.N) ? 0u : min(16u, a.N - i0);
@@ -585,7 +631,11 @@ __global__ void __launch_bounds__(1024) core_sweep_block_kernel(core_sweep_args 
                         }
                         const ps_u4 l1 = ps_philox(s_site[s], chunk, a.gen, PS_STREAM_CORE_L1, a.k0, a.k1);
                         uint32_t cm = ps_candidates_swar(l1, c4) & vperm;
+                        if (STASH && has_chunk)      // child bytes with the level-1 nibbles (see the wave sweep)
+                            *(uint4 *)(row + i0) = make_uint4(ps_stash(w[0], l1.x), ps_stash(w[1], l1.y),
+                                                              ps_stash(w[2], l1.z), ps_stash(w[3], l1.w));
                         const uint32_t off0 = s_base[s] + i0;
+                        const uint32_t ebase = (lane << 5) | (s << 11);
                         for (;;) {
                             const bool act = cm != 0u;
                             const uint64_t bal = __ballot(act);
@@ -593,12 +643,16 @@ __global__ void __launch_bounds__(1024) core_sweep_block_kernel(core_sweep_args 
                             if (act) {
                                 const uint32_t p = __builtin_ctz(cm);
                                 cm &= cm - 1u;
-                                const uint32_t b = p >> 3, j = 7u - (p & 7u);
-                                const uint32_t sel = ((j & 1u) * 4u + b) | 0x0c0c0c00u;
-                                const uint32_t byte = (j & 2u) ? __builtin_amdgcn_perm(l1.w, l1.z, sel)
-                                                               : __builtin_amdgcn_perm(l1.y, l1.x, sel);
                                 const uint32_t pos = qn + ps_lane_prefix(bal);
-                                if (pos < g.QW) q[pos] = (off0 + 4u * j + b) | (byte << 20) | (s << 28);
+                                if (STASH) {
+                                    if (pos < g.QW) q[pos] = ebase | p;
+                                } else {
+                                    const uint32_t b = p >> 3, j = 7u - (p & 7u);
+                                    const uint32_t sel = ((j & 1u) * 4u + b) | 0x0c0c0c00u;
+                                    const uint32_t byte = (j & 2u) ? __builtin_amdgcn_perm(l1.w, l1.z, sel)
+                                                                   : __builtin_amdgcn_perm(l1.y, l1.x, sel);
+                                    if (pos < g.QW) q[pos] = (off0 + 4u * j + b) | (byte << 20) | (s << 28);
+                                }
                             }
                             qn += (uint32_t)__popcll(bal);
                         }
@@ -620,7 +674,16 @@ __global__ void __launch_bounds__(1024) core_sweep_block_kernel(core_sweep_args 
             for (uint32_t base = 0; base < qn; base += 64u) {
                 const uint32_t e = base + lane;
                 const bool valid = e < qn;
-                const uint32_t ent = valid ? q[e] : 0u;
+                uint32_t ent = valid ? q[e] : 0u;
+                if (STASH) {
+                    // (bit position p = 8b + 7 - j of cell 4j + b | lane << 5 | slot << 11) -> LDS offset in rowS
+                    const uint32_t p = ent & 31u, sl = ent >> 11;
+                    uint32_t seg = s_seg[0];
+#pragma unroll
+                    for (uint32_t k = 1; k < PS_SB; k++) seg = (sl == k) ? s_seg[k] : seg;
+                    const uint32_t off = seg + (((ent >> 5) & 63u) << 4) + 4u * (7u - (p & 7u)) + (p >> 3);
+                    ent = off | ((uint32_t)(rowS[off] >> 4) << 20) | (sl << 28);
+                }
                 const uint32_t byte = (ent >> 20) & 0xFFu;
                 uint32_t allele = 0;
                 if (use_lut) {
@@ -681,18 +744,48 @@ __global__ void __launch_bounds__(1024) core_sweep_block_kernel(core_sweep_args 
                 nhr = g.HW;
             }
             ps_block_sync_lds();    // every segment is mutated: rowS is the snapshot (population.rs:693-695)
-            for (uint32_t e = lane; e < nhr; e += 64u) hr_b[e] = (uint32_t)rowS[hr_b[e]];
+            for (uint32_t e = lane; e < nhr; e += 64u) hr_b[e] = (uint32_t)rowS[hr_b[e]] & 15u;
             ps_block_sync_lds();    // all donor reads done
             for (uint32_t e = lane; e < nhr; e += 64u) rowS[hr_a[e]] = (uint8_t)hr_b[e];
         }
         ps_block_sync_lds();        // the child rows are final; nobody reads the parent rows any more
+        // The prefetch has had the whole group's compute time to land.  The wait is explicit and on every
+        // path: only the prefetch loads and the previous group's long-finished stores are outstanding
+        // here, so vmcnt(0) is exact -- whereas waits the compiler attaches to the conditional LDS stores
+        // below leave loads pending in its model on the skipped paths and come back as vmcnt waits at the
+        // loop top, i.e. behind this group's stores (vmcnt counts loads and stores in issue order): one
+        // exposed HBM write latency per row group.
+        __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
+        // With a separate parent buffer the prefetched group is staged BEFORE this group's stores are issued.
+        const bool stage_first = DO_GATHER && pipelined;
+        if (stage_first) {
+            if (po0 < nbytes_next) *(uint4 *)(stage + po0) = pf0;
+            if (po1 < nbytes_next) *(uint4 *)(stage + po1) = pf1;
+            if (po2 < nbytes_next) *(uint4 *)(stage + po2) = pf2;
+            if (po3 < nbytes_next) *(uint4 *)(stage + po3) = pf3;
+        }
         {
             uint8_t *dstg = a.state + (size_t)r0 * a.pitch;
-            for (uint32_t o = tid * 16u; o < nr * a.pitch; o += blockDim.x * 16u)
-                *(uint4 *)(dstg + o) = *(const uint4 *)(rowS + o);
+            const uint32_t nbytes = nr * a.pitch;
+            if (pipelined) {
+                // at most PS_PF pieces per thread: the LDS reads together, then the stores
+                uint4 o0 = make_uint4(0, 0, 0, 0), o1 = o0, o2 = o0, o3 = o0;
+                if (po0 < nbytes) o0 = ps_strip(*(const uint4 *)(rowS + po0), STASH && events);
+                if (po1 < nbytes) o1 = ps_strip(*(const uint4 *)(rowS + po1), STASH && events);
+                if (po2 < nbytes) o2 = ps_strip(*(const uint4 *)(rowS + po2), STASH && events);
+                if (po3 < nbytes) o3 = ps_strip(*(const uint4 *)(rowS + po3), STASH && events);
+                if (po0 < nbytes) *(uint4 *)(dstg + po0) = o0;
+                if (po1 < nbytes) *(uint4 *)(dstg + po1) = o1;
+                if (po2 < nbytes) *(uint4 *)(dstg + po2) = o2;
+                if (po3 < nbytes) *(uint4 *)(dstg + po3) = o3;
+            } else {
+                for (uint32_t o = tid * 16u; o < nbytes; o += blockDim.x * 16u)
+                    *(uint4 *)(dstg + o) = ps_strip(*(const uint4 *)(rowS + o), STASH && events);
+            }
         }
         // stage the next row group; a thread overwrites only LDS bytes it has just read itself
-        if (pipelined) {
+        if (stage_first) {
+        } else if (pipelined) {
             if (po0 < nbytes_next) *(uint4 *)(stage + po0) = pf0;
             if (po1 < nbytes_next) *(uint4 *)(stage + po1) = pf1;
             if (po2 < nbytes_next) *(uint4 *)(stage + po2) = pf2;

@@ -563,7 +563,11 @@ static int launch_core_sweep_wave_r(ps_population *p, const core_sweep_args &a, 
     const uint32_t fit = std::max(1u, std::min(8u, p->lds_limit / lds));
     const uint32_t bpc = std::min(p->sweep_blocks_per_cu, fit);
     const uint32_t grid = std::max(8u, std::min((want + 7u) & ~7u, 256u * bpc));   // a multiple of the 8 groups
-    hipLaunchKernelGGL((core_sweep_wave_kernel<ROWS, GA, MU, HR>), dim3(grid), dim3(block), lds, st, a);
+    // every candidate byte below 16: the level-1 nibble rides in the child byte (core_kernels.h, STASH)
+    if (a.plan.has_events && a.plan.bC <= 15u)
+        hipLaunchKernelGGL((core_sweep_wave_kernel<ROWS, GA, MU, HR, true>), dim3(grid), dim3(block), lds, st, a);
+    else
+        hipLaunchKernelGGL((core_sweep_wave_kernel<ROWS, GA, MU, HR, false>), dim3(grid), dim3(block), lds, st, a);
     HIPCHK(hipGetLastError());
     return PS_OK;
 }
@@ -640,10 +644,10 @@ static bool block_sweep_preload(const ps_population *p, const core_block_geom &g
     return p->pitch <= 65536u && g.R * g.segs <= nw * g.SB && !p->no_block_preload;
 }
 
-template <uint32_t SB, bool PRE, bool GA, bool MU, bool HR>
-static int launch_block_kernel(const core_sweep_args &a, const core_block_geom &g, uint32_t lds, uint32_t nw, hipStream_t st)
+template <uint32_t SB, bool PRE, bool GA, bool MU, bool HR, bool STASH>
+static int launch_block_kernel_s(const core_sweep_args &a, const core_block_geom &g, uint32_t lds, uint32_t nw, hipStream_t st)
 {
-    auto kern = core_sweep_block_kernel<SB, PRE, GA, MU, HR>;
+    auto kern = core_sweep_block_kernel<SB, PRE, GA, MU, HR, STASH>;
     if (lds > 64 * 1024)
         HIPCHK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const uint32_t groups = (a.rows + g.R - 1) / g.R;
@@ -654,6 +658,14 @@ static int launch_block_kernel(const core_sweep_args &a, const core_block_geom &
     hipLaunchKernelGGL(kern, dim3(grid), dim3(64u * nw), lds, st, a, g);
     HIPCHK(hipGetLastError());
     return PS_OK;
+}
+
+template <uint32_t SB, bool PRE, bool GA, bool MU, bool HR>
+static int launch_block_kernel(const core_sweep_args &a, const core_block_geom &g, uint32_t lds, uint32_t nw, hipStream_t st)
+{
+    // every candidate byte below 16: the level-1 nibble rides in the child byte (core_kernels.h, STASH)
+    if (a.plan.has_events && a.plan.bC <= 15u) return launch_block_kernel_s<SB, PRE, GA, MU, HR, true>(a, g, lds, nw, st);
+    return launch_block_kernel_s<SB, PRE, GA, MU, HR, false>(a, g, lds, nw, st);
 }
 
 template <bool GA, bool MU, bool HR>
@@ -707,7 +719,10 @@ static int launch_core_sweep(ps_population *p, const uint32_t *d_idx, uint32_t g
     a.k0 = (uint32_t)p->cfg.seed;
     a.k1 = (uint32_t)(p->cfg.seed >> 32);
     a.plan = p->cplan;
+    // the kernels' mutate / HR variants assume a plan with events (straight-line per-row code)
+    if (!a.plan.has_events) mu = hr = false;
     if (!mu && !hr) a.plan.has_events = 0;
+    if (!ga && !mu && !hr) return PS_OK;
     const bool wave = wave_sweep_eligible(p, mu, hr);
     a.overflow_flag = p->d_flag;
     a.stamps = p->d_stamps;
