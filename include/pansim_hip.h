@@ -246,6 +246,29 @@ int ps_sim_sweep_timing(ps_sim *s, int reset, uint64_t *launches, double *total_
                         double *bytes_per_launch);
 int ps_sim_enable_timing(ps_sim *s, int on);
 
+/* ------------------------------------------------------------------------ */
+/* one process, several devices: the run sharded by core site  */
+/* ------------------------------------------------------------------------ */
+/* main() of the reference is one process (main.rs:429-553).  ps_multi holds one ps_sim per site shard,
+ * shard k on HIP device devices[k] (null: k modulo the visible devices; ordinals may repeat, i.e. several
+ * shards on one GPU), each driven by its own host thread inside a call.  A generation needs no exchange
+ * between the shards; the distance phase sums the shards' integer Hamming numerators on shard 0's device
+ * (device-to-device copies).  All results equal those of the unsharded run bit for bit. */
+typedef struct ps_multi ps_multi;
+int ps_multi_create(const ps_sim_params *p, int n_shards, const int *devices, ps_multi **out);
+void ps_multi_destroy(ps_multi *m);
+int ps_multi_shards(ps_multi *m);
+ps_sim *ps_multi_shard(ps_multi *m, int k);      /* borrowed: selection coefficients, pair list, accessory matrix */
+/* main.rs:429-464 for generations [first, first+count) on every shard */
+int ps_multi_run(ps_multi *m, uint32_t first_generation, uint32_t count);
+int ps_multi_sync(ps_multi *m);
+/* population.rs:787-837 for the run's pair list: core numerators summed over the shards (out_core: P values) */
+int ps_multi_pairwise_counts(ps_multi *m, uint32_t *out_core);
+/* main.rs:467-470: core and accessory distances of the run's pair list (P values each) */
+int ps_multi_pairwise_distances(ps_multi *m, double *core_out, double *acc_out);
+/* main.rs:550-553: <outpref>_core_genome.csv (lines assembled from the shards' columns) and _pangenome.csv */
+int ps_multi_write(ps_multi *m, const char *outpref);
+
 #ifdef __cplusplus
 }
 #endif

@@ -7,7 +7,7 @@ HIP kernels; there is no CPU fallback and importing the API without the built li
 from ._lib import LIB_PATH, PansimError, load  # noqa: F401
 from .population import (Population, draw_parents, fmt_f64, hamming_bitwise_fast, init_vector,  # noqa: F401
                          int_to_base, jaccard_distance_fast, sample_weights, standard_deviation)
-from .simulation import (DEFAULTS, Simulation, derive, make_params, sample_pairs,  # noqa: F401
+from .simulation import (DEFAULTS, MultiSimulation, Simulation, derive, make_params, sample_pairs,  # noqa: F401
                          selection_coefficients, validate)
 
 __version__ = "0.1.0"

@@ -883,7 +883,7 @@ __global__ void __launch_bounds__(256) core_transpose_kernel(uint8_t *state, uin
 // '\n', 2*L bytes per individual -- produced from the site-major state through a 64x64 LDS tile so
 // that both the state reads and the text writes are coalesced.
 __global__ void __launch_bounds__(256) core_csv_kernel(const uint8_t *state, uint8_t *text, uint32_t pitch,
-                                                       uint64_t L, uint32_t i0, uint32_t ni)
+                                                       uint64_t L, uint32_t i0, uint32_t ni, uint8_t last_char)
 {
     __shared__ uint8_t tile[64][65];
     const uint32_t tx = threadIdx.x & 63u, ty = threadIdx.x >> 6;
@@ -906,7 +906,7 @@ __global__ void __launch_bounds__(256) core_csv_kernel(const uint8_t *state, uin
             const uint64_t s = s0 + (c >> 1);
             if (s >= L) continue;
             uint8_t ch;
-            if (c & 1u) ch = (s == L - 1) ? '\n' : ',';
+            if (c & 1u) ch = (s == L - 1) ? last_char : ',';      // (a site shard that is not the last one ends in ',')
             else {
                 const uint8_t v = tile[c >> 1][r];
                 ch = (v == 1) ? 'A' : (v == 2) ? 'C' : (v == 4) ? 'G' : (v == 8) ? 'T' : 'N';
@@ -1425,6 +1425,13 @@ __global__ void __launch_bounds__(256) core_pair_counts_simple(
         acc += __popc((uint32_t)(row[i] ^ row[j]));
     }
     if (acc) atomicAdd(&out[perm ? perm[k] : k], acc);
+}
+
+// dst[k] += src[k]: partial Hamming numerators of the site shards of one process (ps_multi)
+__global__ void __launch_bounds__(256) u32_add_kernel(uint32_t *dst, const uint32_t *src, uint64_t n)
+{
+    const uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < n) dst[k] += src[k];
 }
 
 // distances.rs:22-52 / :55-77 on two byte slices already in device memory

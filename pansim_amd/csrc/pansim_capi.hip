@@ -16,6 +16,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "acc_kernels.h"
@@ -1602,7 +1603,7 @@ extern "C" int ps_write(ps_population *p, const char *outpref)
         for (uint64_t i0 = 0; rc == PS_OK && i0 < N; i0 += chunk, k ^= 1) {
             const uint32_t ni = (uint32_t)std::min<uint64_t>(chunk, N - i0);
             dim3 grid((uint32_t)((C + 63) / 64), (ni + 63) / 64);
-            core_csv_kernel<<<grid, 256, 0, p->stream>>>(p->state, d_text, p->pitch, C, (uint32_t)i0, ni);
+            core_csv_kernel<<<grid, 256, 0, p->stream>>>(p->state, d_text, p->pitch, C, (uint32_t)i0, ni, (uint8_t)'\n');
             if (hipMemcpyAsync(h_text[k], d_text, (uint64_t)ni * row_bytes, hipMemcpyDeviceToHost, p->stream) != hipSuccess)
                 rc = ps_fail(PS_ERR_NO_DEVICE, "D2H copy failed in ps_write");
             if (pending_buf >= 0 && fwrite(h_text[pending_buf], 1, pending, f) != pending)
@@ -2121,4 +2122,226 @@ extern "C" int ps_sim_sweep_timing(ps_sim *s, int reset, uint64_t *launches, dou
         s->tev.clear();
     }
     return PS_OK;
+}
+
+// ---------------------------------------------------------------------------
+// Several site shards in one process (main.rs:429-553 is one process): ps_multi
+// ---------------------------------------------------------------------------
+// One ps_sim per shard of the core sites, each on its own device (ordinals may repeat: two
+// shards on one GPU), each driven by its own host thread for the duration of a call.  The shards never
+// talk to each other during a generation (the accessory matrix is replicated and every shard draws the
+// same parents); the one exchange step is the sum of the P Hamming numerators of the distance phase.
+struct ps_multi {
+    ps_sim_params prm{};
+    std::vector<ps_sim *> shard;
+    std::vector<uint32_t *> d_cnt;      // per shard, on its device: P numerators
+    uint32_t *d_tmp = nullptr;          // on shard 0's device: landing buffer of the peer copies
+    uint64_t cnt_cap = 0;
+};
+
+// run fn(k) for every shard on its own host thread; the first failure (with its message) is returned
+template <typename F>
+static int multi_for_each(ps_multi *m, F fn)
+{
+    const size_t n = m->shard.size();
+    std::vector<int> rc(n, PS_OK);
+    std::vector<std::string> err(n);
+    auto body = [&](size_t k) {
+        rc[k] = fn(k);
+        if (rc[k] != PS_OK) err[k] = g_err;      // g_err is thread local
+    };
+    if (n == 1) {
+        body(0);
+    } else {
+        std::vector<std::thread> th;
+        for (size_t k = 0; k < n; k++) th.emplace_back(body, k);
+        for (auto &t : th) t.join();
+    }
+    for (size_t k = 0; k < n; k++)
+        if (rc[k] != PS_OK) { g_err = err[k]; return rc[k]; }
+    return PS_OK;
+}
+
+extern "C" void ps_multi_destroy(ps_multi *m)
+{
+    if (!m) return;
+    for (size_t k = 0; k < m->shard.size(); k++) {
+        if (m->shard[k] && m->shard[k]->core) (void)hipSetDevice(m->shard[k]->core->device);
+        if (k < m->d_cnt.size() && m->d_cnt[k]) (void)hipFree(m->d_cnt[k]);
+        if (k == 0 && m->d_tmp) (void)hipFree(m->d_tmp);
+        ps_sim_destroy(m->shard[k]);
+    }
+    delete m;
+}
+
+extern "C" int ps_multi_create(const ps_sim_params *p, int n_shards, const int *devices, ps_multi **out)
+{
+    if (!p || !out) return ps_fail(PS_ERR_INVALID, "null argument");
+    *out = nullptr;
+    if (n_shards < 1 || n_shards > 1024) return ps_fail(PS_ERR_INVALID, "n_shards must be 1..1024");
+    if ((uint64_t)n_shards > p->core_size) return ps_fail(PS_ERR_INVALID, "more shards than core sites");
+    if (p->shard_count != 1 || p->shard_rank != 0)
+        return ps_fail(PS_ERR_INVALID, "ps_multi_create shards the run itself: pass shard_rank 0, shard_count 1");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return ps_fail(PS_ERR_NO_DEVICE, "no HIP device is visible: libpansim_hip has no CPU path");
+    ps_multi *m = new ps_multi();
+    m->prm = *p;
+    m->shard.assign((size_t)n_shards, nullptr);
+    m->d_cnt.assign((size_t)n_shards, nullptr);
+    // (created one after the other: each creation synchronises its device anyway)
+    for (int k = 0; k < n_shards; k++) {
+        ps_sim_params q = *p;
+        q.shard_rank = k;
+        q.shard_count = n_shards;
+        q.device = devices ? devices[k] : (p->device >= 0 && n_shards == 1 ? p->device : k % ndev);
+        const int rc = ps_sim_create(&q, &m->shard[(size_t)k]);
+        if (rc != PS_OK) {
+            const std::string keep = g_err;
+            ps_multi_destroy(m);
+            g_err = keep;
+            return rc;
+        }
+    }
+    *out = m;
+    return PS_OK;
+}
+
+extern "C" int ps_multi_shards(ps_multi *m) { return m ? (int)m->shard.size() : 0; }
+extern "C" ps_sim *ps_multi_shard(ps_multi *m, int k)
+{
+    return (m && k >= 0 && (size_t)k < m->shard.size()) ? m->shard[(size_t)k] : nullptr;
+}
+
+extern "C" int ps_multi_run(ps_multi *m, uint32_t first_generation, uint32_t count)
+{
+    if (!m) return ps_fail(PS_ERR_INVALID, "null handle");
+    return multi_for_each(m, [&](size_t k) { return ps_sim_run(m->shard[k], first_generation, count); });
+}
+
+extern "C" int ps_multi_sync(ps_multi *m)
+{
+    if (!m) return ps_fail(PS_ERR_INVALID, "null handle");
+    return multi_for_each(m, [&](size_t k) { return ps_sim_sync(m->shard[k]); });
+}
+
+// Hamming numerators of the run's sampled pairs over ALL core sites: every shard counts its sites into a
+// buffer on its own device; the partial counts are then copied device to device onto shard 0's GPU
+// (hipMemcpyPeerAsync: xGMI between GPUs, a plain copy inside one) and added there.
+static int multi_core_counts(ps_multi *m, uint32_t **d_total)
+{
+    const uint64_t P = m->prm.max_distances;
+    ps_population *c0 = m->shard[0]->core;
+    if (m->cnt_cap < P) {
+        for (size_t k = 0; k < m->shard.size(); k++) {
+            PSCHK(use_device(m->shard[k]->core));
+            if (m->d_cnt[k]) HIPCHK(hipFree(m->d_cnt[k]));
+            m->d_cnt[k] = nullptr;
+            HIPCHK(hipMalloc(&m->d_cnt[k], std::max<uint64_t>(P, 1) * sizeof(uint32_t)));
+        }
+        PSCHK(use_device(c0));
+        if (m->d_tmp) HIPCHK(hipFree(m->d_tmp));
+        m->d_tmp = nullptr;
+        HIPCHK(hipMalloc(&m->d_tmp, std::max<uint64_t>(P, 1) * sizeof(uint32_t)));
+        m->cnt_cap = P;
+    }
+    PSCHK(multi_for_each(m, [&](size_t k) {
+        ps_sim *s = m->shard[k];
+        PSCHK(ps_sim_sync(s));
+        return ps_pairwise_counts(s->core, P, s->r1.data(), s->r2.data(), m->d_cnt[k], nullptr, 1);
+    }));
+    PSCHK(use_device(c0));
+    for (size_t k = 1; k < m->shard.size(); k++) {
+        HIPCHK(hipMemcpyPeerAsync(m->d_tmp, c0->device, m->d_cnt[k], m->shard[k]->core->device, P * sizeof(uint32_t), c0->stream));
+        u32_add_kernel<<<(uint32_t)((P + 255) / 256), 256, 0, c0->stream>>>(m->d_cnt[0], m->d_tmp, P);
+        HIPCHK(hipGetLastError());
+    }
+    *d_total = m->d_cnt[0];
+    return PS_OK;
+}
+
+extern "C" int ps_multi_pairwise_counts(ps_multi *m, uint32_t *out_core)
+{
+    if (!m || !out_core) return ps_fail(PS_ERR_INVALID, "null argument");
+    const uint64_t P = m->prm.max_distances;
+    uint32_t *d_total = nullptr;
+    PSCHK(multi_core_counts(m, &d_total));
+    ps_population *c0 = m->shard[0]->core;
+    HIPCHK(hipMemcpyAsync(out_core, d_total, P * sizeof(uint32_t), hipMemcpyDeviceToHost, c0->stream));
+    HIPCHK(hipStreamSynchronize(c0->stream));
+    return PS_OK;
+}
+
+// Population::pairwise_distances of both matrices for the run's pair list (main.rs:467-470)
+extern "C" int ps_multi_pairwise_distances(ps_multi *m, double *core_out, double *acc_out)
+{
+    if (!m || !core_out || !acc_out) return ps_fail(PS_ERR_INVALID, "null argument");
+    const uint64_t P = m->prm.max_distances;
+    std::vector<uint32_t> cnt(P);
+    PSCHK(ps_multi_pairwise_counts(m, cnt.data()));
+    const double ncols = (double)m->prm.core_size;
+    for (uint64_t k = 0; k < P; k++) {
+        const uint32_t distance = cnt[k] / 2;                       // population.rs:817
+        core_out[k] = (double)distance / ncols;                     // :822
+    }
+    ps_sim *s0 = m->shard[0];
+    return ps_pairwise_distances(s0->acc, P, s0->r1.data(), s0->r2.data(), acc_out);
+}
+
+// Population::write for both matrices (main.rs:550-553): every line of <outpref>_core_genome.csv is the
+// concatenation of the shards' columns, expanded on each shard's device
+extern "C" int ps_multi_write(ps_multi *m, const char *outpref)
+{
+    if (!m || !outpref) return ps_fail(PS_ERR_INVALID, "null argument");
+    const size_t K = m->shard.size();
+    if (K == 1) {
+        PSCHK(ps_write(m->shard[0]->core, outpref));
+        return ps_write(m->shard[0]->acc, outpref);
+    }
+    PSCHK(ps_multi_sync(m));
+    const uint64_t N = m->prm.pop_size, L = m->prm.core_size;
+    const std::string path = std::string(outpref) + "_core_genome.csv";
+    FILE *f = fopen(path.c_str(), "w");
+    if (!f) return ps_fail(PS_ERR_IO, "cannot create %s", path.c_str());
+    const uint32_t chunk = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(N, (256ull << 20) / (2 * L)));
+    std::vector<uint8_t *> d_text(K, nullptr), h_text(K, nullptr);
+    int rc = PS_OK;
+    for (size_t k = 0; k < K && rc == PS_OK; k++) {
+        ps_population *c = m->shard[k]->core;
+        const uint64_t bytes = std::max<uint64_t>((uint64_t)chunk * 2 * c->cfg.ncols, 1);
+        if (hipSetDevice(c->device) != hipSuccess || hipMalloc(&d_text[k], bytes) != hipSuccess
+            || hipHostMalloc(&h_text[k], bytes) != hipSuccess)
+            rc = ps_fail(PS_ERR_OOM, "cannot allocate the text buffers of ps_multi_write");
+    }
+    for (uint64_t i0 = 0; rc == PS_OK && i0 < N; i0 += chunk) {
+        const uint32_t ni = (uint32_t)std::min<uint64_t>(chunk, N - i0);
+        rc = multi_for_each(m, [&](size_t k) {
+            ps_population *c = m->shard[k]->core;
+            const uint64_t C = c->cfg.ncols;
+            PSCHK(use_device(c));
+            dim3 grid((uint32_t)((C + 63) / 64), (ni + 63) / 64);
+            core_csv_kernel<<<grid, 256, 0, c->stream>>>(c->state, d_text[k], c->pitch, C, (uint32_t)i0, ni,
+                                                         (uint8_t)(k + 1 == K ? '\n' : ','));
+            HIPCHK(hipGetLastError());
+            HIPCHK(hipMemcpyAsync(h_text[k], d_text[k], (uint64_t)ni * 2 * C, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(hipStreamSynchronize(c->stream));
+            return (int)PS_OK;
+        });
+        for (uint32_t i = 0; rc == PS_OK && i < ni; i++)
+            for (size_t k = 0; k < K; k++) {
+                const uint64_t rb = 2 * m->shard[k]->core->cfg.ncols;
+                if (fwrite(h_text[k] + (uint64_t)i * rb, 1, rb, f) != rb) {
+                    rc = ps_fail(PS_ERR_IO, "short write to %s", path.c_str());
+                    break;
+                }
+            }
+    }
+    for (size_t k = 0; k < K; k++) {
+        (void)hipSetDevice(m->shard[k]->core->device);
+        if (d_text[k]) (void)hipFree(d_text[k]);
+        if (h_text[k]) (void)hipHostFree(h_text[k]);
+    }
+    fclose(f);
+    PSCHK(rc);
+    return ps_write(m->shard[0]->acc, outpref);
 }

@@ -44,6 +44,12 @@ static const Flag FLAGS[] = {
     { "competition_strength", "Strength of competition felt by strain to all others. 0.0 = no competition", "0.0", true },
 };
 
+// not a flag of the reference: number of core-site shards of this process, shard k on device k modulo the
+// visible GPUs (include/pansim_hip.h, ps_multi); results do not depend on it
+static const Flag EXT_FLAGS[] = {
+    { "gpus", "Number of core-site shards, one per GPU (more shards than GPUs share them). Results do not depend on it.", "1", true },
+};
+
 static void print_help()
 {
     printf("pansim 0.1.0\nSamuel Horsfield shorsfield@ebi.ac.uk\nRuns Wright-Fisher simulation, simulating neutral core genome "
@@ -53,6 +59,8 @@ static void print_help()
         else printf("        --%s\n            %s\n\n", f.name, f.help);
     }
     printf("    -h, --help\n            Print help information\n\n    -V, --version\n            Print version information\n");
+    printf("\nMI355X OPTIONS (not in the reference):\n");
+    for (const Flag &f : EXT_FLAGS) printf("        --%s <%s>\n            %s [default: %s]\n\n", f.name, f.name, f.help, f.def);
 }
 
 [[noreturn]] static void die(int code, const std::string &msg)
@@ -141,6 +149,7 @@ int main(int argc, char **argv)
         if (f.takes_value) val[f.name] = f.def;
         else present[f.name] = false;
     }
+    for (const Flag &f : EXT_FLAGS) val[f.name] = f.def;
     for (int i = 1; i < argc; i++) {
         std::string a = argv[i];
         if (a == "-h" || a == "--help") { print_help(); return 0; }
@@ -153,6 +162,8 @@ int main(int argc, char **argv)
         if (eq != std::string::npos) { value = name.substr(eq + 1); name = name.substr(0, eq); has_eq = true; }
         const Flag *fl = nullptr;
         for (const Flag &f : FLAGS)
+            if (name == f.name) fl = &f;
+        for (const Flag &f : EXT_FLAGS)
             if (name == f.name) fl = &f;
         if (!fl)
             die(2, "error: Found argument '--" + name + "' which wasn't expected, or isn't valid in this context\n\nUSAGE:\n    pansim [OPTIONS]\n\nFor more information try --help");
@@ -216,8 +227,12 @@ int main(int argc, char **argv)
     CK(ps_sim_derive(&p, &d));
     if (p.verbose) printf("avg_gene_freq adjusted to %s\n", fmt(d.avg_gene_freq_adj).c_str()); // main.rs:269-271
 
-    ps_sim *sim = nullptr;
-    CK(ps_sim_create(&p, &sim));
+    // one ps_sim per core-site shard (one shard: the plain run); main.rs:372-427
+    const uint64_t n_shards = as_u64(val, "gpus");
+    if (n_shards < 1 || n_shards > 1024) die(101, "pansim: --gpus must be 1..1024");
+    ps_multi *multi = nullptr;
+    CK(ps_multi_create(&p, (int)n_shards, nullptr, &multi));
+    ps_sim *sim = ps_multi_shard(multi, 0);
     const uint64_t G = d.pan_size, P = p.max_distances;
 
     if (p.print_selection) {                                           // main.rs:321-331
@@ -229,18 +244,16 @@ int main(int argc, char **argv)
         fclose(f);
     }
 
-    ps_population *core = ps_sim_core(sim), *acc = ps_sim_acc(sim);
-    const uint32_t *r1 = ps_sim_range1(sim), *r2 = ps_sim_range2(sim);
+    ps_population *acc = ps_sim_acc(sim);      // replicated on every shard
     std::vector<double> avg_core(p.n_gen), avg_acc(p.n_gen), std_core(p.n_gen), std_acc(p.n_gen);
     std::vector<double> cd(P), ad(P);
     const bool stepwise = p.print_dist || p.verbose;
-    if (!stepwise) CK(ps_sim_run(sim, 0, (uint32_t)p.n_gen));          // main.rs:429-464
+    if (!stepwise) CK(ps_multi_run(multi, 0, (uint32_t)p.n_gen));      // main.rs:429-464
     for (int32_t j = 0; j < p.n_gen; j++) {
-        if (stepwise) CK(ps_sim_run(sim, (uint32_t)j, 1));
+        if (stepwise) CK(ps_multi_run(multi, (uint32_t)j, 1));
         if (j == p.n_gen - 1) {                                        // main.rs:467-499
-            CK(ps_sim_sync(sim));
-            CK(ps_pairwise_distances(core, P, r1, r2, cd.data()));
-            CK(ps_pairwise_distances(acc, P, r1, r2, ad.data()));
+            CK(ps_multi_sync(multi));
+            CK(ps_multi_pairwise_distances(multi, cd.data(), ad.data()));
             FILE *f = fopen((outpref + ".tsv").c_str(), "w");
             if (!f) die(1, "Error: cannot create " + outpref + ".tsv");
             write_pairs_tsv(f, cd, ad);
@@ -253,16 +266,15 @@ int main(int argc, char **argv)
             fclose(f);
         }
         if (p.print_dist) {                                            // main.rs:502-519
-            CK(ps_sim_sync(sim));
-            CK(ps_pairwise_distances(core, P, r1, r2, cd.data()));
-            CK(ps_pairwise_distances(acc, P, r1, r2, ad.data()));
+            CK(ps_multi_sync(multi));
+            CK(ps_multi_pairwise_distances(multi, cd.data(), ad.data()));
             CK(ps_standard_deviation(cd.data(), P, &std_core[j], &avg_core[j]));
             CK(ps_standard_deviation(ad.data(), P, &std_acc[j], &avg_acc[j]));
         }
         if (p.verbose) {                                               // main.rs:522-526
             printf("Finished gen: %d\n", j + 1);
             double gf = 0.0;
-            CK(ps_sim_sync(sim));
+            CK(ps_multi_sync(multi));
             CK(ps_calc_gene_freq(acc, &gf));
             printf("avg_gene_freq: %s\n", fmt(gf).c_str());
         }
@@ -276,9 +288,8 @@ int main(int argc, char **argv)
         fclose(f);
     }
     if (p.print_matrices) {                                            // main.rs:550-553 (errors ignored)
-        (void)ps_write(core, outpref.c_str());
-        (void)ps_write(acc, outpref.c_str());
+        (void)ps_multi_write(multi, outpref.c_str());
     }
-    ps_sim_destroy(sim);
+    ps_multi_destroy(multi);
     return 0;
 }

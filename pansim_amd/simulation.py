@@ -59,12 +59,14 @@ def sample_pairs(seed, pop_size, max_distances):
 class Simulation:
     """State of main() between main.rs:259 and :553 for one process (one GPU)."""
 
-    def __init__(self, params=None, **kw):
+    def __init__(self, params=None, _handle=None, **kw):
         self._lib = _lib.load()
         self.params = params if params is not None else make_params(**kw)
         self.derived = derive(self.params)
-        self._h = C.c_void_p()
-        check(self._lib.ps_sim_create(C.byref(self.params), C.byref(self._h)))
+        self._owned = _handle is None
+        self._h = C.c_void_p(_handle) if _handle is not None else C.c_void_p()
+        if self._owned:
+            check(self._lib.ps_sim_create(C.byref(self.params), C.byref(self._h)))
         p, d = self.params, self.derived
         sb = p.core_size * p.shard_rank // p.shard_count
         se = p.core_size * (p.shard_rank + 1) // p.shard_count
@@ -82,7 +84,7 @@ class Simulation:
         self.generation = 0
 
     def close(self):
-        if getattr(self, "_h", None) and self._h.value:
+        if getattr(self, "_h", None) and self._h.value and self._owned:
             self._lib.ps_sim_destroy(self._h)
         self._h = C.c_void_p()
 
@@ -133,5 +135,61 @@ class Simulation:
             self.pan_genome.write(outpref)
 
 
-__all__ = ["Simulation", "make_params", "validate", "derive", "selection_coefficients", "sample_pairs",
+class MultiSimulation:
+    """The run sharded by core site inside ONE process (ps_multi): shard k on HIP device devices[k]
+    (ordinals may repeat), one host thread per shard inside each call; results equal the unsharded run."""
+
+    def __init__(self, params, n_shards, devices=None):
+        self._lib = _lib.load()
+        self.params = params
+        self._h = C.c_void_p()
+        dev = None
+        if devices is not None:
+            dev = (C.c_int * int(n_shards))(*[int(x) for x in devices])
+        check(self._lib.ps_multi_create(C.byref(params), int(n_shards), dev, C.byref(self._h)))
+        self.n_shards = self._lib.ps_multi_shards(self._h)
+        self.shards = []
+        for k in range(self.n_shards):
+            q = make_params(**{f: getattr(params, f) for f, _ in params._fields_})
+            q.shard_rank, q.shard_count = k, self.n_shards
+            self.shards.append(Simulation(q, _handle=self._lib.ps_multi_shard(self._h, k)))
+        self.range1, self.range2 = self.shards[0].range1, self.shards[0].range2
+        self.pan_genome = self.shards[0].pan_genome
+        self.generation = 0
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            self._lib.ps_multi_destroy(self._h)
+        self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def run(self, count, first_generation=None):
+        g0 = self.generation if first_generation is None else int(first_generation)
+        check(self._lib.ps_multi_run(self._h, g0, int(count)))
+        self.generation = g0 + int(count)
+
+    def sync(self):
+        check(self._lib.ps_multi_sync(self._h))
+
+    def pairwise_counts(self):
+        out = np.zeros(self.params.max_distances, np.uint32)
+        check(self._lib.ps_multi_pairwise_counts(self._h, out))
+        return out
+
+    def final_distances(self):
+        P = self.params.max_distances
+        core, acc = np.zeros(P), np.zeros(P)
+        check(self._lib.ps_multi_pairwise_distances(self._h, core, acc))
+        return core, acc
+
+    def write(self, outpref):
+        check(self._lib.ps_multi_write(self._h, str(outpref).encode()))
+
+
+__all__ = ["Simulation", "MultiSimulation", "make_params", "validate", "derive", "selection_coefficients", "sample_pairs",
            "DEFAULTS", "standard_deviation"]

@@ -1,0 +1,66 @@
+"""Several core-site shards inside one process behind the C ABI (ps_multi, `pansim --gpus N`): main() of the
+reference is one process (main.rs:429-553).  On a one-GPU box every shard sits on device 0; results must
+equal the unsharded run bit for bit (a generation needs no exchange between the shards, the distance phase
+sums integer numerators)."""
+import filecmp
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.parametrize("n_shards", [2, 3])
+def test_multi_shards_equal_unsharded(pa, orc, n_shards):
+    from orc_sim import OracleSim
+    kw = dict(pop_size=300, core_size=5003, pan_genes=600, core_genes=200, HR_rate=0.3)
+    P = 4000
+    ref = OracleSim(seed=2, **kw)
+    multi = pa.MultiSimulation(pa.make_params(seed=2, n_gen=3, max_distances=P, **kw), n_shards, devices=[0] * n_shards)
+    assert multi.n_shards == n_shards
+    multi.run(2)
+    multi.run(1)
+    multi.sync()
+    for g in range(3):
+        ref.generation(g)
+    got = np.concatenate([s.core_genome.read_matrix() for s in multi.shards], axis=1)
+    assert np.array_equal(got, ref.core)
+    for s in multi.shards:
+        assert np.array_equal(s.pan_genome.read_matrix(), ref.acc)
+        assert np.array_equal(s.last_parents(), ref.last_idx)
+    r1, r2 = orc.sample_pairs(2, 300, P)
+    assert np.array_equal(multi.pairwise_counts(), orc.pairwise_hamming_counts(ref.core, 0, 5003, r1, r2))
+    core_d, acc_d = multi.final_distances()
+    assert np.array_equal(core_d, orc.pairwise_distances(ref.core, True, 200, r1, r2))
+    assert np.array_equal(acc_d, orc.pairwise_distances(ref.acc, False, 200, r1, r2))
+    multi.close()
+
+
+def test_multi_rejects_bad_arguments(pa):
+    p = pa.make_params(seed=0, n_gen=1, max_distances=10, pop_size=10, core_size=5, pan_genes=20, core_genes=10)
+    with pytest.raises(pa.PansimError):
+        pa.MultiSimulation(p, 6)                       # more shards than core sites
+    with pytest.raises(pa.PansimError):
+        pa.MultiSimulation(p, 2, devices=[0, 99])      # no such device
+
+
+def test_cli_gpus_2_equals_gpus_1(pa, tmp_path):
+    # `pansim --gpus 2` (both shards on the one GPU of this box) against `--gpus 1`: all six files byte for byte
+    exe = os.path.join(ROOT, "pansim_amd", "pansim")
+    base = ["--pop_size", "1100", "--core_size", "2001", "--pan_genes", "500", "--core_genes", "100", "--n_gen", "3",
+            "--seed", "6", "--max_distances", "5000", "--print_matrices", "--print_dist", "--print_selection",
+            "--prop_positive", "0.3", "--verbose"]
+    outs = []
+    for n in (1, 2, 5):
+        pref = tmp_path / ("g%d" % n)
+        r = subprocess.run([exe, *base, "--gpus", str(n), "--outpref", str(pref)], capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr
+        outs.append((pref, r.stdout))
+    for pref, out in outs[1:]:
+        assert out == outs[0][1]
+        for suffix in (".tsv", "_freqs.txt", "_per_gen.tsv", "_selection.tsv", "_core_genome.csv", "_pangenome.csv"):
+            assert filecmp.cmp(str(outs[0][0]) + suffix, str(pref) + suffix, shallow=False), suffix
