@@ -245,6 +245,18 @@ int ps_sim_last_parents(ps_sim *s, uint32_t *out_idx);
 int ps_sim_sweep_timing(ps_sim *s, int reset, uint64_t *launches, double *total_ms,
                         double *bytes_per_launch);
 int ps_sim_enable_timing(ps_sim *s, int on);
+/* main.rs:467-470: pairwise_distances of both matrices for the run's pair list (P values each), the two
+ * kernel chains enqueued together on their own streams.  With site shards the core distances of this call
+ * cover this shard's columns only (ps_multi_pairwise_distances sums the shards' numerators first). */
+int ps_sim_pairwise_distances(ps_sim *s, double *core_out, double *acc_out);
+/* device time of the distance kernels of the last ps_sim_pairwise_distances call, per matrix (HIP events) */
+int ps_sim_distance_timing(ps_sim *s, double *core_ms, double *acc_ms);
+/* Host half of sample_indices inside ps_sim_run, accumulated since the last reset: generations, milliseconds
+ * spent waiting for the device half (gene counts / log-fitness of the previous accessory chain), in the three
+ * softmaxes (population.rs:325-393, libm on the host) and in the parent draw (:440-443: the cumulative table on
+ * the host; the N draws on the device for pop_size >= 4096, on the host below). */
+int ps_sim_host_timing(ps_sim *s, int reset, uint64_t *generations, double *wait_ms, double *weights_ms,
+                       double *draw_ms);
 
 /* ------------------------------------------------------------------------ */
 /* one process, several devices: the run sharded by core site  */

@@ -106,6 +106,9 @@ SIGNATURES = {
     "ps_sim_last_parents": (_int, [_vp, _u32p]),
     "ps_sim_sweep_timing": (_int, [_vp, _int, C.POINTER(_u64), C.POINTER(_f64), C.POINTER(_f64)]),
     "ps_sim_enable_timing": (_int, [_vp, _int]),
+    "ps_sim_pairwise_distances": (_int, [_vp, _f64p, _f64p]),
+    "ps_sim_distance_timing": (_int, [_vp, C.POINTER(_f64), C.POINTER(_f64)]),
+    "ps_sim_host_timing": (_int, [_vp, _int, C.POINTER(_u64), C.POINTER(_f64), C.POINTER(_f64), C.POINTER(_f64)]),
     "ps_multi_create": (_int, [C.POINTER(SimParams), _int, C.POINTER(_int), C.POINTER(_vp)]),
     "ps_multi_destroy": (None, [_vp]),
     "ps_multi_shards": (_int, [_vp]),

@@ -388,6 +388,27 @@ __global__ void acc_fitness_kernel(const uint64_t *accI, const double *log1p_s, 
     logw[i] = neg_inf ? 0.0 : sum;
 }
 
+// P-draw on the device (population.rs:440-443, WeightedIndex::sample): parent k = number of cumulative
+// weights <= x_k over the first N-1 of them, x_k = f64_k * total with the k-th f64 of the seeded PARENTS
+// stream.  The cumulative table is built by the host (sequential f64 sums, libm softmaxes); the draw itself
+// is one IEEE multiplication and comparisons, so it equals the host's bit for bit.  Written to device memory
+// (the gather kernels) and to host-mapped memory (ps_sim_last_parents).
+__global__ void __launch_bounds__(256) acc_draw_parents_kernel(const double *cum, double total, uint32_t N,
+                                                               uint32_t k0, uint32_t k1, uint32_t gen,
+                                                               uint32_t *idx_dev, uint32_t *idx_host)
+{
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= N) return;
+    const double x = ps_hs_f64(k0, k1, PS_STREAM_PARENTS, gen, k) * total;
+    uint32_t lo = 0, hi = N - 1u;
+    while (lo < hi) {
+        const uint32_t mid = lo + ((hi - lo) >> 1);
+        if (cum[mid] <= x) lo = mid + 1u; else hi = mid;
+    }
+    idx_dev[k] = lo;
+    idx_host[k] = lo;
+}
+
 // neutral selection (every ln(1+s_g) is 0): only the gene counts are needed (population.rs:282-291,
 // log_sum = 0.0 for every row); one wave per individual, lanes over the row words
 __global__ void __launch_bounds__(256) acc_gene_count_rows_kernel(const uint64_t *accI, int32_t *num_genes,

@@ -10,6 +10,7 @@
 
 #include <algorithm>
 #include <charconv>
+#include <chrono>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -1003,20 +1004,62 @@ extern "C" int ps_fitness_terms(ps_population *acc, const double *sel, int32_t *
     return fitness_terms_device(acc, sel, num_genes, logw, acc->stream);
 }
 
-// logsumexp 0.1 `ln_sum_exp` in its one-pass streaming form
-static double ln_sum_exp(const double *x, uint64_t n)
+// Host threads for the element-wise libm calls of the softmaxes (the sums stay sequential)
+static unsigned host_threads_for(uint64_t n)
 {
-    double alpha = -INFINITY, r = 0.0;
-    for (uint64_t i = 0; i < n; i++) {
-        if (x[i] <= alpha) r += std::exp(x[i] - alpha);
-        else { r *= std::exp(alpha - x[i]); r += 1.0; alpha = x[i]; }
-    }
-    return std::log(r) + alpha;
+    if (n < 16384) return 1;
+    unsigned hw = std::thread::hardware_concurrency();
+    if (const char *e = getenv("PANSIM_HOST_THREADS")) hw = (unsigned)std::max(1, atoi(e));
+    return std::max(1u, std::min(std::min(hw, 16u), (unsigned)(n / 8192)));
 }
-static void softmax_norm(double *v, uint64_t n)
+template <typename F>
+static void par_for(uint64_t n, F fn)      // fn(begin, end) on contiguous slices
 {
-    const double lse = ln_sum_exp(v, n);
-    for (uint64_t i = 0; i < n; i++) v[i] = std::exp(v[i] - lse);
+    const unsigned T = host_threads_for(n);
+    if (T <= 1) { fn((uint64_t)0, n); return; }
+    std::vector<std::thread> th;
+    for (unsigned t = 0; t < T; t++) th.emplace_back(fn, n * t / T, n * (t + 1) / T);
+    for (auto &x : th) x.join();
+}
+
+// softmax as population.rs:325-340 / :356-361 / :377-382 write it: lse = ln_sum_exp(v) (logsumexp 0.1, in
+// its one-pass streaming form: for every x, `if x <= alpha { r += exp(x - alpha) } else { r *= exp(alpha - x);
+// r += 1; alpha = x }`, result ln(r) + alpha), v = exp(v - lse), sum = left-to-right sum of v, v = v / sum
+// (0 where v is -inf).  Every floating-point operation below is one of those, on the same operands and in the
+// same order for the sequential ones; only the independent exp calls run on several threads, and a vector of
+// N identical finite values (neutral selection; no competition) needs one exp instead of 2 N.
+static void softmax_norm(double *v, uint64_t n, std::vector<double> &scratch)
+{
+    if (n == 0) return;
+    bool equal = std::isfinite(v[0]);
+    for (uint64_t i = 1; equal && i < n; i++) equal = (v[i] == v[0]);
+    if (equal) {
+        // streaming form on N equal values x: r = 0 * exp(-inf - x) + 1 = 1, then N - 1 times r += exp(0) = 1
+        const double lse = std::log((double)n) + v[0];
+        const double e = std::exp(v[0] - lse);
+        double sum = 0.0;
+        for (uint64_t i = 0; i < n; i++) sum += e;
+        const double q = (e != -INFINITY) ? e / sum : 0.0;
+        for (uint64_t i = 0; i < n; i++) v[i] = q;
+        return;
+    }
+    // exp arguments of the streaming form: they depend on the running maximum only
+    scratch.resize(n);
+    double *arg = scratch.data();
+    std::vector<uint8_t> upd(n);
+    double alpha = -INFINITY;
+    for (uint64_t i = 0; i < n; i++) {
+        if (v[i] <= alpha) { arg[i] = v[i] - alpha; upd[i] = 0; }
+        else { arg[i] = alpha - v[i]; upd[i] = 1; alpha = v[i]; }
+    }
+    par_for(n, [&](uint64_t a, uint64_t b) { for (uint64_t i = a; i < b; i++) arg[i] = std::exp(arg[i]); });
+    double r = 0.0;
+    for (uint64_t i = 0; i < n; i++) {
+        if (upd[i]) { r *= arg[i]; r += 1.0; }
+        else r += arg[i];
+    }
+    const double lse = std::log(r) + alpha;
+    par_for(n, [&](uint64_t a, uint64_t b) { for (uint64_t i = a; i < b; i++) v[i] = std::exp(v[i] - lse); });
     double sum = 0.0;
     for (uint64_t i = 0; i < n; i++) sum += v[i];
     for (uint64_t i = 0; i < n; i++) v[i] = (v[i] != -INFINITY) ? v[i] / sum : 0.0;
@@ -1029,21 +1072,33 @@ extern "C" int ps_sample_weights(const int32_t *num_genes, const double *logw, u
 {
     if (!num_genes || !logw || !avg_pairwise_dists || !weights || n == 0)
         return ps_fail(PS_ERR_INVALID, "null argument");
-    std::vector<double> sel(n, 1.0), tmp(n);                       // population.rs:293
+    std::vector<double> sel(n, 1.0), tmp(n), scratch;              // population.rs:293
     if (n_genes > 0) {                                             // :296
         for (uint64_t i = 0; i < n; i++) sel[i] = logw[i];
-        softmax_norm(sel.data(), n);                               // :325-340
+        softmax_norm(sel.data(), n, scratch);                      // :325-340
     }
     if (!no_control_genome_size) {                                 // :346
         const double lp = std::log(genome_size_penalty);
         for (uint64_t i = 0; i < n; i++) tmp[i] = (double)(num_genes[i] - avg_gene_num) * lp; // :350-355
-        softmax_norm(tmp.data(), n);                               // :356-361
+        softmax_norm(tmp.data(), n, scratch);                      // :356-361
         for (uint64_t i = 0; i < n; i++) weights[i] = tmp[i] * sel[i]; // :368
     } else {
         for (uint64_t i = 0; i < n; i++) weights[i] = sel[i];      // :371
     }
-    for (uint64_t i = 0; i < n; i++) tmp[i] = competition_strength * std::log(avg_pairwise_dists[i]); // :375
-    softmax_norm(tmp.data(), n);                                   // :377-382
+    {
+        // :375 -- the logarithm of N equal distances (1.0 without competition, main.rs:435) is taken once
+        bool equal = true;
+        for (uint64_t i = 1; equal && i < n; i++) equal = (avg_pairwise_dists[i] == avg_pairwise_dists[0]);
+        if (equal) {
+            const double t = competition_strength * std::log(avg_pairwise_dists[0]);
+            for (uint64_t i = 0; i < n; i++) tmp[i] = t;
+        } else {
+            par_for(n, [&](uint64_t a, uint64_t b) {
+                for (uint64_t i = a; i < b; i++) tmp[i] = competition_strength * std::log(avg_pairwise_dists[i]);
+            });
+        }
+    }
+    softmax_norm(tmp.data(), n, scratch);                          // :377-382
     for (uint64_t i = 0; i < n; i++) weights[i] = weights[i] * tmp[i]; // :389-393
     double mx = -INFINITY;
     for (uint64_t i = 0; i < n; i++) mx = std::fmax(mx, weights[i]); // :403
@@ -1790,7 +1845,7 @@ struct ps_sim {
     ps_derived der{};
     ps_population *core = nullptr, *acc = nullptr;
     std::vector<double> sel;
-    std::vector<uint32_t> r1, r2, last_idx;
+    std::vector<uint32_t> r1, r2;
     // ring of parent-index slots so that the accessory chain (and the host) can run
     // ahead of the long core sweep
     uint32_t *d_idx[PS_RING] = {};
@@ -1807,6 +1862,19 @@ struct ps_sim {
     double *d_log1p = nullptr;          // ln(1 + s_g) of THIS run (the accessory handle's own table belongs to its Population API)
     uint64_t step_count = 0;
     bool need_logw = false;
+    // P-draw on the device (populations of >= 4096: the N binary searches over the cumulative table are the
+    // largest part of the host half there, and the host half does not shrink with the number of site shards)
+    bool device_draw = false;
+    double *h_cum = nullptr, *m_cum = nullptr;   // pinned cumulative weights + device alias
+    int last_slot = 0;
+    // distance phase (ps_sim_pairwise_distances): pinned numerators, events around the kernels of each matrix
+    uint32_t *h_cnt = nullptr;           // 3 x P: core numerators | accessory intersections | unions
+    uint64_t h_cnt_cap = 0;
+    hipEvent_t ev_dist[4] = {};          // core begin / end, accessory begin / end
+    double dist_core_ms = 0.0, dist_acc_ms = 0.0;
+    // host half of a generation, accumulated since the last reset (ps_sim_host_timing)
+    uint64_t host_calls = 0;
+    double host_wait_ms = 0.0, host_weights_ms = 0.0, host_draw_ms = 0.0;
     // sweep timing
     bool timing = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> tev;
@@ -1830,6 +1898,9 @@ extern "C" void ps_sim_destroy(ps_sim *s)
     if (s->h_num_genes) (void)hipHostFree(s->h_num_genes);
     if (s->h_logw) (void)hipHostFree(s->h_logw);
     if (s->h_avg) (void)hipHostFree(s->h_avg);
+    if (s->h_cum) (void)hipHostFree(s->h_cum);
+    if (s->h_cnt) (void)hipHostFree(s->h_cnt);
+    for (auto e : s->ev_dist) if (e) (void)hipEventDestroy(e);
     if (s->d_avg) (void)hipFree(s->d_avg);
     if (s->d_log1p) (void)hipFree(s->d_log1p);
     for (auto &pr : s->tev) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
@@ -1885,7 +1956,6 @@ static int sim_create_impl(const ps_sim_params *p, ps_sim *s)
     s->r1.resize(p->max_distances);
     s->r2.resize(p->max_distances);
     PSCHK(ps_sample_pairs(p->seed, N, p->max_distances, s->r1.data(), s->r2.data())); // main.rs:413-427
-    s->last_idx.assign(N, 0);
     PSCHK(use_device(s->core));
     for (int k = 0; k < PS_RING; k++) {
         HIPCHK(hipMalloc(&s->d_idx[k], N * sizeof(uint32_t)));
@@ -1949,6 +2019,10 @@ static int sim_create_impl(const ps_sim_params *p, ps_sim *s)
     HIPCHK(hipHostGetDevicePointer((void **)&s->m_num_genes, s->h_num_genes, 0));
     HIPCHK(hipHostGetDevicePointer((void **)&s->m_logw, s->h_logw, 0));
     HIPCHK(hipHostMalloc(&s->h_avg, N * sizeof(double)));
+    s->device_draw = N >= 4096;
+    if (const char *e = getenv("PANSIM_DEVICE_DRAW")) s->device_draw = atoi(e) != 0;
+    HIPCHK(hipHostMalloc(&s->h_cum, N * sizeof(double), hipHostMallocMapped));
+    HIPCHK(hipHostGetDevicePointer((void **)&s->m_cum, s->h_cum, 0));
     HIPCHK(hipMalloc(&s->d_avg, N * sizeof(double)));
     if (G) {
         std::vector<double> l1p(G);
@@ -1998,19 +2072,43 @@ static int sim_one_generation(ps_sim *s, uint32_t gen)
                                                                          s->m_logw, acc->d);
     HIPCHK(hipGetLastError());
     // the slot's previous core sweep must have consumed its indices
+    using clk = std::chrono::steady_clock;
+    auto ms_since = [](clk::time_point t0) { return std::chrono::duration<double, std::milli>(clk::now() - t0).count(); };
+    auto th0 = clk::now();
     if (s->slot_used[slot]) HIPCHK(hipEventSynchronize(s->ev_core[slot]));
     HIPCHK(hipStreamSynchronize(sa));
+    s->host_wait_ms += ms_since(th0);
     // ... host half: three softmaxes and N seeded draws
+    th0 = clk::now();
     std::vector<double> w(N);
     PSCHK(ps_sample_weights(s->h_num_genes, s->h_logw, N, acc->cfg.ncols, s->der.avg_gene_num, s->h_avg,
                             p.no_control_genome_size, p.genome_size_penalty, p.competition_strength, w.data()));
+    s->host_weights_ms += ms_since(th0);
+    th0 = clk::now();
+    s->last_slot = slot;
+    if (s->device_draw) {
+        // cumulative table on the host (sequential f64 sums, as WeightedIndex::new builds it), draws on the
+        // device: the kernel reads the 8*N bytes from host-mapped memory once and writes the parents both to
+        // device memory and to the host-mapped slot
+        double total = w[0];
+        for (uint64_t i = 1; i < N; i++) { s->h_cum[i - 1] = total; total += w[i]; }
+        acc_draw_parents_kernel<<<(uint32_t)((N + 255) / 256), 256, 0, sa>>>(s->m_cum, total, (uint32_t)N, (uint32_t)p.seed,
+                                                                         (uint32_t)(p.seed >> 32), gen, s->d_idx[slot],
+                                                                         s->m_idx[slot]);
+        HIPCHK(hipGetLastError());
+        s->host_draw_ms += ms_since(th0);
+        s->host_calls++;
+        PSCHK(launch_acc_step(acc, s->d_idx[slot], gen, true, true, sa, nullptr));
+    } else {
     PSCHK(ps_draw_parents(w.data(), N, p.seed, gen, s->h_idx[slot]));
-    memcpy(s->last_idx.data(), s->h_idx[slot], N * sizeof(uint32_t));
+    s->host_draw_ms += ms_since(th0);
+    s->host_calls++;
     // main.rs:447, :455, :462-464 on the accessory stream.  The gather kernel reads the parents
     // straight from the host-mapped slot (4*N bytes over PCIe) and publishes the device copy the
     // core sweep uses: no copy kernel has to fight the sweep for a CU.
     if (G == 0) HIPCHK(hipMemcpyAsync(s->d_idx[slot], s->h_idx[slot], N * sizeof(uint32_t), hipMemcpyHostToDevice, sa));
     PSCHK(launch_acc_step(acc, s->m_idx[slot], gen, true, true, sa, s->d_idx[slot]));
+    }
     HIPCHK(hipEventRecord(s->ev_idx[slot], sa));
     // Heavy HGT (cfg3-like rates, >= 1e7 expected events): its scattered loads and the streaming
     // sweep slow each other down far more than their sum, so they take turns on the chip:
@@ -2091,7 +2189,99 @@ extern "C" const uint32_t *ps_sim_range2(ps_sim *s) { return s ? s->r2.data() : 
 extern "C" int ps_sim_last_parents(ps_sim *s, uint32_t *out_idx)
 {
     if (!s || !out_idx) return ps_fail(PS_ERR_INVALID, "null argument");
-    memcpy(out_idx, s->last_idx.data(), s->last_idx.size() * sizeof(uint32_t));
+    if (s->step_count == 0) { memset(out_idx, 0, s->prm.pop_size * sizeof(uint32_t)); return PS_OK; }
+    // (with the draw on the device the slot is written by a kernel of the accessory stream)
+    PSCHK(use_device(s->core));
+    HIPCHK(hipStreamSynchronize(s->acc->stream));
+    memcpy(out_idx, s->h_idx[s->last_slot], s->prm.pop_size * sizeof(uint32_t));
+    return PS_OK;
+}
+
+// main.rs:467-470 for this process's matrices: both distance kernels chains are enqueued before anything is
+// waited for (core on the core stream, accessory on its own), the numerators come back through pinned memory,
+// and the reference's f64 expressions run on the host.  With site shards the core numerators of this call
+// cover the shard's sites only (ps_multi_pairwise_distances sums them).
+static int sim_pair_counts(ps_sim *s, uint32_t **core_cnt, uint32_t **acc_in, uint32_t **acc_un)
+{
+    const uint64_t P = s->prm.max_distances;
+    ps_population *core = s->core, *acc = s->acc;
+    PSCHK(use_device(core));
+    if (s->h_cnt_cap < P) {
+        if (s->h_cnt) HIPCHK(hipHostFree(s->h_cnt));
+        s->h_cnt = nullptr;
+        s->h_cnt_cap = 0;
+        HIPCHK(hipHostMalloc(&s->h_cnt, std::max<uint64_t>(3 * P, 1) * sizeof(uint32_t)));
+        s->h_cnt_cap = P;
+    }
+    for (auto &e : s->ev_dist)
+        if (!e) HIPCHK(hipEventCreate(&e));
+    PSCHK(upload_pairs(core, P, s->r1.data(), s->r2.data()));
+    PSCHK(upload_pairs(acc, P, s->r1.data(), s->r2.data()));
+    uint32_t *c1 = (uint32_t *)core->d_pairs, *a1 = (uint32_t *)acc->d_pairs;
+    // everything the generation loop queued on either stream precedes the distance kernels of both
+    HIPCHK(hipStreamSynchronize(acc->stream));
+    HIPCHK(hipStreamSynchronize(core->stream));
+    HIPCHK(hipEventRecord(s->ev_dist[0], core->stream));
+    PSCHK(pair_counts_device(core, P, c1, c1 + P, c1 + 2 * P, c1 + 3 * P, c1 + 4 * P, core->stream));
+    HIPCHK(hipEventRecord(s->ev_dist[1], core->stream));
+    HIPCHK(hipMemcpyAsync(s->h_cnt, c1 + 3 * P, P * 4, hipMemcpyDeviceToHost, core->stream));
+    HIPCHK(hipEventRecord(s->ev_dist[2], acc->stream));
+    if (acc->cfg.ncols) PSCHK(pair_counts_device(acc, P, a1, a1 + P, a1 + 2 * P, a1 + 3 * P, a1 + 4 * P, acc->stream));
+    else HIPCHK(hipMemsetAsync(a1 + 3 * P, 0, 2 * P * 4, acc->stream));
+    HIPCHK(hipEventRecord(s->ev_dist[3], acc->stream));
+    HIPCHK(hipMemcpyAsync(s->h_cnt + P, a1 + 3 * P, 2 * P * 4, hipMemcpyDeviceToHost, acc->stream));
+    HIPCHK(hipStreamSynchronize(acc->stream));
+    HIPCHK(hipStreamSynchronize(core->stream));
+    float ms = 0.f;
+    HIPCHK(hipEventElapsedTime(&ms, s->ev_dist[0], s->ev_dist[1]));
+    s->dist_core_ms = ms;
+    HIPCHK(hipEventElapsedTime(&ms, s->ev_dist[2], s->ev_dist[3]));
+    s->dist_acc_ms = ms;
+    *core_cnt = s->h_cnt;
+    *acc_in = s->h_cnt + P;
+    *acc_un = s->h_cnt + 2 * P;
+    return PS_OK;
+}
+
+static void acc_distances_host(const uint32_t *in, const uint32_t *un, uint64_t P, double cg, double *out)
+{
+    par_for(P, [&](uint64_t a, uint64_t b) {
+        for (uint64_t k = a; k < b; k++) out[k] = 1.0 - (((double)in[k] + cg) / ((double)un[k] + cg));   // population.rs:828-830
+    });
+}
+
+extern "C" int ps_sim_pairwise_distances(ps_sim *s, double *core_out, double *acc_out)
+{
+    if (!s || !core_out || !acc_out) return ps_fail(PS_ERR_INVALID, "null argument");
+    const uint64_t P = s->prm.max_distances;
+    uint32_t *cc = nullptr, *ai = nullptr, *au = nullptr;
+    PSCHK(sim_pair_counts(s, &cc, &ai, &au));
+    const double ncols = (double)s->core->cfg.ncols;
+    par_for(P, [&](uint64_t a, uint64_t b) {
+        for (uint64_t k = a; k < b; k++) core_out[k] = (double)(cc[k] / 2) / ncols;                      // population.rs:817-822
+    });
+    acc_distances_host(ai, au, P, (double)s->prm.core_genes, acc_out);
+    return PS_OK;
+}
+
+// device time of the kernels of the last ps_sim_pairwise_distances call, per matrix (HIP events on their streams)
+extern "C" int ps_sim_distance_timing(ps_sim *s, double *core_ms, double *acc_ms)
+{
+    if (!s) return ps_fail(PS_ERR_INVALID, "null handle");
+    if (core_ms) *core_ms = s->dist_core_ms;
+    if (acc_ms) *acc_ms = s->dist_acc_ms;
+    return PS_OK;
+}
+
+extern "C" int ps_sim_host_timing(ps_sim *s, int reset, uint64_t *generations, double *wait_ms, double *weights_ms,
+                                  double *draw_ms)
+{
+    if (!s) return ps_fail(PS_ERR_INVALID, "null handle");
+    if (generations) *generations = s->host_calls;
+    if (wait_ms) *wait_ms = s->host_wait_ms;
+    if (weights_ms) *weights_ms = s->host_weights_ms;
+    if (draw_ms) *draw_ms = s->host_draw_ms;
+    if (reset) { s->host_calls = 0; s->host_wait_ms = s->host_weights_ms = s->host_draw_ms = 0.0; }
     return PS_OK;
 }
 
@@ -2277,6 +2467,7 @@ extern "C" int ps_multi_pairwise_distances(ps_multi *m, double *core_out, double
 {
     if (!m || !core_out || !acc_out) return ps_fail(PS_ERR_INVALID, "null argument");
     const uint64_t P = m->prm.max_distances;
+    if (m->shard.size() == 1) return ps_sim_pairwise_distances(m->shard[0], core_out, acc_out);
     std::vector<uint32_t> cnt(P);
     PSCHK(ps_multi_pairwise_counts(m, cnt.data()));
     const double ncols = (double)m->prm.core_size;

@@ -54,6 +54,15 @@ PS_HD ps_u4 ps_philox(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32
     return o;
 }
 
+// n-th f64 of a seeded host stream: two per Philox block, top 53 bits x 2^-53
+PS_HD double ps_hs_f64(uint32_t k0, uint32_t k1, uint32_t stream, uint32_t gen, uint64_t n)
+{
+    const uint64_t blk = n >> 1;
+    const ps_u4 w = ps_philox((uint32_t)blk, (uint32_t)(blk >> 32), gen, stream, k0, k1);
+    const uint64_t x = (n & 1) ? (((uint64_t)w.w << 32) | w.z) : (((uint64_t)w.y << 32) | w.x);
+    return (double)(x >> 11) * (1.0 / 9007199254740992.0);
+}
+
 // Core cell plan: cumulative 32-bit thresholds over one uniform word u
 //   u < T[0],T[1],T[2] : mutate to 2,4,8            (population.rs:511-540)
 //   u < T[3],T[4],T[5] : mutate to 2,4,8 AND receive a donor allele

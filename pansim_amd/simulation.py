@@ -116,13 +116,25 @@ class Simulation:
         check(self._lib.ps_sim_sweep_timing(self._h, int(reset), C.byref(n), C.byref(ms), C.byref(b)))
         return n.value, ms.value, b.value
 
+    def host_timing(self, reset=True):
+        """(generations, ms waiting for the device half, ms in the softmaxes, ms in the parent draw) since the last reset"""
+        n, a, b, c = C.c_uint64(), C.c_double(), C.c_double(), C.c_double()
+        check(self._lib.ps_sim_host_timing(self._h, int(reset), C.byref(n), C.byref(a), C.byref(b), C.byref(c)))
+        return n.value, a.value, b.value, c.value
+
     # -- outputs of main.rs:467-499 ---------------------------------------------------
     def final_distances(self):
-        self.sync()
+        """main.rs:467-470 (ps_sim_pairwise_distances: both matrices' kernels enqueued together)"""
         P = self.params.max_distances
-        core = self.core_genome.pairwise_distances(P, self.range1, self.range2)
-        acc = self.pan_genome.pairwise_distances(P, self.range1, self.range2)
+        core, acc = np.zeros(P), np.zeros(P)
+        check(self._lib.ps_sim_pairwise_distances(self._h, core, acc))
         return core, acc
+
+    def distance_timing(self):
+        """device ms of the core / accessory distance kernels of the last final_distances() call"""
+        a, b = C.c_double(), C.c_double()
+        check(self._lib.ps_sim_distance_timing(self._h, C.byref(a), C.byref(b)))
+        return a.value, b.value
 
     def write_outputs(self, outpref):
         core, acc = self.final_distances()

@@ -151,6 +151,33 @@ def test_sample_weights_and_draws_match_oracle(pa, orc):
     assert rc == 0 and np.array_equal(w, ow)
 
 
+@pytest.mark.parametrize("N", [40000, 65536])
+def test_sample_weights_large_populations_match_oracle(pa, orc, N):
+    # the library takes the independent exp / ln calls of the three softmaxes on several host threads and N
+    # equal inputs through one exp (population.rs:325-393); the oracle runs the plain sequential loops: every
+    # weight must still be the same double
+    rng = np.random.default_rng(N)
+    G = 4000
+    cases = [
+        (rng.integers(900, 1100, N), np.zeros(N), np.ones(N), 0.0, False),              # the default path (neutral)
+        (rng.integers(900, 1100, N), rng.normal(0, 3, N), np.ones(N), 0.0, False),      # selection
+        (rng.integers(900, 1100, N), rng.normal(0, 3, N), rng.random(N) + 1e-6, 25.0, True),   # competition, no size control
+        (np.full(N, 1000), np.zeros(N), np.full(N, 0.37), 3.0, False),                  # every vector constant
+        (rng.integers(0, 4000, N), np.where(rng.random(N) < 0.01, -np.inf, rng.normal(0, 1, N)), np.ones(N), 0.0, False),
+    ]
+    for ng, lw, avg, comp, noc in cases:
+        ng = ng.astype(np.int32)
+        w = pa.sample_weights(ng, lw, G, 1000, avg, noc, 0.99, comp)
+        rc, ow = orc.sample_weights(ng, lw, G, 1000, avg, noc, 0.99, comp)
+        assert rc == 0 and np.array_equal(w, ow)
+    # a -0.0 among +0.0 log-weights takes the constant-vector path: same doubles as the plain loop
+    lw = np.zeros(N)
+    lw[::7] = -0.0
+    w = pa.sample_weights(cases[0][0].astype(np.int32), lw, G, 1000, np.ones(N), False, 0.99, 0.0)
+    rc, ow = orc.sample_weights(cases[0][0].astype(np.int32), lw, G, 1000, np.ones(N), False, 0.99, 0.0)
+    assert rc == 0 and np.array_equal(w, ow)
+
+
 def test_format_and_small_helpers(pa, orc):
     for x, want in KAT["rust_display_f64"]:
         assert pa.fmt_f64(x) == want
