@@ -215,6 +215,7 @@ struct ps_population {
     void *d_pairs = nullptr;         // sorted r1 | r2 | perm | outA | outB | tstart | tcount
     uint32_t pair_threads = 0;       // entries of the thread table (tiled distance kernel)
     uint64_t pairs_cap = 0, pairs_cached = 0;
+    const uint32_t *pairs_src1 = nullptr, *pairs_src2 = nullptr;   // caller's arrays the cache was built from (ps_sim's own list only)
     bool pairs_tiled = false;        // the cached list is sorted and has a thread table (tiled distance kernels)
     std::vector<uint32_t> h_r1, h_r2; // the caller's list the device copy was built from
     uint32_t lds_limit = 160 * 1024;
@@ -1182,7 +1183,7 @@ static int ensure_pairs(ps_population *p, uint64_t P)
 // LDS row: a broadcast instead of a bank conflict) together with the permutation that
 // restores the caller's order.  The list is fixed for a whole run (main.rs:413-427), so the
 // device copy is reused while the caller keeps passing the same list.
-static int upload_pairs(ps_population *p, uint64_t P, const uint32_t *r1, const uint32_t *r2)
+static int upload_pairs(ps_population *p, uint64_t P, const uint32_t *r1, const uint32_t *r2, bool trusted = false)
 {
     PSCHK(ensure_pairs(p, P));
     const uint64_t N = p->cfg.pop_size;
@@ -1190,11 +1191,15 @@ static int upload_pairs(ps_population *p, uint64_t P, const uint32_t *r1, const 
     // population that fits its LDS tile (elsewhere -- accessory pairs, cfg5's all-pairs tiles -- the
     // caller's order is uploaded as it is)
     const bool tiled_possible = p->cfg.core && (uint64_t)N * (4 + 4) * 4 <= p->lds_limit;
+    // (a ps_sim passes its own immutable list: same pointers as the cached copy was built from)
     if (p->pairs_cached == P && p->pairs_tiled == tiled_possible && p->h_r1.size() == P
-        && memcmp(p->h_r1.data(), r1, P * 4) == 0 && memcmp(p->h_r2.data(), r2, P * 4) == 0)
+        && ((trusted && p->pairs_src1 == r1 && p->pairs_src2 == r2)
+            || (memcmp(p->h_r1.data(), r1, P * 4) == 0 && memcmp(p->h_r2.data(), r2, P * 4) == 0)))
         return PS_OK;
     p->pairs_cached = 0;
     p->pairs_tiled = tiled_possible;
+    p->pairs_src1 = trusted ? r1 : nullptr;
+    p->pairs_src2 = trusted ? r2 : nullptr;
     p->h_r1.assign(r1, r1 + P);
     p->h_r2.assign(r2, r2 + P);
     std::vector<uint32_t> s1(P), s2(P), perm(P);
@@ -1967,8 +1972,8 @@ static int sim_create_impl(const ps_sim_params *p, ps_sim *s)
     // the pair list is fixed for the whole run (main.rs:413-427): sort and upload it now, so that
     // the distance phase starts with the device copy in place
     if (p->max_distances > 0) {
-        PSCHK(upload_pairs(s->core, p->max_distances, s->r1.data(), s->r2.data()));
-        PSCHK(upload_pairs(s->acc, p->max_distances, s->r1.data(), s->r2.data()));
+        PSCHK(upload_pairs(s->core, p->max_distances, s->r1.data(), s->r2.data(), true));
+        PSCHK(upload_pairs(s->acc, p->max_distances, s->r1.data(), s->r2.data(), true));
     }
     // a block sweep that fills the CU's LDS (cfg4 population) leaves none for the donor lists
     if (!wave_sweep_eligible(s->core, true, p->HR_rate > 0.0)) {
@@ -2215,8 +2220,8 @@ static int sim_pair_counts(ps_sim *s, uint32_t **core_cnt, uint32_t **acc_in, ui
     }
     for (auto &e : s->ev_dist)
         if (!e) HIPCHK(hipEventCreate(&e));
-    PSCHK(upload_pairs(core, P, s->r1.data(), s->r2.data()));
-    PSCHK(upload_pairs(acc, P, s->r1.data(), s->r2.data()));
+    PSCHK(upload_pairs(core, P, s->r1.data(), s->r2.data(), true));
+    PSCHK(upload_pairs(acc, P, s->r1.data(), s->r2.data(), true));
     uint32_t *c1 = (uint32_t *)core->d_pairs, *a1 = (uint32_t *)acc->d_pairs;
     // everything the generation loop queued on either stream precedes the distance kernels of both
     HIPCHK(hipStreamSynchronize(acc->stream));
@@ -2245,7 +2250,8 @@ static int sim_pair_counts(ps_sim *s, uint32_t **core_cnt, uint32_t **acc_in, ui
 
 static void acc_distances_host(const uint32_t *in, const uint32_t *un, uint64_t P, double cg, double *out)
 {
-    par_for(P, [&](uint64_t a, uint64_t b) {
+    par_for(P < (1u << 20) ? 1 : P, [&](uint64_t a, uint64_t b) {
+        if (P < (1u << 20)) { a = 0; b = P; }
         for (uint64_t k = a; k < b; k++) out[k] = 1.0 - (((double)in[k] + cg) / ((double)un[k] + cg));   // population.rs:828-830
     });
 }
@@ -2257,7 +2263,8 @@ extern "C" int ps_sim_pairwise_distances(ps_sim *s, double *core_out, double *ac
     uint32_t *cc = nullptr, *ai = nullptr, *au = nullptr;
     PSCHK(sim_pair_counts(s, &cc, &ai, &au));
     const double ncols = (double)s->core->cfg.ncols;
-    par_for(P, [&](uint64_t a, uint64_t b) {
+    par_for(P < (1u << 20) ? 1 : P, [&](uint64_t a, uint64_t b) {
+        if (P < (1u << 20)) { a = 0; b = P; }
         for (uint64_t k = a; k < b; k++) core_out[k] = (double)(cc[k] / 2) / ncols;                      // population.rs:817-822
     });
     acc_distances_host(ai, au, P, (double)s->prm.core_genes, acc_out);
