@@ -273,7 +273,10 @@ __global__ void __launch_bounds__(256) acc_hgt_donor_bin_kernel(acc_hgt_args a)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t sc_lds[];
     uint32_t *fill = sc_lds;                                           // [parts]
-    uint16_t *glist = (uint16_t *)(sc_lds + ((a.parts + 3u) & ~3u));   // present genes of the item's donor
+    // present genes of the item's donor: in LDS, or -- beside a block sweep that owns the CU's LDS -- in the
+    // workgroup's slice of a global scratch (hot in L2, as in the light kernel)
+    uint16_t *glist = a.list_scratch ? a.list_scratch + (uint64_t)blockIdx.x * a.list_stride
+                                     : (uint16_t *)(sc_lds + ((a.parts + 3u) & ~3u));
     __shared__ uint32_t sh_n;
     const acc_dims d = a.d;
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
@@ -289,6 +292,7 @@ __global__ void __launch_bounds__(256) acc_hgt_donor_bin_kernel(acc_hgt_args a)
         if (tid < 64u) {
             const uint32_t m = ps_wave_gene_list(a.srcI + (uint64_t)dn * d.GW, d.GW, a.gb[c], a.ge[c], glist, lane);
             if (tid == 0) sh_n = m;
+            __threadfence_block();                         // (the list may live in global memory)
         }
         __syncthreads();
         const uint32_t n = sh_n;

@@ -195,6 +195,7 @@ struct ps_population {
     uint32_t hgt_slices = 0;             // tuning: event slices of the LDS-partitioned HGT kernel (0 = choose)
     uint32_t hgt_events_per_thread = 0;  // light HGT kernel: 0 = whole chip, else narrow launch (set by ps_sim)
     bool hgt_list_in_global = false;     // light HGT kernel: donor lists in global scratch (no LDS beside the block sweep)
+    bool hgt_bin_list_in_global = false; // binned HGT, bin pass: the same (tests)
     uint32_t *cnt = nullptr;
     int cur = 0;
     ps_acc_plan aplan{};
@@ -428,6 +429,8 @@ extern "C" int ps_set_tuning(ps_population *p, const char *key, int64_t value)
         p->block_batch = (uint32_t)value;
     } else if (k == "hgt_list_in_global") {
         p->hgt_list_in_global = value != 0;
+    } else if (k == "hgt_bin_list_in_global") {
+        p->hgt_bin_list_in_global = value != 0;
     } else if (k == "no_block_preload") {
         p->no_block_preload = value != 0;
     } else if (k == "block_waves") {
@@ -847,7 +850,10 @@ static int launch_acc_hgt(ps_population *p, uint32_t gen, hipStream_t st, hipEve
         const uint32_t cap = (uint32_t)(((uint64_t)(mean + 10.0 * std::sqrt(mean) + 64.0) + 63) & ~63ull);
         const uint64_t bin_words = (uint64_t)donor_blocks * parts * cap;
         const uint64_t cnt_bytes = ((uint64_t)donor_blocks * parts * 4 + 255) & ~255ull;
-        const uint64_t need = img_bytes + bin_words * 4 + cnt_bytes;
+        // (measured at the cfg4 population: the bin pass running beside the block sweep this way makes the generation
+        // LONGER -- 8.3 -> 9.4 ms per generation at 1/8 of the sites -- so ps_sim leaves it off: test hook only)
+        const uint64_t list_bytes = p->hgt_bin_list_in_global ? (((uint64_t)donor_blocks * max_comp * sizeof(uint16_t) + 255) & ~255ull) : 0;
+        const uint64_t need = img_bytes + bin_words * 4 + cnt_bytes + list_bytes;
         if (p->hgt_scratch_cap < need) {
             if (p->hgt_scratch) HIPCHK(hipFree(p->hgt_scratch));
             p->hgt_scratch = nullptr;
@@ -864,7 +870,13 @@ static int launch_acc_hgt(ps_population *p, uint32_t gen, hipStream_t st, hipEve
         a.bin_cap = cap;
         a.srcI = p->I[p->cur];          // not edited before the reduce pass: it IS the snapshot
         a.dstI = p->I[p->cur];
-        const uint32_t dlds = ((parts + 3u) & ~3u) * 4u + list_lds;
+        if (list_bytes) {
+            // the co-running block sweep owns the CU's LDS: donor lists in global scratch, the bin pass then fits
+            // beside it with its fill counters only
+            a.list_scratch = (uint16_t *)((uint8_t *)p->hgt_scratch + img_bytes + bin_words * 4 + cnt_bytes);
+            a.list_stride = max_comp;
+        }
+        const uint32_t dlds = ((parts + 3u) & ~3u) * 4u + (list_bytes ? 0u : list_lds);
         if (dlds > 64 * 1024)
             HIPCHK(hipFuncSetAttribute((const void *)acc_hgt_donor_bin_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dlds));
         hipLaunchKernelGGL(acc_hgt_donor_bin_kernel, dim3(donor_blocks), dim3(256), dlds, st, a);

@@ -205,6 +205,7 @@ def test_acc_operators_match_oracle(pa, orc, N, G, comps, lm, lr):
     # and the binned two-pass form with one recipient partition and with ~N/21 partitions
     row_bytes = 8 * ((G + 63) // 64)
     for tune in ({"hgt_mode": 1}, {"hgt_mode": 1, "hgt_list_in_global": 1}, {"hgt_mode": 2},
+                 {"hgt_mode": 2, "hgt_bin_list_in_global": 1},
                  {"hgt_mode": 2, "lds_limit": min(160 * 1024, max(1024 + 21 * row_bytes, 2 * G + 8192))},
                  {"hgt_mode": 2, "hgt_slices": 3}):
         alt = pa.Population(N, G, 2, False, 0.25, seed, 10)
