@@ -153,3 +153,22 @@ def test_randomised_stress_subset(pa, orc):
     lines = []
     bad = run(40, seed=20261003, log=lambda *a: lines.append(" ".join(map(str, a))))
     assert bad == 0, "\n".join(lines)
+
+
+@pytest.mark.parametrize("device_draw", ["0", "1"])
+def test_parent_draw_on_host_and_device_agree(pa, orc, monkeypatch, device_draw):
+    # P-draw (population.rs:440-443): the N weighted draws run on the device for pop_size >= 4096 and on the host
+    # below; PANSIM_DEVICE_DRAW forces either.  Selection and competition on, so that the weights are not uniform.
+    from orc_sim import OracleSim
+    monkeypatch.setenv("PANSIM_DEVICE_DRAW", device_draw)
+    kw = dict(pop_size=4100 if device_draw == "0" else 333, core_size=700, pan_genes=500, core_genes=100)
+    extra = dict(prop_positive=0.3, competition_strength=5.0)
+    sim = pa.Simulation(pa.make_params(seed=13, n_gen=4, max_distances=200, **kw, **extra))
+    ref = OracleSim(seed=13, **kw, **extra)
+    for g in range(4):
+        sim.run(1)
+        ref.generation(g)
+        assert np.array_equal(sim.last_parents(), ref.last_idx), "generation %d" % g
+    assert np.array_equal(sim.core_genome.read_matrix(), ref.core)
+    assert np.array_equal(sim.pan_genome.read_matrix(), ref.acc)
+    sim.close()
