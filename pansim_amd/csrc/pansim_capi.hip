@@ -1882,7 +1882,7 @@ struct ps_sim {
     // P-draw on the device (populations of >= 4096: the N binary searches over the cumulative table are the
     // largest part of the host half there, and the host half does not shrink with the number of site shards)
     bool device_draw = false;
-    double *h_cum = nullptr, *m_cum = nullptr;   // pinned cumulative weights + device alias
+    double *h_cum = nullptr, *d_cum = nullptr;   // cumulative weights: pinned host copy, device copy
     int last_slot = 0;
     // distance phase (ps_sim_pairwise_distances): pinned numerators, events around the kernels of each matrix
     uint32_t *h_cnt = nullptr;           // 3 x P: core numerators | accessory intersections | unions
@@ -1916,6 +1916,7 @@ extern "C" void ps_sim_destroy(ps_sim *s)
     if (s->h_logw) (void)hipHostFree(s->h_logw);
     if (s->h_avg) (void)hipHostFree(s->h_avg);
     if (s->h_cum) (void)hipHostFree(s->h_cum);
+    if (s->d_cum) (void)hipFree(s->d_cum);
     if (s->h_cnt) (void)hipHostFree(s->h_cnt);
     for (auto e : s->ev_dist) if (e) (void)hipEventDestroy(e);
     if (s->d_avg) (void)hipFree(s->d_avg);
@@ -2038,8 +2039,8 @@ static int sim_create_impl(const ps_sim_params *p, ps_sim *s)
     HIPCHK(hipHostMalloc(&s->h_avg, N * sizeof(double)));
     s->device_draw = N >= 4096;
     if (const char *e = getenv("PANSIM_DEVICE_DRAW")) s->device_draw = atoi(e) != 0;
-    HIPCHK(hipHostMalloc(&s->h_cum, N * sizeof(double), hipHostMallocMapped));
-    HIPCHK(hipHostGetDevicePointer((void **)&s->m_cum, s->h_cum, 0));
+    HIPCHK(hipHostMalloc(&s->h_cum, N * sizeof(double)));
+    HIPCHK(hipMalloc(&s->d_cum, N * sizeof(double)));
     HIPCHK(hipMalloc(&s->d_avg, N * sizeof(double)));
     if (G) {
         std::vector<double> l1p(G);
@@ -2104,12 +2105,13 @@ static int sim_one_generation(ps_sim *s, uint32_t gen)
     th0 = clk::now();
     s->last_slot = slot;
     if (s->device_draw) {
-        // cumulative table on the host (sequential f64 sums, as WeightedIndex::new builds it), draws on the
-        // device: the kernel reads the 8*N bytes from host-mapped memory once and writes the parents both to
-        // device memory and to the host-mapped slot
+        // cumulative table on the host (sequential f64 sums, as WeightedIndex::new builds it), copied to the
+        // device (8*N bytes; the 16 dependent reads of every search would otherwise cross PCIe: 155 us at
+        // N = 65536); the kernel writes the parents both to device memory and to the host-mapped slot
         double total = w[0];
         for (uint64_t i = 1; i < N; i++) { s->h_cum[i - 1] = total; total += w[i]; }
-        acc_draw_parents_kernel<<<(uint32_t)((N + 255) / 256), 256, 0, sa>>>(s->m_cum, total, (uint32_t)N, (uint32_t)p.seed,
+        HIPCHK(hipMemcpyAsync(s->d_cum, s->h_cum, (N - 1) * sizeof(double), hipMemcpyHostToDevice, sa));
+        acc_draw_parents_kernel<<<(uint32_t)((N + 255) / 256), 256, 0, sa>>>(s->d_cum, total, (uint32_t)N, (uint32_t)p.seed,
                                                                          (uint32_t)(p.seed >> 32), gen, s->d_idx[slot],
                                                                          s->m_idx[slot]);
         HIPCHK(hipGetLastError());
