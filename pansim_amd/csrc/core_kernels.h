@@ -13,6 +13,8 @@
 
 #include "ps_common.h"
 
+#include <type_traits>
+
 struct core_sweep_args {
     uint8_t *state;
     const uint32_t *idx;   // parents (device), DO_GATHER only
@@ -507,17 +509,29 @@ struct core_block_geom {
     uint32_t SB;       // segments per wave batch (template parameter PS_SB: 4, or 2 when LDS is short)
 };
 
+// mask (in the permuted bit order of ps_candidates_swar) of the cells i0 .. i0+15 that exist (< N)
+__device__ __forceinline__ uint32_t ps_valid_cells(uint32_t i0, uint32_t N)
+{
+    if (i0 + 16u <= N) return 0xF0F0F0F0u;
+    uint32_t m = 0;
+    for (uint32_t k = 0; k < 16u; k++)
+        if (i0 + k < N) m |= 1u << (8u * (k & 3u) + 7u - (k >> 2));
+    return m;
+}
+
 template <uint32_t PS_SB, bool PRE, bool DO_GATHER, bool DO_MUT, bool DO_HR, bool STASH>
 __global__ void __launch_bounds__(1024) core_sweep_block_kernel(core_sweep_args a, core_block_geom g)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
-    const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63u, nw = blockDim.x >> 6;
+    // (the wave index through readfirstlane: everything derived from it -- rows, segments, sites of the wave's
+    // slots -- then lives in scalar registers instead of being recomputed with vector multiplies per slot)
+    const uint32_t tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63u, nw = blockDim.x >> 6;
     uint8_t *rowS = lds;                                   // child rows [R][pitch]
     uint8_t *rowA = lds + (DO_GATHER ? g.R * a.pitch : 0); // parent rows [R][pitch] (gather only)
     uint32_t *wbase = (uint32_t *)(lds + (DO_GATHER ? 2u : 1u) * g.R * a.pitch) + wave * (g.QW + 2u * g.HW);
     uint32_t *q = wbase, *hr_a = wbase + g.QW, *hr_b = hr_a + g.HW;
     const ps_core_plan pl = a.plan;
-    const bool events = pl.has_events && (DO_MUT || DO_HR);
+    constexpr bool events = DO_MUT || DO_HR;      // (the host launches these variants only for plans with events)
     const uint32_t c4 = (pl.bC + 1u) * 0x01010101u;
     const uint32_t t0b = pl.T[0] >> 24, t1b = pl.T[1] >> 24, t2b = pl.T[2] >> 24;
     unsigned long long lut = 0;     // 2-bit code per byte value < 32 (see the wave sweep)
@@ -534,10 +548,12 @@ __global__ void __launch_bounds__(1024) core_sweep_block_kernel(core_sweep_args 
     // whole launch, and all parent indices fit 16 bits: the wave keeps the 16 parents of each of
     // its lanes' cells in registers, two per VGPR (idxP[chunk][8], built by idx_pack16_kernel)
     uint32_t pid[PS_SB][8];
+    uint32_t vperm_pre[PS_SB];      // PRE: valid-cell masks of the wave's (fixed) segments
     if (PRE && DO_GATHER) {
         uint32_t sg = first_sg;
 #pragma unroll
         for (uint32_t s = 0; s < PS_SB; s++) {
+            vperm_pre[s] = ps_valid_cells((sg * 64u + lane) * 16u, a.N);
             const uint32_t chunk = min(sg * 64u + lane, a.cpr - 1u);
             const uint4 lo = *(const uint4 *)(a.idxT + 8u * chunk), hi = *(const uint4 *)(a.idxT + 8u * chunk + 4u);
             pid[s][0] = lo.x; pid[s][1] = lo.y; pid[s][2] = lo.z; pid[s][3] = lo.w;
@@ -584,81 +600,112 @@ __global__ void __launch_bounds__(1024) core_sweep_block_kernel(core_sweep_args 
         for (uint32_t item0 = wave * PS_SB; item0 < items; item0 += nw * PS_SB) {
             uint32_t s_base[PS_SB], s_site[PS_SB];   // wave-uniform per slot: LDS offset of the row, site
             uint32_t s_seg[PS_SB];                   // STASH: LDS offset of the slot's segment
+            uint32_t cmv[PS_SB];                     // STASH: candidate masks of the batch (one push loop for all slots)
             uint32_t qn = 0;
             uint32_t rr = rr0, sg = sg0;
-#pragma unroll
-            for (uint32_t s = 0; s < PS_SB; s++) {
+            // FULL (wave-uniform): every slot of the batch exists and every lane of every segment holds a chunk
+            // (N a multiple of 1024, whole row groups): no per-slot branches and no masked stores.  (Going further
+            // -- all gathers of the batch, then all Philox chains, then all stores -- needs 128 VGPRs with spills
+            // and was slower: 0.91 against 0.79 ms per 1.2e9 cells at N = 65536.)
+            auto slot = [&](auto full_tag, uint32_t s) {
+                constexpr bool FULL = decltype(full_tag)::value;
                 s_base[s] = rr * a.pitch;
                 s_seg[s] = rr * a.pitch + sg * 1024u;
                 s_site[s] = a.site_offset + r0 + rr;
-                if (item0 + s < items) {
+                cmv[s] = 0u;
+                if (FULL || item0 + s < items) {
+                    // lanes past the row (chunk >= cpr) compute on the row's last chunk and only their LDS store is
+                    // masked; their candidate mask is empty (no valid cells)
                     const uint32_t chunk = sg * 64u + lane;
-                    const bool has_chunk = chunk < a.cpr;
+                    const bool has_chunk = FULL || chunk < a.cpr;
+                    const uint32_t chunkc = FULL ? chunk : min(chunk, a.cpr - 1u);
                     const uint32_t i0 = chunk * 16u;
                     uint8_t *row = rowS + s_base[s];
                     uint32_t w[4] = { 0u, 0u, 0u, 0u };
                     if (DO_GATHER) {
                         const uint8_t *par = rowA + s_base[s];
-                        if (has_chunk) {
-                            if (PRE) {
+                        if (PRE) {
 #pragma unroll
-                                for (int j = 0; j < 4; j++) {
-                                    const uint32_t pk0 = pid[s][2 * j], pk1 = pid[s][2 * j + 1];
-                                    w[j] = ps_pack4(par[pk0 & 0xFFFFu], par[pk0 >> 16], par[pk1 & 0xFFFFu], par[pk1 >> 16]);
-                                }
-                            } else {
-                                // idxT[k][chunk]: consecutive lanes read consecutive words; entries beyond N
-                                // hold the index of the row's first padding byte (always 0)
-                                const uint32_t *ip = a.idxT + chunk;
-#pragma unroll
-                                for (int j = 0; j < 4; j++) {
-                                    w[j] = ps_pack4(par[ip[0]], par[ip[a.cpr]], par[ip[2u * a.cpr]], par[ip[3u * a.cpr]]);
-                                    ip += 4u * a.cpr;
-                                }
+                            for (int j = 0; j < 4; j++) {
+                                const uint32_t pk0 = pid[s][2 * j], pk1 = pid[s][2 * j + 1];
+                                w[j] = ps_pack4(par[pk0 & 0xFFFFu], par[pk0 >> 16], par[pk1 & 0xFFFFu], par[pk1 >> 16]);
                             }
-                            if (!(STASH && events)) *(uint4 *)(row + i0) = make_uint4(w[0], w[1], w[2], w[3]);
+                        } else {
+                            // idxT[k][chunk]: consecutive lanes read consecutive words; entries beyond N
+                            // hold the index of the row's first padding byte (always 0)
+                            const uint32_t *ip = a.idxT + chunkc;
+#pragma unroll
+                            for (int j = 0; j < 4; j++) {
+                                w[j] = ps_pack4(par[ip[0]], par[ip[a.cpr]], par[ip[2u * a.cpr]], par[ip[3u * a.cpr]]);
+                                ip += 4u * a.cpr;
+                            }
                         }
-                    } else if (STASH && events && has_chunk) {
-                        const uint4 cur = *(const uint4 *)(row + i0);
+                        if (!(STASH && events) && has_chunk) *(uint4 *)(row + i0) = make_uint4(w[0], w[1], w[2], w[3]);
+                    } else if (STASH && events) {
+                        const uint4 cur = *(const uint4 *)(row + chunkc * 16u);
                         w[0] = cur.x; w[1] = cur.y; w[2] = cur.z; w[3] = cur.w;
                     }
                     if (events) {
-                        const uint32_t nvalid = (i0 >= a.N) ? 0u : min(16u, a.N - i0);
-                        uint32_t vperm = 0xF0F0F0F0u;   // all 16 cells valid
-                        if (nvalid < 16u) {
-                            vperm = 0;
-                            for (uint32_t k = 0; k < nvalid; k++) vperm |= 1u << (8u * (k & 3u) + 7u - (k >> 2));
-                        }
+                        const uint32_t vperm = FULL ? 0xF0F0F0F0u : PRE ? vperm_pre[s] : ps_valid_cells(i0, a.N);
                         const ps_u4 l1 = ps_philox(s_site[s], chunk, a.gen, PS_STREAM_CORE_L1, a.k0, a.k1);
                         uint32_t cm = ps_candidates_swar(l1, c4) & vperm;
-                        if (STASH && has_chunk)      // child bytes with the level-1 nibbles (see the wave sweep)
-                            *(uint4 *)(row + i0) = make_uint4(ps_stash(w[0], l1.x), ps_stash(w[1], l1.y),
-                                                              ps_stash(w[2], l1.z), ps_stash(w[3], l1.w));
-                        const uint32_t off0 = s_base[s] + i0;
-                        const uint32_t ebase = (lane << 5) | (s << 11);
-                        for (;;) {
-                            const bool act = cm != 0u;
-                            const uint64_t bal = __ballot(act);
-                            if (bal == 0ull) break;
-                            if (act) {
-                                const uint32_t p = __builtin_ctz(cm);
-                                cm &= cm - 1u;
-                                const uint32_t pos = qn + ps_lane_prefix(bal);
-                                if (STASH) {
-                                    if (pos < g.QW) q[pos] = ebase | p;
-                                } else {
+                        if (STASH) {
+                            // child bytes with the level-1 nibbles (see the wave sweep); the push happens below
+                            if (has_chunk)
+                                *(uint4 *)(row + i0) = make_uint4(ps_stash(w[0], l1.x), ps_stash(w[1], l1.y),
+                                                                  ps_stash(w[2], l1.z), ps_stash(w[3], l1.w));
+                            cmv[s] = cm;
+                        } else {
+                            const uint32_t off0 = s_base[s] + i0;
+                            for (;;) {
+                                const bool act = cm != 0u;
+                                const uint64_t bal = __ballot(act);
+                                if (bal == 0ull) break;
+                                if (act) {
+                                    const uint32_t p = __builtin_ctz(cm);
+                                    cm &= cm - 1u;
+                                    const uint32_t pos = qn + ps_lane_prefix(bal);
                                     const uint32_t b = p >> 3, j = 7u - (p & 7u);
                                     const uint32_t sel = ((j & 1u) * 4u + b) | 0x0c0c0c00u;
                                     const uint32_t byte = (j & 2u) ? __builtin_amdgcn_perm(l1.w, l1.z, sel)
                                                                    : __builtin_amdgcn_perm(l1.y, l1.x, sel);
                                     if (pos < g.QW) q[pos] = (off0 + 4u * j + b) | (byte << 20) | (s << 28);
                                 }
+                                qn += (uint32_t)__popcll(bal);
                             }
-                            qn += (uint32_t)__popcll(bal);
                         }
                     }
                 }
                 if (++sg == g.segs) { sg = 0; rr++; }
+            };
+            if (item0 + PS_SB <= items && a.cpr == g.segs * 64u && a.N == a.pitch) {
+#pragma unroll
+                for (uint32_t s = 0; s < PS_SB; s++) slot(std::true_type{}, s);
+            } else {
+#pragma unroll
+                for (uint32_t s = 0; s < PS_SB; s++) slot(std::false_type{}, s);
+            }
+            if (STASH && events) {
+                // ONE push loop for the batch: its trip count is the largest number of candidates any lane holds in
+                // one segment, not the sum over the segments
+                for (;;) {
+                    uint32_t any = cmv[0];
+#pragma unroll
+                    for (uint32_t s = 1; s < PS_SB; s++) any |= cmv[s];
+                    if (__ballot(any != 0u) == 0ull) break;
+#pragma unroll
+                    for (uint32_t s = 0; s < PS_SB; s++) {
+                        const bool act = cmv[s] != 0u;
+                        const uint64_t bal = __ballot(act);
+                        if (act) {
+                            const uint32_t p = __builtin_ctz(cmv[s]);
+                            cmv[s] &= cmv[s] - 1u;
+                            const uint32_t pos = qn + ps_lane_prefix(bal);
+                            if (pos < g.QW) q[pos] = (lane << 5) | (s << 11) | p;
+                        }
+                        qn += (uint32_t)__popcll(bal);
+                    }
+                }
             }
             rr0 += step_rr;
             sg0 += step_sg;
