@@ -64,3 +64,50 @@ def test_cli_gpus_2_equals_gpus_1(pa, tmp_path):
         assert out == outs[0][1]
         for suffix in (".tsv", "_freqs.txt", "_per_gen.tsv", "_selection.tsv", "_core_genome.csv", "_pangenome.csv"):
             assert filecmp.cmp(str(outs[0][0]) + suffix, str(pref) + suffix, shallow=False), suffix
+
+
+def _hip_worker(rank, world, port, out):
+    # one rank of a two-process site-sharded run with the REAL HIP engine (both ranks share the box's one GPU);
+    # the exchange is pansim_amd.distributed over gloo (the driver's multi-GPU runs use nccl = RCCL)
+    import sys
+    import torch.distributed as dist
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from pansim_amd.distributed import ShardedSimulation
+    s = ShardedSimulation(rank, world, seed=21, n_gen=3, max_distances=900, device=0, **_MP_KW)
+    s.run(3)
+    agree = s.parents_agree()
+    core, acc = s.final_distances()
+    np.save(os.path.join(out, "core_%d.npy" % rank), core)
+    np.save(os.path.join(out, "acc_%d.npy" % rank), acc)
+    np.save(os.path.join(out, "shard_%d.npy" % rank), s.sim.core_genome.read_matrix())
+    open(os.path.join(out, "agree_%d" % rank), "w").write(str(int(agree)))
+    s.close()
+    dist.destroy_process_group()
+
+
+_MP_KW = dict(pop_size=260, core_size=3001, pan_genes=400, core_genes=100, HR_rate=0.3, HGT_rate=0.3)
+
+
+def test_two_processes_with_the_hip_engine(pa, orc, tmp_path):
+    # SURVEY 8(e) with one PROCESS per shard: every rank runs libpansim_hip with shard_count = 2, draws the same
+    # parents, and the all-reduced integer numerators give the unsharded distances
+    import torch.multiprocessing as mp
+    from orc_sim import OracleSim
+    world = 2
+    port = 31000 + os.getpid() % 2000
+    mp.spawn(_hip_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    full = OracleSim(seed=21, **_MP_KW)
+    for g in range(3):
+        full.generation(g)
+    r1, r2 = orc.sample_pairs(21, _MP_KW["pop_size"], 900)
+    want_core = orc.pairwise_distances(full.core, True, _MP_KW["core_genes"], r1, r2)
+    want_acc = orc.pairwise_distances(full.acc, False, _MP_KW["core_genes"], r1, r2)
+    shards = [np.load(tmp_path / ("shard_%d.npy" % r)) for r in range(world)]
+    assert np.array_equal(np.concatenate(shards, axis=1), full.core)
+    for r in range(world):
+        assert (tmp_path / ("agree_%d" % r)).read_text() == "1"
+        assert np.array_equal(np.load(tmp_path / ("core_%d.npy" % r)), want_core)
+        assert np.array_equal(np.load(tmp_path / ("acc_%d.npy" % r)), want_acc)
