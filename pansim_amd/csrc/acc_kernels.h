@@ -498,15 +498,80 @@ __global__ void __launch_bounds__(256) acc_pair_matrix_kernel(const uint64_t *ac
     Dt[(uint64_t)i * d.N + j] = 1.0 - (((double)in + 0.0 + core_genes) / ((double)un + 0.0 + core_genes));
 }
 
+// The same matrix from LDS tiles: a 256-thread workgroup owns 64 x 64 pairs (only tiles on or above the
+// diagonal; the distance is symmetric bit for bit, so both (i, j) and (j, i) are written), stages 16 row words
+// of the 64 + 64 individuals at a time, and every thread counts its 4 x 4 pairs from 4 + 4 LDS reads per word
+// (the plain kernel re-reads a 504-byte row per pair from L2: 0.15 ms alone, 0.31 ms beside the sweep at N = 1000).
+#define PS_PM_CH 16u
+__global__ void __launch_bounds__(256) acc_pair_matrix_tiled_kernel(const uint64_t *accI, double *Dt, acc_dims d,
+                                                                    double core_genes)
+{
+    __shared__ uint64_t TA[64u * (PS_PM_CH + 1u)], TB[64u * (PS_PM_CH + 1u)];
+    const uint32_t bi = blockIdx.y, bj = blockIdx.x;
+    if (bj < bi) return;
+    const uint32_t tid = threadIdx.x, tx = tid & 15u, ty = tid >> 4;
+    const uint32_t i0 = bi * 64u, j0 = bj * 64u;
+    uint32_t in[4][4], un[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; a++)
+#pragma unroll
+        for (int b = 0; b < 4; b++) { in[a][b] = 0; un[a][b] = 0; }
+    for (uint32_t g0 = 0; g0 < d.GW; g0 += PS_PM_CH) {
+        __syncthreads();
+        for (uint32_t t = tid; t < 64u * PS_PM_CH; t += 256u) {
+            const uint32_t r = t / PS_PM_CH, c = t % PS_PM_CH;
+            const bool okc = g0 + c < d.GW;
+            TA[r * (PS_PM_CH + 1u) + c] = (okc && i0 + r < d.N) ? accI[(uint64_t)(i0 + r) * d.GW + g0 + c] : 0ull;
+            TB[r * (PS_PM_CH + 1u) + c] = (okc && j0 + r < d.N) ? accI[(uint64_t)(j0 + r) * d.GW + g0 + c] : 0ull;
+        }
+        __syncthreads();
+#pragma unroll 4
+        for (uint32_t c = 0; c < PS_PM_CH; c++) {
+            uint64_t x[4], y[4];
+#pragma unroll
+            for (int a = 0; a < 4; a++) x[a] = TA[(ty + 16u * a) * (PS_PM_CH + 1u) + c];
+#pragma unroll
+            for (int b = 0; b < 4; b++) y[b] = TB[(tx + 16u * b) * (PS_PM_CH + 1u) + c];
+#pragma unroll
+            for (int a = 0; a < 4; a++)
+#pragma unroll
+                for (int b = 0; b < 4; b++) {
+                    in[a][b] += __popcll(x[a] & y[b]);
+                    un[a][b] += __popcll(x[a] | y[b]);
+                }
+        }
+    }
+#pragma unroll
+    for (int a = 0; a < 4; a++)
+#pragma unroll
+        for (int b = 0; b < 4; b++) {
+            const uint32_t i = i0 + ty + 16u * a, j = j0 + tx + 16u * b;
+            if (i < d.N && j < d.N) {
+                const double pd = 1.0 - (((double)in[a][b] + 0.0 + core_genes) / ((double)un[a][b] + 0.0 + core_genes));
+                Dt[(uint64_t)i * d.N + j] = pd;
+                if (bi != bj) Dt[(uint64_t)j * d.N + i] = pd;
+            }
+        }
+}
+
 __global__ void __launch_bounds__(64) acc_average_from_matrix_kernel(const double *Dt, double *out, acc_dims d)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= d.N) return;
+    // the fold is sequential (f64 addition in ascending j), the loads are not: 16 of them in flight per thread
+    // (one dependent load per addition made this kernel 0.27 ms at N = 1000: a thousand L2 latencies in a row)
     double sum = 0.0;
-    for (uint32_t j = 0; j < d.N; j++) {
-        if (j == i) continue;
-        sum = sum + Dt[(uint64_t)j * d.N + i];      // = distance(i, j)
+    uint32_t j = 0;
+    for (; j + 16u <= d.N; j += 16u) {
+        double v[16];
+#pragma unroll
+        for (uint32_t u = 0; u < 16u; u++) v[u] = Dt[(uint64_t)(j + u) * d.N + i];      // = distance(i, j + u)
+#pragma unroll
+        for (uint32_t u = 0; u < 16u; u++)
+            if (j + u != i) sum = sum + v[u];
     }
+    for (; j < d.N; j++)
+        if (j != i) sum = sum + Dt[(uint64_t)j * d.N + i];
     double fd = sum / (double)(d.N - 1u);
     if (fd == 0.0) fd = 2.2250738585072014e-308;    // f64::MIN_POSITIVE, population.rs:774-776
     out[i] = fd;

@@ -1168,8 +1168,8 @@ static int average_distance_device(ps_population *p, double *d_out, hipStream_t 
     const uint64_t N = p->cfg.pop_size;
     if (N <= 8192) {
         if (!p->d_Dt) HIPCHK(hipMalloc(&p->d_Dt, N * N * sizeof(double)));
-        dim3 grid((uint32_t)((N + 255) / 256), (uint32_t)N);
-        acc_pair_matrix_kernel<<<grid, 256, 0, st>>>(p->I[p->cur], p->d_Dt, p->d, (double)p->cfg.core_genes);
+        const uint32_t nt = (uint32_t)((N + 63) / 64);
+        acc_pair_matrix_tiled_kernel<<<dim3(nt, nt), 256, 0, st>>>(p->I[p->cur], p->d_Dt, p->d, (double)p->cfg.core_genes);
         acc_average_from_matrix_kernel<<<(uint32_t)((N + 63) / 64), 64, 0, st>>>(p->d_Dt, d_out, p->d);
     } else {
         acc_average_distance_kernel<<<(uint32_t)((N + 63) / 64), 64, 0, st>>>(p->I[p->cur], d_out, p->d,
