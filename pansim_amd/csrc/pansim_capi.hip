@@ -2414,6 +2414,18 @@ extern "C" int ps_multi_create(const ps_sim_params *p, int n_shards, const int *
             return rc;
         }
     }
+    // direct xGMI copies for the sum of the distance numerators (without peer access the runtime stages the
+    // copies through host memory: still correct, only slower)
+    const int dev0 = m->shard[0]->core->device;
+    for (int k = 1; k < n_shards; k++) {
+        const int devk = m->shard[(size_t)k]->core->device;
+        int can = 0;
+        if (devk != dev0 && hipSetDevice(dev0) == hipSuccess && hipDeviceCanAccessPeer(&can, dev0, devk) == hipSuccess && can) {
+            const hipError_t e = hipDeviceEnablePeerAccess(devk, 0);
+            if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) (void)hipGetLastError();
+        }
+    }
+    (void)hipGetLastError();
     *out = m;
     return PS_OK;
 }
