@@ -111,3 +111,27 @@ def test_two_processes_with_the_hip_engine(pa, orc, tmp_path):
         assert (tmp_path / ("agree_%d" % r)).read_text() == "1"
         assert np.array_equal(np.load(tmp_path / ("core_%d.npy" % r)), want_core)
         assert np.array_equal(np.load(tmp_path / ("acc_%d.npy" % r)), want_acc)
+
+
+@pytest.mark.parametrize("kw,n_shards", [
+    (dict(pop_size=64, core_size=5, pan_genes=120, core_genes=20), 5),                     # one site per shard
+    (dict(pop_size=130, core_size=333, pan_genes=50, core_genes=50), 2),                   # no accessory genes at all
+    (dict(pop_size=2, core_size=40, pan_genes=30, core_genes=10, HR_rate=0.9), 3),         # the smallest population
+])
+def test_multi_edge_shapes(pa, orc, kw, n_shards):
+    from orc_sim import OracleSim
+    P = 50
+    ref = OracleSim(seed=8, **kw)
+    multi = pa.MultiSimulation(pa.make_params(seed=8, n_gen=3, max_distances=P, **kw), n_shards, devices=[0] * n_shards)
+    multi.run(3)
+    multi.sync()
+    for g in range(3):
+        ref.generation(g)
+    got = np.concatenate([s.core_genome.read_matrix() for s in multi.shards], axis=1)
+    assert np.array_equal(got, ref.core)
+    r1, r2 = orc.sample_pairs(8, kw["pop_size"], P)
+    core_d, acc_d = multi.final_distances()
+    assert np.array_equal(core_d, orc.pairwise_distances(ref.core, True, kw["core_genes"], r1, r2))
+    want_acc = orc.pairwise_distances(ref.acc, False, kw["core_genes"], r1, r2)
+    assert np.array_equal(acc_d, want_acc, equal_nan=True)
+    multi.close()
