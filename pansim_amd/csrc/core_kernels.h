@@ -218,7 +218,9 @@ __device__ __forceinline__ uint4 ps_strip(uint4 v, bool on)
 }
 
 #ifdef PS_STAMP
-#define PS_T(k) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); st_acc[k] += t_ - st_last; st_last = t_; } while (0)
+// (asm volatile with a memory clobber: the compiler may not move the stamp across LDS / global accesses; pure
+// VALU work can still drift across it, so the split between adjacent compute phases stays indicative)
+#define PS_T(k) do { unsigned long long t_; asm volatile("s_waitcnt lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); st_acc[k] += t_ - st_last; st_last = t_; } while (0)
 #else
 #define PS_T(k) do { } while (0)
 #endif
@@ -232,7 +234,8 @@ __global__ void __launch_bounds__(256, PS_ROWS >= 4 ? 6 : 8) core_sweep_wave_ker
 {
 #ifdef PS_STAMP
     unsigned long long st_acc[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
-    unsigned long long st_last = __builtin_amdgcn_s_memtime();
+    unsigned long long st_last;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_last) :: "memory");
 #endif
     constexpr uint32_t PS_QCAP = ps_qcap(PS_ROWS);
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
@@ -530,6 +533,11 @@ __global__ void __launch_bounds__(1024) core_sweep_block_kernel(core_sweep_args 
     uint8_t *rowA = lds + (DO_GATHER ? g.R * a.pitch : 0); // parent rows [R][pitch] (gather only)
     uint32_t *wbase = (uint32_t *)(lds + (DO_GATHER ? 2u : 1u) * g.R * a.pitch) + wave * (g.QW + 2u * g.HW);
     uint32_t *q = wbase, *hr_a = wbase + g.QW, *hr_b = hr_a + g.HW;
+#ifdef PS_STAMP
+    unsigned long long st_acc[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+    unsigned long long st_last;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_last) :: "memory");
+#endif
     const ps_core_plan pl = a.plan;
     constexpr bool events = DO_MUT || DO_HR;      // (the host launches these variants only for plans with events)
     const uint32_t c4 = (pl.bC + 1u) * 0x01010101u;
@@ -594,6 +602,7 @@ __global__ void __launch_bounds__(1024) core_sweep_block_kernel(core_sweep_args 
             pf3 = *(const uint4 *)(src + (po3 < nbytes_next ? po3 : 0u));
         }
 
+        PS_T(0);   // loop control + prefetch issue
         uint32_t nhr = 0;       // wave-uniform length of this wave's HR list
         const uint32_t items = nr * g.segs;
         uint32_t rr0 = first_rr, sg0 = first_sg;
@@ -685,6 +694,7 @@ __global__ void __launch_bounds__(1024) core_sweep_block_kernel(core_sweep_args 
 #pragma unroll
                 for (uint32_t s = 0; s < PS_SB; s++) slot(std::false_type{}, s);
             }
+            PS_T(1);   // gather + level-1 Philox + child store (all slots)
             if (STASH && events) {
                 // ONE push loop for the batch: its trip count is the largest number of candidates any lane holds in
                 // one segment, not the sum over the segments
@@ -710,6 +720,7 @@ __global__ void __launch_bounds__(1024) core_sweep_block_kernel(core_sweep_args 
             rr0 += step_rr;
             sg0 += step_sg;
             if (sg0 >= g.segs) { sg0 -= g.segs; rr0++; }
+            PS_T(2);   // push loop
             if (!events) continue;
             ps_wave_sync();
             if (qn > g.QW) {
@@ -748,6 +759,7 @@ __global__ void __launch_bounds__(1024) core_sweep_block_kernel(core_sweep_args 
                 n2 += (uint32_t)__popcll(bal);
             }
             ps_wave_sync();
+            PS_T(3);   // dense pass
             // exact pass
             for (uint32_t base = 0; base < n2; base += 64u) {
                 const uint32_t e = base + lane;
@@ -785,6 +797,7 @@ __global__ void __launch_bounds__(1024) core_sweep_block_kernel(core_sweep_args 
             }
             ps_wave_sync();
         }
+        PS_T(4);   // exact pass
         if (DO_HR && events) {
             if (nhr > g.HW) {
                 if (lane == 0) atomicOr(a.overflow_flag, 4u);
@@ -795,7 +808,9 @@ __global__ void __launch_bounds__(1024) core_sweep_block_kernel(core_sweep_args 
             ps_block_sync_lds();    // all donor reads done
             for (uint32_t e = lane; e < nhr; e += 64u) rowS[hr_a[e]] = (uint8_t)hr_b[e];
         }
+        PS_T(5);   // HR (two barriers inside) incl. the wait at its first barrier
         ps_block_sync_lds();        // the child rows are final; nobody reads the parent rows any more
+        PS_T(6);   // barrier: child rows final
         // The prefetch has had the whole group's compute time to land.  The wait is explicit and on every
         // path: only the prefetch loads and the previous group's long-finished stores are outstanding
         // here, so vmcnt(0) is exact -- whereas waits the compiler attaches to the conditional LDS stores
@@ -843,7 +858,12 @@ __global__ void __launch_bounds__(1024) core_sweep_block_kernel(core_sweep_args 
                 *(uint4 *)(stage + o) = *(const uint4 *)(src + o);
         }
         ps_block_sync_lds();        // the next iteration overwrites the child rows
+        PS_T(7);   // wait for the prefetch, stage, store, closing barrier
     }
+#ifdef PS_STAMP
+    if (lane == 0)
+        for (int k = 0; k < 8; k++) atomicAdd((unsigned long long *)a.stamps + k, st_acc[k]);
+#endif
 }
 
 // idxP[chunk][j] = idx[16*chunk + 2j] | idx[16*chunk + 2j + 1] << 16 (N beyond N, as in idxT):
