@@ -153,19 +153,21 @@ __global__ void __launch_bounds__(1024) core_sweep_inline_kernel(core_sweep_args
 //
 // A wave takes PS_ROWS consecutive site rows per iteration (their loads are in
 // flight together and the 16 parent indices of a lane are shared by all rows).
-// Events are sparse (about 5 % of the cells at the default rates), so per row:
-//   1. one Philox call per lane gives the 16 level-1 bytes; a SWAR compare finds
-//      the candidate bytes (<= bC);
-//   2. a candidate whose byte lies strictly inside one "mutate only" interval of the
-//      plan is decided by the byte alone (the 24 refinement bits cannot change the
-//      outcome) and its allele is written straight into the LDS row;
-//   3. the remaining candidates (byte holds a threshold, or may receive a donor
-//      allele) are compacted into a wave-private LDS queue with ballot/mbcnt.
-// The queue is drained once per PS_ROWS rows, 64 entries at a time with every lane
-// busy: level-2 Philox, exact classification, mutation bytes into the LDS rows, HR
-// donors read from the post-mutation rows and written back after all reads.
+// Events are sparse (about 5 % of the cells at the default rates), so
+//   1. per row, one Philox call per lane gives the 16 level-1 bytes and a SWAR compare
+//      finds the candidate bytes (<= bC); the gathered child bytes go back to the LDS
+//      row (STASH form: with the low nibble of the level-1 byte in bits 4-7);
+//   2. ONE ballot/mbcnt loop per iteration pushes EVERY candidate cell of the PS_ROWS
+//      rows into a wave-private LDS queue (nothing is decided at push time);
+//   3. a dense pass, 64 entries at a time with every lane busy, decides the candidates
+//      whose byte lies strictly inside one "mutate only" interval of the plan from the
+//      byte alone (the 24 refinement bits cannot change the outcome), writes their
+//      alleles into the LDS rows and compacts the undecided ones in place;
+//   4. an exact pass over the undecided cells: level-2 Philox, 32-bit thresholds,
+//      mutation bytes into the LDS rows; HR donors are read from the post-mutation rows
+//      and written back after all reads.
 // The host only selects this kernel when the queue cannot overflow in practice
-// (mean + 12 sigma of the entry count fits); an overflow raises a sticky error flag.
+// (mean + 10 sigma of the entry count fits); an overflow raises a sticky error flag.
 // ---------------------------------------------------------------------------
 // rows per wave iteration (template parameter ROWS) and queue capacity per wave
 __host__ __device__ constexpr uint32_t ps_qcap(uint32_t rows) { return rows >= 4 ? 640u : rows == 3 ? 512u : 384u; }
