@@ -496,7 +496,8 @@ __global__ void __launch_bounds__(256, PS_ROWS >= 4 ? 6 : 8) core_sweep_wave_ker
 // cells that receive a donor allele are collected in a per-wave HR list, and the donor
 // reads / writes happen between block barriers once every segment of the row group has
 // been mutated (the donor may sit in any segment).
-// Queue entry: LDS byte offset of the cell in rowS (20 bits) | level-1 byte << 20 | slot << 28.
+// Queue entry: LDS byte offset of the cell in rowS (20 bits) | level-1 byte << 20 | slot << 28; in the STASH form
+// the push loop writes (bit position | lane << 5 | slot << 11) and the dense pass expands it to that format.
 // ---------------------------------------------------------------------------
 #define PS_PF 4u   // prefetch registers (uint4) per thread: pf0..pf3 in the kernel
 // Workgroup barrier that orders LDS traffic only: outstanding global loads (the prefetch of the
