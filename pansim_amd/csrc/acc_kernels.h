@@ -484,21 +484,7 @@ __global__ void acc_average_distance_kernel(const uint64_t *accI, double *out, a
 // (1) every pair's Jaccard distance, written transposed (the distance is symmetric bit for bit),
 // (2) one thread per individual sums its column in ascending j -- the reference's left-to-right
 //     fold (population.rs:770) -- with coalesced reads.
-__global__ void __launch_bounds__(256) acc_pair_matrix_kernel(const uint64_t *accI, double *Dt, acc_dims d,
-                                                              double core_genes)
-{
-    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x, i = blockIdx.y;
-    if (j >= d.N) return;
-    const uint64_t *x = accI + (uint64_t)i * d.GW, *y = accI + (uint64_t)j * d.GW;
-    uint32_t in = 0, un = 0;
-    for (uint32_t gw = 0; gw < d.GW; gw++) {
-        in += __popcll(x[gw] & y[gw]);
-        un += __popcll(x[gw] | y[gw]);
-    }
-    Dt[(uint64_t)i * d.N + j] = 1.0 - (((double)in + 0.0 + core_genes) / ((double)un + 0.0 + core_genes));
-}
-
-// The same matrix from LDS tiles: a 256-thread workgroup owns 64 x 64 pairs (only tiles on or above the
+// The matrix comes from LDS tiles: a 256-thread workgroup owns 64 x 64 pairs (only tiles on or above the
 // diagonal; the distance is symmetric bit for bit, so both (i, j) and (j, i) are written), stages 16 row words
 // of the 64 + 64 individuals at a time, and every thread counts its 4 x 4 pairs from 4 + 4 LDS reads per word
 // (the plain kernel re-reads a 504-byte row per pair from L2: 0.15 ms alone, 0.31 ms beside the sweep at N = 1000).

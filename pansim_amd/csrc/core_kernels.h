@@ -448,7 +448,7 @@ __global__ void __launch_bounds__(256, PS_ROWS >= 4 ? 6 : 8) core_sweep_wave_ker
                         const uint32_t ent = q[e];
                         if (ent >> 31) {
                             const uint32_t donor = (ent >> 12) & 1023u;
-                            q[e] = (ent & 4095u) | (((uint32_t)rowbuf[(ent & 3072u) | donor] & 15u) << 12) | 0x80000000u;
+                            q[e] = (ent & 4095u) | (((uint32_t)rowbuf[(ent & 3072u) | donor] & (STASH ? 15u : 255u)) << 12) | 0x80000000u;
                         }
                     }
                 }
@@ -807,7 +807,7 @@ __global__ void __launch_bounds__(1024) core_sweep_block_kernel(core_sweep_args 
                 nhr = g.HW;
             }
             ps_block_sync_lds();    // every segment is mutated: rowS is the snapshot (population.rs:693-695)
-            for (uint32_t e = lane; e < nhr; e += 64u) hr_b[e] = (uint32_t)rowS[hr_b[e]] & 15u;
+            for (uint32_t e = lane; e < nhr; e += 64u) hr_b[e] = (uint32_t)rowS[hr_b[e]] & (STASH ? 15u : 255u);
             ps_block_sync_lds();    // all donor reads done
             for (uint32_t e = lane; e < nhr; e += 64u) rowS[hr_a[e]] = (uint8_t)hr_b[e];
         }

@@ -569,8 +569,9 @@ static int launch_core_sweep_wave_r(ps_population *p, const core_sweep_args &a, 
     const uint32_t fit = std::max(1u, std::min(8u, p->lds_limit / lds));
     const uint32_t bpc = std::min(p->sweep_blocks_per_cu, fit);
     const uint32_t grid = std::max(8u, std::min((want + 7u) & ~7u, 256u * bpc));   // a multiple of the 8 groups
-    // every candidate byte below 16: the level-1 nibble rides in the child byte (core_kernels.h, STASH)
-    if (a.plan.has_events && a.plan.bC <= 15u)
+    // every candidate byte below 16 and every state byte below 16 (a loaded matrix may hold any byte): the level-1
+    // nibble rides in the child byte (core_kernels.h, STASH)
+    if (a.plan.has_events && a.plan.bC <= 15u && p->nibble_safe)
         hipLaunchKernelGGL((core_sweep_wave_kernel<ROWS, GA, MU, HR, true>), dim3(grid), dim3(block), lds, st, a);
     else
         hipLaunchKernelGGL((core_sweep_wave_kernel<ROWS, GA, MU, HR, false>), dim3(grid), dim3(block), lds, st, a);
@@ -667,10 +668,10 @@ static int launch_block_kernel_s(const core_sweep_args &a, const core_block_geom
 }
 
 template <uint32_t SB, bool PRE, bool GA, bool MU, bool HR>
-static int launch_block_kernel(const core_sweep_args &a, const core_block_geom &g, uint32_t lds, uint32_t nw, hipStream_t st)
+static int launch_block_kernel(const core_sweep_args &a, const core_block_geom &g, uint32_t lds, uint32_t nw, hipStream_t st, bool nibble_safe)
 {
-    // every candidate byte below 16: the level-1 nibble rides in the child byte (core_kernels.h, STASH)
-    if (a.plan.has_events && a.plan.bC <= 15u) return launch_block_kernel_s<SB, PRE, GA, MU, HR, true>(a, g, lds, nw, st);
+    // every candidate byte and every state byte below 16: the level-1 nibble rides in the child byte (core_kernels.h, STASH)
+    if (a.plan.has_events && a.plan.bC <= 15u && nibble_safe) return launch_block_kernel_s<SB, PRE, GA, MU, HR, true>(a, g, lds, nw, st);
     return launch_block_kernel_s<SB, PRE, GA, MU, HR, false>(a, g, lds, nw, st);
 }
 
@@ -687,10 +688,10 @@ static int launch_core_sweep_block(ps_population *p, const core_sweep_args &a, c
             else idx_transpose_kernel<<<(n + 255) / 256, 256, 0, st>>>(d_idx, p->d_idxT, a.N, p->cpr);
         }
         if (GA && pre)
-            return g.SB == 4u ? launch_block_kernel<4, GA, GA, MU, HR>(a, g, lds, nw, st)
-                              : launch_block_kernel<2, GA, GA, MU, HR>(a, g, lds, nw, st);
-        return g.SB == 4u ? launch_block_kernel<4, false, GA, MU, HR>(a, g, lds, nw, st)
-                          : launch_block_kernel<2, false, GA, MU, HR>(a, g, lds, nw, st);
+            return g.SB == 4u ? launch_block_kernel<4, GA, GA, MU, HR>(a, g, lds, nw, st, p->nibble_safe)
+                              : launch_block_kernel<2, GA, GA, MU, HR>(a, g, lds, nw, st, p->nibble_safe);
+        return g.SB == 4u ? launch_block_kernel<4, false, GA, MU, HR>(a, g, lds, nw, st, p->nibble_safe)
+                          : launch_block_kernel<2, false, GA, MU, HR>(a, g, lds, nw, st, p->nibble_safe);
     }
     // inline kernel: every candidate handled by its owner lane, no queues to overflow
     const uint32_t block = 1024u;
@@ -1186,6 +1187,7 @@ static int ensure_pairs(ps_population *p, uint64_t P)
     p->d_pairs = nullptr;
     p->pairs_cap = 0;
     p->pairs_cached = 0;
+    p->pairs_src1 = p->pairs_src2 = nullptr;      // the pointer-identity shortcut of upload_pairs dies with the device copy
     HIPCHK(hipMalloc(&p->d_pairs, P * 7 * sizeof(uint32_t)));   // r1 | r2 | perm | outA | outB | tstart | tcount
     p->pairs_cap = P;
     return PS_OK;

@@ -84,6 +84,11 @@ class Simulation:
         self.generation = 0
 
     def close(self):
+        # core_genome / pan_genome borrow handles owned by the ps_sim: they die with it
+        for name in ("core_genome", "pan_genome"):
+            pop = getattr(self, name, None)
+            if pop is not None:
+                pop._h = C.c_void_p()
         if getattr(self, "_h", None) and self._h.value and self._owned:
             self._lib.ps_sim_destroy(self._h)
         self._h = C.c_void_p()
@@ -170,6 +175,12 @@ class MultiSimulation:
         self.generation = 0
 
     def close(self):
+        # the shard wrappers borrow handles owned by the ps_multi: null them first, so that a later use raises
+        # a PansimError (null handle) instead of touching freed memory
+        for s in getattr(self, "shards", []):
+            for pop in (s.core_genome, s.pan_genome):
+                pop._h = C.c_void_p()
+            s._h = C.c_void_p()
         if getattr(self, "_h", None) and self._h.value:
             self._lib.ps_multi_destroy(self._h)
         self._h = C.c_void_p()

@@ -73,6 +73,11 @@ def run(trials, seed=1, log=print):
         lm = float(rng.choice([0.0, 0.2, 0.05 * LG, 0.2 * LG]))
         lh = float(rng.choice([0.0, 0.1, 0.02 * LG, 0.2 * LG])) if N > 1 else 0.0
         m = (1 << rng.integers(0, 4, (N, L))).astype(np.uint8)
+        if rng.random() < 0.2:
+            # a loaded matrix may hold any byte (ps_load_matrix): the sweeps must carry bytes above 15 through
+            # gather, mutation and HR unchanged (the STASH forms, which borrow bits 4-7, are not used then)
+            for _ in range(int(rng.integers(1, 8))):
+                m[rng.integers(0, N), rng.integers(0, L)] = int(rng.choice([0, 3, 16, 17, 128, 200, 255]))
         sample = rng.integers(0, N, N).astype(np.uint32)
         seed, gen = int(rng.integers(0, 2**40)), int(rng.integers(0, 2**31))
         plan = o.core_plan(lm, lh, LG)

@@ -574,6 +574,41 @@ def test_block_sweep_geometries(pa, orc, N, L, tune):
     pop.close()
 
 
+@pytest.mark.parametrize("N,L,tune", [(1000, 60, {}), (700, 33, {"sweep_rows": 2}), (3000, 40, {}),
+                                      (1000, 50, {"force_block_sweep": 1}), (9000, 24, {"block_batch": 2}),
+                                      (2048, 30, {"force_inline_sweep": 1})])
+def test_sweeps_carry_bytes_above_15(pa, orc, N, L, tune):
+    # ps_load_matrix accepts any byte; at the default rates (bC <= 15) the sweeps use their STASH forms, which
+    # borrow bits 4-7 of the child byte in LDS -- only for matrices whose bytes are all below 16.  A matrix with
+    # bytes 16 / 200 / 255 must come through gather, mutation and HR like in the oracle.
+    rng = np.random.default_rng(N * 13 + L)
+    m0 = _rand_core(rng, N, L)
+    for v in (16, 17, 128, 200, 255, 0, 3):
+        for _ in range(40):
+            m0[rng.integers(0, N), rng.integers(0, L)] = v
+    sample = rng.integers(0, N, N).astype(np.uint32)
+    LG = 1200000
+    lm, lh = 0.05 * LG, 0.0025 * LG          # cfg2's per-site rates: bC = 12
+    plan = orc.core_plan(lm, lh, LG)
+    want = orc.next_generation(m0, sample)
+    orc.mutate_core(want, 100, 21, 5, plan)
+    orc.recombine_core(want, 100, 21, 5, plan)
+    pop = pa.Population(N, L, 4, True, 0.0, 21, 0, col_offset=100, global_cols=LG)
+    for k, v in tune.items():
+        pop.set_tuning(k, v)
+    pop.set_rates([lm], [lh])
+    pop.load_matrix(m0)
+    pop.step(5, sample, True)
+    assert np.array_equal(pop.read_matrix(), want)
+    # the three calls in order agree as well
+    pop.load_matrix(m0)
+    pop.next_generation(sample)
+    pop.mutate_alleles(5)
+    pop.recombine(5)
+    assert np.array_equal(pop.read_matrix(), want)
+    pop.close()
+
+
 # ----------------------------------------------------------------------------- BASELINE full sizes
 def _crc(a):
     import zlib
