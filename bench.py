@@ -5,25 +5,32 @@ A "step" is one generation of main.rs:429-464 (fitness-weighted parent draw, par
 both matrices, core mutation, accessory gain/loss, HR, HGT) on BASELINE.json configs[1]:
 --pop_size 1000 --core_size 1200000 --pan_genes 6000 (defaults otherwise), state resident in HBM.
 
+The default line (N = 1) also carries `other_configs`: short runs of the other BASELINE configurations on the same
+GPU -- cfg3 (HR = HGT = 0.5), the cfg5 population (N = 8192: sweep + the all-pairs distance phase at P = 2^25),
+cfg4 (N = 65536) as one rank of 8 (`--emulate-shard 8`) and whole on one GPU -- each with generations/s, the
+sweep's roofline fraction and the distance phase.  `--config NAME` makes one of them the main workload (that is
+how the per-config rocprofv3 summaries under profiles/ are collected).
+
 Multi-GPU (one process per GPU, launched by torch.distributed.run): the core genome is sharded
-BY SITE.  Weak scaling: every rank holds 1.2 M sites of a core genome of
-n_gpus x 1.2 M sites; the accessory matrix is replicated and every rank draws the same parents
-from the same seeded stream, so a generation needs no data-path collective.  `value` counts
-1.2 M-site shard-generations per second summed over ranks (at n_gpus = 1: plain generations/s);
-`whole_genome_generations_per_s` is the rate of the (n_gpus x larger) simulation itself.
-`--scaling strong` (not the driver's contract) keeps --core_size as the whole genome and splits it
-over the ranks: BASELINE configs[3] is `--pop_size 65536 --scaling strong`.
-`--emulate-shard K` (one GPU): this process runs shard 0 of K -- 1/K of the sites, the whole replicated
-accessory chain and the host half of the parent draw -- i.e. what one rank of a K-GPU strong-scaling run does
-per generation; `host_half_ms` splits the host side.
+BY SITE.  The driver's contract line is WEAK scaling of cfg2: every rank holds 1.2 M sites of a core
+genome of n_gpus x 1.2 M sites; the accessory matrix is replicated and every rank draws the same parents
+from the same seeded stream.  `value` then counts 1.2 M-site SHARD-generations per second summed over the ranks
+(= `shard_generations_per_s`; at n_gpus = 1 plain generations/s); `whole_genome_generations_per_s` is the rate at
+which the (n_gpus x larger) simulation itself advances.  The same line carries `north_star_scaling`: the
+north-star's scaling workload, --pop_size 65536 with the 1.2 M core sites split over the ranks (STRONG scaling),
+in whole-simulation generations/s.  `--scaling strong` makes that split the main workload (`value` = the
+whole simulation's generations/s).
+`--emulate-shard K` (one GPU): this process runs shard 0 of K -- 1/K of the sites, its share of the accessory
+chain and the host half of the parent draw -- i.e. what one rank of a K-GPU strong-scaling run does per generation.
 
 Before anything is timed the sweep is run in untimed batches until its per-launch time is stable (clock ramp and
-first touch on a cold box), independently of --warmup.
+first touch on a cold box), independently of --warmup; with several ranks the decision to stop is shared, so that
+every rank runs the same number of generations.
 
 The JSON line also carries `roofline` (fused sweep: algorithmic bytes / HIP-event launch time against
-8 TB/s, PMC traffic from profiles/), `distance_roofline` (the sampled-pair distance phase: kernel time by HIP
-events), `cpu_baseline` (the reference algorithm restated in C on the host cores: all cores, one thread, and its
-distance phase), `mpairs_per_s` / `distance_ms` / `pair_sites_per_s` for the whole distance phase.
+8 TB/s, PMC traffic from profiles/), `distance_roofline` (the distance phase priced against the roofline of the
+kernel form that ran), `cpu_baseline` (the reference algorithm restated in C on the host cores: all cores, one
+thread, and its distance phase), `mpairs_per_s` / `distance_ms` / `pair_sites_per_s` for the whole distance phase.
 """
 import argparse
 import json
@@ -34,19 +41,36 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s
+MFMA_I8_PEAK_TOPS = 5000.0   # MI355X_MICROARCH.md, Matrix cores: I8 = 2x BF16 per clock, BF16 ~2.5 PFLOP/s dense
+
+CONFIGS = {
+    # name: (simulation parameters, P, shard emulation, default steps, default warmup, BASELINE label)
+    "cfg2": (dict(pop_size=1000, core_size=1200000, pan_genes=6000, HR_rate=0.05, HGT_rate=0.05), 100000, 0, None, None,
+             "BASELINE configs[1]"),
+    "cfg3": (dict(pop_size=1000, core_size=1200000, pan_genes=6000, HR_rate=0.5, HGT_rate=0.5), 100000, 0, 40, 5,
+             "BASELINE configs[2]"),
+    "cfg5pop": (dict(pop_size=8192, core_size=1200000, pan_genes=6000, HR_rate=0.05, HGT_rate=0.05), 1 << 25, 0, 10, 2,
+                "BASELINE configs[4] (population, P = 2^25 all-pairs distance phase; the matrix writers are not timed)"),
+    "cfg4_shard8": (dict(pop_size=65536, core_size=1200000, pan_genes=6000, HR_rate=0.05, HGT_rate=0.05), 100000, 8, 10, 2,
+                    "BASELINE configs[3], shard 0 of 8 emulated on one GPU"),
+    "cfg4": (dict(pop_size=65536, core_size=1200000, pan_genes=6000, HR_rate=0.05, HGT_rate=0.05), 100000, 0, 5, 1,
+             "BASELINE configs[3], all 1.2 M sites on one GPU (78.6 GB of core state)"),
+}
 
 
-def pmc_traffic():
+def pmc_traffic(kernel):
     """HBM bytes per launch of the fused sweep from the committed rocprofv3 --pmc passes
-    (profiles/r02_pmc_sweep.json, written by scripts/collect_pmc.py; FETCH_SIZE doubled per the
-    gfx950 correction of MI355X_MICROARCH.md).  None if that file is absent."""
+    (profiles/r0N_pmc_sweep.json, written by scripts/collect_pmc.py; FETCH_SIZE doubled per the
+    gfx950 correction of MI355X_MICROARCH.md).  None if no such file is present."""
+    names = (("r03_pmc_sweep.json", "r02_pmc_sweep.json", "r01_pmc_sweep.json") if kernel == "wave" else
+             ("r03_pmc_block_sweep.json", "r02_pmc_block_sweep.json"))
     try:
-        for name in ("r02_pmc_sweep.json", "r01_pmc_sweep.json"):
+        for name in names:
             path = os.path.join(ROOT, "profiles", name)
             if os.path.exists(path):
                 d = json.load(open(path))
-                return d["hbm_bytes_per_launch"], d["source"] + " (profiles/%s)" % name
+                return d["hbm_bytes_per_launch"], d["source"] + " (profiles/%s, workload %s)" % (name, d.get("workload", "?"))
         return None, None
     except (OSError, KeyError, ValueError):
         return None, None
@@ -78,7 +102,6 @@ def cpu_baseline(kw, seed, pairs, budget_s=20.0):
     """Reference algorithm (event-driven, rows in parallel like rayon) timed on the host cores:
     all cores (the figure `value` reports), one thread (the reference's --threads default), and the
     sampled-pair distance phase on a bounded number of pairs."""
-    import numpy as np
     from oracle import oracle as o
     threads = host_cores()
     sim = o.RefSim(o.make_params(**kw), seed=seed, threads=threads)
@@ -116,20 +139,214 @@ def cpu_baseline(kw, seed, pairs, budget_s=20.0):
                                     % n_pairs}}
 
 
+class Ctx:
+    """process-group plumbing shared by every workload of one bench.py invocation"""
+
+    def __init__(self, torch, dist, world, rank, local_rank, backend):
+        self.torch, self.dist, self.world, self.rank, self.local_rank, self.backend = torch, dist, world, rank, local_rank, backend
+        self.coll_dev = "cuda" if backend == "nccl" else "cpu"
+
+    def barrier(self):
+        if self.world > 1:
+            self.dist.barrier()
+        self.torch.cuda.synchronize()
+
+    def reduce(self, x, op="max"):
+        """all-reduce of one float over the ranks (max or min)"""
+        if self.world == 1:
+            return float(x)
+        t = self.torch.tensor([x], device=self.coll_dev, dtype=self.torch.float64)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX if op == "max" else self.dist.ReduceOp.MIN)
+        return float(t.item())
+
+
+def distance_roofline(form, N, L_local, G_acc, P, core_ms, acc_ms):
+    """Prices the core distance kernels' HIP-event time against the roofline of the kernel form that ran
+    (include/pansim_hip.h, PS_PAIR_FORM_*); byte and operation counts are the KERNELS' own algorithmic ones."""
+    kms = max(core_ms, 1e-6) * 1e-3
+    bpair_ref = 2.0 * (L_local + (G_acc + 7) // 8)      # SURVEY 8(d): the reference streams two byte rows per pair
+    out = {"kernel_ms": {"core": core_ms, "accessory": acc_ms},
+           "reference_equivalent_GBps": P * bpair_ref / kms / 1e9,
+           "note_reference_equivalent": "P x 2 (L + G/8) bytes of the reference's formulation / kernel time: a rate, not a "
+                                        "roofline fraction (the kernels read packed strings)"}
+    if form in (1, 3):
+        # regime (ii): pairs compared from LDS tiles.  Per 16 sites of a pair (one dword of 2-bit codes) the compare
+        # issues v_xor, v_lshrrev, v_bitop3 and v_bcnt: 4 VALU wave-instructions.  Peak at the guide's 2-cycle issue
+        # (MI355X_MICROARCH.md, wave scheduling): 64 lanes x 16 sites / 8 cycles per SIMD, 1024 SIMDs, 2.4 GHz;
+        # at the issue costs measured by scripts/ubench/valu_issue.hip (2.5 / 2.5 / 2.5 / 4.4 cycles) the same count
+        # gives 11.9 cycles.  Nibble form (3): 8 sites per dword, 2 instructions (v_xor, v_bcnt).
+        if form == 1:
+            peak_guide, peak_meas = 64 * 16 / 8.0 * 1024 * 2.4e9, 64 * 16 / 11.9 * 1024 * 2.4e9
+        else:
+            peak_guide, peak_meas = 64 * 8 / 4.0 * 1024 * 2.4e9, 64 * 8 / 6.9 * 1024 * 2.4e9
+        ach = P * float(L_local) / kms
+        out.update({"regime": "ii (sampled pairs from LDS tiles of the packed matrix, with reuse)", "bound": "valu",
+                    "achieved": ach, "peak": peak_guide, "unit": "pair-sites/s", "frac": ach / peak_guide,
+                    "peak_at_measured_issue_costs": peak_meas, "frac_at_measured_issue_costs": ach / peak_meas})
+    elif form == 4:
+        # regime (i): one transposition of the matrix to 2-bit strings (read N L bytes, write N L / 4), then two
+        # strings of L / 4 bytes streamed per pair
+        alg = float(N) * L_local * 1.25 + float(P) * 2.0 * L_local / 4.0
+        ach = alg / kms / 1e9
+        out.update({"regime": "i (matrix transposed once to 2-bit strings, two strings streamed per pair)", "bound": "hbm",
+                    "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                    "algorithmic_bytes": alg})
+    elif form == 6:
+        # all pairs on the matrix cores: N (N - 1) / 2 pairs x L sites x 4 one-hot products, 2 operations each
+        ops = float(N) * (N - 1) / 2.0 * L_local * 4.0 * 2.0
+        ach = ops / kms / 1e12
+        out.update({"regime": "all pairs, one-hot X X^T on v_mfma_i32_32x32x32_i8 (exact i32 counts), then lookup",
+                    "bound": "mfma-i8", "achieved": ach, "peak": MFMA_I8_PEAK_TOPS, "unit": "TOP/s", "frac": ach / MFMA_I8_PEAK_TOPS,
+                    "pair_sites_per_s": float(N) * (N - 1) / 2.0 * L_local / kms})
+    elif form == 2:
+        # all pairs, xor + popcount on nibble strings: 2 VALU wave-instructions per 8 sites of a pair
+        ach = float(N) * (N - 1) / 2.0 * L_local / kms
+        peak_guide, peak_meas = 64 * 8 / 4.0 * 1024 * 2.4e9, 64 * 8 / 6.9 * 1024 * 2.4e9
+        out.update({"regime": "all pairs, register-tiled xor + popcount on nibble strings, then lookup", "bound": "valu",
+                    "achieved": ach, "peak": peak_guide, "unit": "pair-sites/s (all N (N-1) / 2 pairs)", "frac": ach / peak_guide,
+                    "peak_at_measured_issue_costs": peak_meas, "frac_at_measured_issue_costs": ach / peak_meas})
+    else:
+        out.update({"regime": "one thread per pair on the byte matrix", "bound": "hbm", "achieved": None, "peak": None,
+                    "unit": None, "frac": None})
+    return out
+
+
+def measure(ctx, kw, P, steps, warmup, shard_rank, shard_count, seed=0, want_pairs=False):
+    """One workload: create the simulation (this rank's shard), settle, warm up, time exactly `steps` generations
+    between barriers (max over ranks), then the distance phase.  Returns a dict of raw measurements."""
+    import pansim_amd as pa
+    torch, dist, world = ctx.torch, ctx.dist, ctx.world
+    sim = pa.Simulation(pa.make_params(seed=seed, n_gen=steps + warmup, max_distances=P, shard_rank=shard_rank,
+                                       shard_count=shard_count, device=ctx.local_rank, **kw))
+    N = kw["pop_size"]
+    sim.enable_timing(True)
+    est_gen_ms = 2.0 * N * sim.core_genome.ncols / 4e9            # sweep at ~4 TB/s
+    settle, prev, batch = [], None, int(max(5, min(50, 30.0 / max(est_gen_ms, 1e-3))))
+    for _ in range(40):
+        sim.sweep_timing(reset=True)
+        sim.run(batch)
+        sim.sync()
+        n, ms, _b = sim.sweep_timing(reset=True)
+        cur = ms / max(n, 1)
+        settle.append(round(cur, 4))
+        stable = prev is not None and abs(cur - prev) <= 0.01 * prev and len(settle) >= 3
+        # every rank must leave the loop after the same number of generations (the parents and the accessory
+        # mutations are keyed on the generation number): stop only when every rank is stable
+        if ctx.reduce(0.0 if stable else 1.0, "max") == 0.0:
+            break
+        prev = cur
+    sim.run(warmup)
+    sim.sync()
+    sim.sweep_timing(reset=True)
+    sim.host_timing(reset=True)
+    ctx.barrier()
+    t0 = time.perf_counter()
+    sim.run(steps)
+    sim.sync()
+    ctx.barrier()
+    dt = ctx.reduce(time.perf_counter() - t0, "max")
+    launches, sweep_ms, bytes_per_launch = sim.sweep_timing(reset=True)
+    host_n, host_wait, host_weights, host_draw = sim.host_timing(reset=True)
+    sim.enable_timing(False)
+
+    # distance phase (main.rs:467-482): P sampled pairs, core Hamming + accessory Jaccard.
+    # Site-sharded: integer partial counts are summed over ranks (RCCL all-reduce).
+    dist_kernel_ms = None
+    if world == 1:
+        # one process holds every site it will ever hold: the library's own distance phase (both matrices'
+        # kernels enqueued together, pinned numerators, main.rs:467-470).  A first call builds the scratch
+        # buffers (2-bit copy of the matrix, partial counts); the timed call is the steady state of --print_dist.
+        sim.final_distances()
+        ctx.barrier()
+        t1 = time.perf_counter()
+        core_d, acc_d = sim.final_distances()
+        ctx.barrier()
+        dist_dt = time.perf_counter() - t1
+        dist_kernel_ms = sim.distance_timing()
+    else:
+        cnt = torch.zeros(P, dtype=torch.int32, device="cuda")
+        sim.core_genome.pairwise_counts_device(sim.range1, sim.range2, cnt.data_ptr())      # builds the scratch buffers
+        ctx.barrier()
+        t1 = time.perf_counter()
+        sim.core_genome.pairwise_counts_device(sim.range1, sim.range2, cnt.data_ptr())
+        if ctx.backend == "nccl":
+            dist.all_reduce(cnt)
+        else:
+            c = cnt.cpu()
+            dist.all_reduce(c)
+            cnt = c
+        acc_d = sim.pan_genome.pairwise_distances(P, sim.range1, sim.range2)
+        core_d = (cnt.cpu().numpy().astype("uint32") // 2) / float(kw["core_size"])
+        ctx.barrier()
+        dist_dt = ctx.reduce(time.perf_counter() - t1, "max")
+    assert core_d.shape == acc_d.shape
+    avg_ms = sweep_ms / max(launches, 1)
+    r = {"dt": dt, "steps": steps, "warmup": warmup, "launches": launches, "sweep_avg_ms": avg_ms,
+         "sweep_avg_ms_max_over_ranks": ctx.reduce(avg_ms, "max"), "sweep_avg_ms_min_over_ranks": ctx.reduce(avg_ms, "min"),
+         "bytes_per_launch": bytes_per_launch,
+         "host": (host_n, host_wait, host_weights, host_draw), "settle": settle, "dist_dt": dist_dt,
+         "dist_kernel_ms": dist_kernel_ms, "pair_form": sim.core_genome.last_pair_form(), "L_local": sim.core_genome.ncols,
+         "G_acc": sim.pan_genome.ncols, "P": P, "N": N, "kw": kw}
+    if want_pairs:
+        r["pairs"] = (sim.range1, sim.range2)
+    sim.close()
+    return r
+
+
+def sweep_roofline(r, with_traffic):
+    N = r["N"]
+    achieved = r["bytes_per_launch"] / (r["sweep_avg_ms"] * 1e-3) / 1e9 if r["launches"] else 0.0
+    kern = "wave" if N <= 1024 else "block"
+    traffic, traffic_src = pmc_traffic(kern) if with_traffic else (None, None)
+    return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+            "kernel": ("core_sweep_wave_kernel<gather,mutate,HR>" if kern == "wave" else
+                       "core_sweep_block_kernel<gather,mutate,HR>"), "avg_launch_ms": r["sweep_avg_ms"],
+            "algorithmic_bytes_per_launch": r["bytes_per_launch"]}
+
+
+def host_half(r):
+    host_n, host_wait, host_weights, host_draw = r["host"]
+    return {"generations": host_n, "wait_for_device": host_wait / max(host_n, 1),
+            "softmaxes": host_weights / max(host_n, 1), "parent_draw": host_draw / max(host_n, 1),
+            "note": "per generation, inside ps_sim_run; hidden behind the previous sweep when shorter than it"}
+
+
+def summary(r, label, emu=0):
+    """compact record of one workload (the entries of `other_configs` / `north_star_scaling`)"""
+    roof = sweep_roofline(r, False)
+    period = 1e3 * r["dt"] / r["steps"]
+    out = {"workload": label, "generations_per_s": r["steps"] / r["dt"], "ms_per_generation": period, "steps": r["steps"],
+           "warmup": r["warmup"], "core_sites_this_process": r["L_local"],
+           "sweep": {"kernel": roof["kernel"], "avg_launch_ms": roof["avg_launch_ms"], "achieved_GBps": roof["achieved"],
+                     "frac": roof["frac"], "algorithmic_bytes_per_launch": roof["algorithmic_bytes_per_launch"]},
+           "exposed_non_sweep_ms": period - roof["avg_launch_ms"],
+           "distance_ms": 1e3 * r["dist_dt"], "pairs": r["P"], "mpairs_per_s": r["P"] / r["dist_dt"] / 1e6,
+           "host_half_ms": host_half(r), "settle_sweep_ms": r["settle"]}
+    if r["dist_kernel_ms"] is not None:
+        out["distance_roofline"] = distance_roofline(r["pair_form"], r["N"], r["L_local"], r["G_acc"], r["P"], *r["dist_kernel_ms"])
+    if emu:
+        out["emulated_shards"] = emu
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=100)
-    ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--pop_size", type=int, default=1000)
-    ap.add_argument("--core_size", type=int, default=1200000, help="core sites PER GPU")
-    ap.add_argument("--pan_genes", type=int, default=6000)
-    ap.add_argument("--HR_rate", type=float, default=0.05)
-    ap.add_argument("--HGT_rate", type=float, default=0.05)
-    ap.add_argument("--max_distances", type=int, default=100000)
+    ap.add_argument("--steps", type=int, default=None)
+    ap.add_argument("--warmup", type=int, default=None)
+    ap.add_argument("--config", choices=sorted(CONFIGS), default=None,
+                    help="make this BASELINE configuration the main workload (default: cfg2, the metric's own)")
+    ap.add_argument("--pop_size", type=int, default=None)
+    ap.add_argument("--core_size", type=int, default=None, help="core sites PER GPU (weak) / in all (strong)")
+    ap.add_argument("--pan_genes", type=int, default=None)
+    ap.add_argument("--HR_rate", type=float, default=None)
+    ap.add_argument("--HGT_rate", type=float, default=None)
+    ap.add_argument("--max_distances", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--emulate-shard", type=int, default=0, metavar="K",
-                    help="one GPU only: run shard 0 of K of a strong-scaling run (1/K of --core_size, full accessory chain)")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the short runs of the other BASELINE configurations")
+    ap.add_argument("--emulate-shard", type=int, default=None, metavar="K",
+                    help="one GPU only: run shard 0 of K of a strong-scaling run (1/K of --core_size, its share of the accessory chain)")
     ap.add_argument("--competition_strength", type=float, default=0.0)
     ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
                     help="weak (default, the driver's contract): --core_size sites PER GPU; strong: --core_size is the "
@@ -138,8 +355,6 @@ def main():
 
     import torch
     import torch.distributed as dist
-
-    import pansim_amd as pa
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -155,163 +370,116 @@ def main():
     if backend != "nccl":
         local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
-    coll_dev = "cuda" if backend == "nccl" else "cpu"
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(backend)
+    ctx = Ctx(torch, dist, world, rank, local_rank, backend)
 
-    def barrier():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    emu = args.emulate_shard
+    # ---- the main workload
+    base_kw, base_P, base_emu, d_steps, d_warmup, label = CONFIGS[args.config or "cfg2"]
+    kw = dict(base_kw)
+    for k in ("pop_size", "core_size", "pan_genes", "HR_rate", "HGT_rate"):
+        if getattr(args, k) is not None:
+            kw[k] = getattr(args, k)
+    P = args.max_distances if args.max_distances is not None else base_P
+    emu = args.emulate_shard if args.emulate_shard is not None else base_emu
+    steps = args.steps if args.steps is not None else (d_steps or 100)
+    warmup = args.warmup if args.warmup is not None else (d_warmup if d_warmup is not None else 10)
     if emu and world != 1:
         raise SystemExit("--emulate-shard runs on one GPU")
     strong = args.scaling == "strong" or emu > 0
-    kw = dict(pop_size=args.pop_size, core_size=args.core_size * (1 if strong else world), pan_genes=args.pan_genes,
-              HR_rate=args.HR_rate, HGT_rate=args.HGT_rate)
+    default_wl = (args.config in (None, "cfg2") and kw == CONFIGS["cfg2"][0] and P == CONFIGS["cfg2"][1] and not strong
+                  and args.competition_strength == 0.0)
+    if not default_wl and kw == base_kw and args.config:
+        wl_label = label
+    elif default_wl:
+        wl_label = CONFIGS["cfg2"][5]
+    else:
+        wl_label = "BASELINE configs[3]" if kw["pop_size"] == 65536 else "custom"
+    core_per_gpu = kw["core_size"]
+    kw["core_size"] = core_per_gpu * (1 if strong else world)
     if args.competition_strength:
         kw["competition_strength"] = args.competition_strength
-    seed = 0
-    sim = pa.Simulation(pa.make_params(seed=seed, n_gen=args.steps + args.warmup,
-                                       max_distances=args.max_distances, shard_rank=0 if emu else rank,
-                                       shard_count=emu if emu else world, device=local_rank, **kw))
-    # untimed warm-up until the sweep's per-launch time is stable: a fresh box ramps its clocks and touches
-    # its pages during the first few hundred launches (the driver's --warmup 5 is 3 ms of GPU time at cfg2)
-    sim.enable_timing(True)
-    est_gen_ms = 2.0 * args.pop_size * sim.core_genome.ncols / 4e9            # sweep at ~4 TB/s
-    settle, prev, batch = [], None, int(max(5, min(50, 30.0 / max(est_gen_ms, 1e-3))))
-    for _ in range(40):
-        sim.sweep_timing(reset=True)
-        sim.run(batch)
-        sim.sync()
-        n, ms, _b = sim.sweep_timing(reset=True)
-        cur = ms / max(n, 1)
-        settle.append(round(cur, 4))
-        if prev is not None and abs(cur - prev) <= 0.01 * prev and len(settle) >= 3:
-            break
-        prev = cur
-    sim.run(args.warmup)
-    sim.sync()
-    sim.sweep_timing(reset=True)
-    sim.host_timing(reset=True)
-    barrier()
-    t0 = time.perf_counter()
-    sim.run(args.steps)
-    sim.sync()
-    barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], device=coll_dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-    launches, sweep_ms, bytes_per_launch = sim.sweep_timing(reset=True)
-    host_n, host_wait, host_weights, host_draw = sim.host_timing(reset=True)
-    sim.enable_timing(False)
+    r = measure(ctx, kw, P, steps, warmup, 0 if emu else rank, emu if emu else world, want_pairs=True)
 
-    # distance phase (main.rs:467-482): P sampled pairs, core Hamming + accessory Jaccard.
-    # Site-sharded: integer partial counts are summed over ranks (RCCL all-reduce).
-    P = args.max_distances
-    dist_kernel_ms = None
-    if world == 1:
-        # one process holds every site it will ever hold: the library's own distance phase (both matrices'
-        # kernels enqueued together, pinned numerators, main.rs:467-470).  A first call builds the scratch
-        # buffers (2-bit copy of the matrix, partial counts); the timed call is the steady state of --print_dist.
-        sim.final_distances()
-        barrier()
-        t1 = time.perf_counter()
-        core_d, acc_d = sim.final_distances()
-        barrier()
-        dist_dt = time.perf_counter() - t1
-        dist_kernel_ms = sim.distance_timing()
-    else:
-        cnt = torch.zeros(P, dtype=torch.int32, device="cuda")
-        barrier()
-        t1 = time.perf_counter()
-        sim.core_genome.pairwise_counts_device(sim.range1, sim.range2, cnt.data_ptr())
-        if backend == "nccl":
-            dist.all_reduce(cnt)
-        else:
-            c = cnt.cpu()
-            dist.all_reduce(c)
-            cnt = c
-        acc_d = sim.pan_genome.pairwise_distances(P, sim.range1, sim.range2)
-        core_d = (cnt.cpu().numpy().astype("uint32") // 2) / float(kw["core_size"])
-        barrier()
-        dist_dt = time.perf_counter() - t1
-    assert core_d.shape == acc_d.shape
-
+    out = None
     if rank == 0:
-        avg_ms = sweep_ms / max(launches, 1)
-        achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if launches else 0.0
-        default_wl = (args.pop_size, args.core_size, args.pan_genes, args.HR_rate, args.HGT_rate, strong, args.competition_strength) == (1000, 1200000, 6000, 0.05, 0.05, False, 0.0)
-        L_local = sim.core_genome.ncols
-        G_acc = sim.pan_genome.ncols
-        # regime of SURVEY 8(d) the core distance kernels ran in: N <= ~5000 -> pairs compared from LDS tiles of the
-        # 2-bit packed matrix (ii, integer-VALU bound); wider populations -> the matrix is transposed to 2-bit strings
-        # once and two strings are streamed per pair (i, HBM bound), or all-pairs tiles when 2 P > N^2 / 2
-        tiled = args.pop_size * 8 * 4 <= 160 * 1024
-        # VALU peak of regime (ii): per 16 sites of a pair (one dword of 2-bit codes) the compare issues
-        # v_xor, v_lshrrev, v_bitop3 (2.5 cycles each per wave-instruction on a SIMD at full occupancy) and
-        # v_bcnt_u32_b32 (4.4) -- scripts/ubench/valu_issue.hip -- i.e. 64 lanes x 16 sites per 11.9 cycles per
-        # SIMD, 1024 SIMDs at 2.4 GHz
-        valu_peak = 64 * 16 / 11.9 * 1024 * 2.4e9
-        bpair = 2.0 * (L_local + (G_acc + 7) // 8)
+        L_local, G_acc, N = r["L_local"], r["G_acc"], kw["pop_size"]
         droof = None
-        if dist_kernel_ms is not None:
-            core_ms, acc_ms = dist_kernel_ms
-            kms = max(core_ms, 1e-6)
-            droof = {"regime": "ii (LDS-tiled with reuse)" if tiled else "i (two bit strings streamed per pair after one transposition)",
-                     "kernel_ms": {"core": core_ms, "accessory": acc_ms},
-                     "bound": "valu" if tiled else "hbm",
-                     "achieved": (P * float(L_local) / (kms * 1e-3)) if tiled else (P * bpair / (kms * 1e-3) / 1e9),
-                     "peak": valu_peak if tiled else HBM_PEAK_GBS,
-                     "unit": "pair-sites/s" if tiled else "GB/s of the reference's 2 (L + G/8) bytes per pair",
-                     "regime_i_equivalent_GBps": P * bpair / (kms * 1e-3) / 1e9}
-            droof["frac"] = droof["achieved"] / droof["peak"]
-        traffic, traffic_src = pmc_traffic() if default_wl else (None, None)
+        if r["dist_kernel_ms"] is not None:
+            droof = distance_roofline(r["pair_form"], N, L_local, G_acc, P, *r["dist_kernel_ms"])
+        roof = sweep_roofline(r, default_wl or args.config in ("cfg3", "cfg4", "cfg4_shard8", "cfg5pop"))
+        rate = steps / r["dt"]
         out = {
-            "metric": "generations/sec", "value": (1 if strong else world) * args.steps / dt,
-            "whole_genome_generations_per_s": args.steps / dt, "core_sites_total": kw["core_size"],
-            "unit": ("generations/s (pop=%d, %d core sites in all, pan=%d)" if strong else
-                     "generations/s (pop=%d, %d core sites per GPU, pan=%d)") % (args.pop_size, args.core_size, args.pan_genes),
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": args.scaling,
+            "metric": "generations/sec", "value": (1 if strong else world) * rate,
+            "shard_generations_per_s": world * rate if not strong else None,
+            "whole_genome_generations_per_s": rate, "core_sites_total": kw["core_size"],
+            "unit": ("generations/s of the whole simulation (pop=%d, %d core sites in all, split over %d GPU(s), pan=%d)"
+                     % (kw["pop_size"], kw["core_size"], world, kw["pan_genes"])) if strong else
+                    ("generations/s (pop=%d, %d core sites, pan=%d)" % (kw["pop_size"], core_per_gpu, kw["pan_genes"])) if world == 1 else
+                    ("1.2 M-site SHARD-generations/s summed over %d ranks (weak scaling: pop=%d, %d core sites PER GPU, pan=%d; the "
+                     "simulation itself, %d sites, advances at whole_genome_generations_per_s)"
+                     % (world, kw["pop_size"], core_per_gpu, kw["pan_genes"], kw["core_size"])),
+            "n_gpus": world, "steps": steps, "warmup": warmup,
+            "ms_per_step": 1e3 * r["dt"] / steps, "higher_is_better": True, "scaling": "strong" if strong else "weak",
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-            "config": {"workload": ("BASELINE configs[1]: " if default_wl else "BASELINE configs[3]: " if args.pop_size == 65536
-                                    else "") + "--pop_size %d --core_size %d --pan_genes %d, seed 0, "
-                                   "HR_rate %g HGT_rate %g; core sites sharded %d-way"
-                                   % (args.pop_size, kw["core_size"], args.pan_genes, args.HR_rate,
-                                      args.HGT_rate, world),
+            "config": {"workload": "%s: --pop_size %d --core_size %d --pan_genes %d, seed 0, HR_rate %g HGT_rate %g; core sites "
+                                   "sharded %d-way" % (wl_label, kw["pop_size"], kw["core_size"], kw["pan_genes"], kw["HR_rate"],
+                                                       kw["HGT_rate"], world),
                        "parallelism": "site-shard x%d" % world},
-            "mpairs_per_s": P / dist_dt / 1e6,
-            "distance_ms": 1e3 * dist_dt,
-            # regime (ii), pairs compared from LDS tiles (HBM traffic ~ N*L per 32768 pairs,
-            # integer-VALU bound); secondary figure pair-sites/s over the whole distance phase
-            "distance_regime": "ii (LDS-tiled with reuse)" if tiled else "i (transposed 2-bit strings streamed per pair) / all-pairs tiles",
-            "pair_sites_per_s": P * float(kw["core_size"]) / dist_dt,
+            "mpairs_per_s": P / r["dist_dt"] / 1e6,
+            "distance_ms": 1e3 * r["dist_dt"],
+            "pair_sites_per_s": P * float(L_local if emu else kw["core_size"]) / r["dist_dt"],
             "distance_roofline": droof,
-            "host_half_ms": {"generations": host_n, "wait_for_device": host_wait / max(host_n, 1),
-                             "softmaxes": host_weights / max(host_n, 1), "parent_draw": host_draw / max(host_n, 1),
-                             "note": "per generation, inside ps_sim_run; hidden behind the previous sweep when shorter than it"},
-            "settle_sweep_ms": settle,
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                         "kernel": ("core_sweep_wave_kernel<gather,mutate,HR>" if args.pop_size <= 1024 else
-                                    "core_sweep_block_kernel<gather,mutate,HR>"), "avg_launch_ms": avg_ms,
-                         "algorithmic_bytes_per_launch": bytes_per_launch},
+            "host_half_ms": host_half(r),
+            "settle_sweep_ms": r["settle"],
+            "roofline": roof,
         }
+        if world > 1:
+            out["sweep_avg_ms_over_ranks"] = {"min": r["sweep_avg_ms_min_over_ranks"], "max": r["sweep_avg_ms_max_over_ranks"]}
         if world == 1 and not args.no_cpu_baseline and not emu:
-            out["cpu_baseline"] = cpu_baseline(kw, seed, (sim.range1, sim.range2))
+            out["cpu_baseline"] = cpu_baseline(kw, 0, r["pairs"], budget_s=20.0 if kw["pop_size"] <= 1000 else 30.0)
         if emu:
             out["emulated_shards"] = emu
             out["config"]["workload"] += "; THIS LINE: shard 0 of %d emulated on one GPU (%d sites)" % (emu, L_local)
+
+    # ---- the other BASELINE configurations, short runs on the same GPU (N = 1, default workload only)
+    if default_wl and world == 1 and not args.no_other_configs:
+        others = {}
+        for name in ("cfg3", "cfg5pop", "cfg4_shard8", "cfg4"):
+            okw, oP, oemu, osteps, owarm, olabel = CONFIGS[name]
+            try:
+                t0 = time.perf_counter()
+                ro = measure(ctx, dict(okw), oP, osteps, owarm, 0, oemu if oemu else 1)
+                others[name] = summary(ro, olabel + ": --pop_size %d --core_size %d --pan_genes %d --HR_rate %g --HGT_rate %g, P = %d"
+                                       % (okw["pop_size"], okw["core_size"], okw["pan_genes"], okw["HR_rate"], okw["HGT_rate"], oP),
+                                       emu=oemu)
+                others[name]["wall_s_incl_setup"] = time.perf_counter() - t0
+            except Exception as e:      # (a configuration that does not fit this GPU must not void the contract line)
+                others[name] = {"error": str(e)[:300]}
+        out["other_configs"] = others
+
+    # ---- the north-star's scaling workload at this world size: --pop_size 65536, 1.2 M core sites split over the ranks
+    if default_wl and world > 1:
+        okw, oP, _e, osteps, owarm, olabel = CONFIGS["cfg4"]
+        ro = measure(ctx, dict(okw), oP, 10, 2, rank, world)
+        if rank == 0:
+            ns = summary(ro, "BASELINE configs[3] / north_star scaling: --pop_size 65536, %d core sites split over %d ranks (strong "
+                             "scaling), P = %d" % (okw["core_size"], world, oP))
+            ns["n_gpus"] = world
+            ns["scaling"] = "strong"
+            ns["unit"] = "generations/s of the whole simulation"
+            ns["sweep"]["avg_launch_ms_over_ranks"] = {"min": ro["sweep_avg_ms_min_over_ranks"], "max": ro["sweep_avg_ms_max_over_ranks"]}
+            ns["collective_bytes_per_generation"] = 0
+            ns["collectives"] = ("none per generation (accessory matrix replicated, every rank draws the same parents); distance "
+                                 "phase: one all-reduce of %d u32 numerators" % oP)
+            out["north_star_scaling"] = ns
+
+    if rank == 0:
         print(json.dumps(out), flush=True)
-    sim.close()
     if world > 1:
         dist.destroy_process_group()
 

@@ -136,6 +136,18 @@ int ps_pairwise_distances(ps_population *p, uint64_t max_distances, const uint32
 int ps_pairwise_counts(ps_population *p, uint64_t max_distances, const uint32_t *range1,
                        const uint32_t *range2, uint32_t *out_a, uint32_t *out_b,
                        int out_is_device);
+/* Which kernel form the last core pair-count call of this handle ran in (bench.py prices the distance phase
+ * against the roofline of that form): */
+enum {
+    PS_PAIR_FORM_NONE = 0,
+    PS_PAIR_FORM_TILED2 = 1,     /* sampled pairs compared from LDS tiles of the 2-bit packed matrix (VALU bound) */
+    PS_PAIR_FORM_ALLPAIRS = 2,   /* all-pairs register tiles, xor + popcount on nibble strings (VALU bound), then lookup */
+    PS_PAIR_FORM_TILED4 = 3,     /* sampled pairs from LDS tiles of nibble strings */
+    PS_PAIR_FORM_ROWS = 4,       /* matrix transposed once to bit strings, two strings streamed per pair (HBM bound) */
+    PS_PAIR_FORM_SIMPLE = 5,     /* one thread per pair on the byte matrix (matrices with bytes above 15) */
+    PS_PAIR_FORM_ALLPAIRS_MFMA = 6 /* all-pairs one-hot X X^T on the i8 matrix cores (exact i32 counts), then lookup */
+};
+int ps_last_pair_form(ps_population *p);
 /* Population::gene_frequencies (population.rs:840-863): ncols + core_genes values */
 int ps_gene_frequencies(ps_population *p, double *out);
 /* Population::calc_gene_freq (population.rs:244-268) */
@@ -151,7 +163,8 @@ int ps_sync(ps_population *p);
  * "force_inline_sweep" (0/1: use the queue-free inline block sweep), "pair_mode" (core
  * distances: 0 = choose by cost, 1 = sampled-pair kernel, 2 = all-pairs tiles + lookup, 3 = sampled-pair
  * kernel in its nibble form even for one-hot matrices, 4 = transposed bit strings streamed per pair -- the
- * sampled form of populations too wide for an LDS tile), "pair_ranges" (site ranges of the tiled
+ * sampled form of populations too wide for an LDS tile, 5 = all-pairs xor + popcount tiles even for one-hot matrices,
+ * 6 = all pairs; one-hot matrices go to the i8 matrix cores in modes 0, 2 and 6), "pair_ranges" (site ranges of the tiled
  * sampled-pair kernels, 0 = choose; the 16-bit counter cap still applies),
  * "hgt_mode" (accessory recombination: 0 = choose, 1 = one atomic per event, 2 = two passes: bin
  * by recipient partition, OR in LDS images), "hgt_slices" (binned HGT: event slices, 0 = choose), "hgt_list_in_global" (0/1: donor gene lists in

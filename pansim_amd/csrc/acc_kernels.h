@@ -74,63 +74,66 @@ __global__ void acc_unpack_rows_kernel(const uint64_t *accI, uint8_t *rows, acc_
 }
 
 struct acc_step_args {
-    const uint64_t *srcG;
-    uint64_t *dstG, *dstI;
-    const uint32_t *idx;      // parents; may alias host-mapped pinned memory (read once per lane)
-    uint32_t *idx_out;        // if set, the gene-block-0 waves publish the parents in device memory
+    const uint64_t *srcI;     // individual-major rows of the parents' generation
+    uint64_t *dstI;           // rows of the children
+    const uint32_t *idx;      // parents; may alias host-mapped pinned memory (one broadcast read per wave)
+    uint32_t *idx_out;        // if set, the word-0 threads publish the parents in device memory
     acc_dims d;
     uint32_t gen, k0, k1;
     ps_acc_plan plan;
 };
 
-// Fused parent gather (population.rs:450-465) and gain/loss (population.rs:486-510):
-// lane = individual, loop over the 64 genes of the block; the new bits of 64
-// individuals are assembled with one ballot per gene.
-template <bool DO_GATHER, bool DO_MUT>
-__global__ void __launch_bounds__(64) acc_step_kernel(acc_step_args a)
+// 64-bit mask of the genes of row word gw that lie in [gb, ge)
+__device__ __forceinline__ uint64_t ps_word_range_mask(uint32_t gw, uint32_t gb, uint32_t ge)
 {
-    const uint32_t w = blockIdx.x, gw = blockIdx.y, lane = threadIdx.x;
+    const uint32_t lo = gw * 64u;
+    if (ge <= lo || gb >= lo + 64u || gb >= ge) return 0ull;
+    uint64_t m = ~0ull;
+    if (gb > lo) m &= ~0ull << (gb - lo);
+    if (ge < lo + 64u) m &= (1ull << (ge - lo)) - 1ull;
+    return m;
+}
+
+// Fused parent gather (population.rs:450-465) and gain/loss (population.rs:486-510) on the individual-major
+// view: child row i = parent row idx[i] (a contiguous GW-word copy) XOR the flip mask of (i, word).  Thread =
+// (individual, row word), words fastest: a wave reads / writes whole rows, and the 16 Philox calls of a word
+// (4 genes each, DESIGN.md 3.3: cell (i, g) flips iff word g mod 4 of Philox(g / 4, i, gen, 3) is below the
+// compartment's threshold) are independent.  Both compartments' "below threshold" masks are built for every
+// gene and selected with the word's compartment masks, so the code has no per-gene compartment tests.
+// (Round 2's form gathered one parent WORD of the gene-major view per (individual, gene) -- 8 bytes read per
+// bit at N = 65536, 0.63 ms for a 33 MB matrix -- and rebuilt the gene-major view with one ballot per gene;
+// that view is now rebuilt only when someone asks for gene frequencies.)
+template <bool DO_GATHER, bool DO_MUT>
+__global__ void __launch_bounds__(256) acc_step_rows_kernel(acc_step_args a)
+{
     const acc_dims d = a.d;
-    const uint32_t i = w * 64u + lane;
-    const bool valid = i < d.N;
-    const uint32_t p = (DO_GATHER && valid) ? a.idx[i] : (valid ? i : 0u);
-    if (DO_GATHER && a.idx_out && gw == 0 && valid) a.idx_out[i] = p;
-    const uint32_t pw = p >> 6, pb = p & 63u;
-    uint64_t rowword = 0;
-    ps_u4 rnd = { 0, 0, 0, 0 };
-    for (uint32_t b0 = 0; b0 < 64; b0 += 16) {
-    if (gw * 64u + b0 >= d.G) break;
-    // the parent words of 16 genes are fetched together (one dependent load per gene made the kernel
-    // 64 global-load latencies long: 0.13 ms beside the sweep)
-    uint64_t pword[16];
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (uint64_t)d.N * d.GW) return;
+    const uint32_t i = (uint32_t)(t / d.GW), gw = (uint32_t)(t % d.GW);
+    const uint32_t p = DO_GATHER ? a.idx[i] : i;
+    if (DO_GATHER && a.idx_out && gw == 0) a.idx_out[i] = p;
+    uint64_t word = a.srcI[(uint64_t)p * d.GW + gw];
+    if (DO_MUT) {
+        const uint32_t t0 = a.plan.n_comp > 0 ? a.plan.flip_thr[0] : 0u, t1 = a.plan.n_comp > 1 ? a.plan.flip_thr[1] : 0u;
+        const uint64_t m0 = a.plan.n_comp > 0 ? ps_word_range_mask(gw, a.plan.comp_begin[0], a.plan.comp_end[0]) : 0ull;
+        // (a gene in both ranges takes the LAST compartment's threshold, as the per-gene loop of round 2 did)
+        const uint64_t m1 = a.plan.n_comp > 1 ? ps_word_range_mask(gw, a.plan.comp_begin[1], a.plan.comp_end[1]) : 0ull;
+        uint32_t lt0[2] = { 0u, 0u }, lt1[2] = { 0u, 0u };
 #pragma unroll
-    for (uint32_t u = 0; u < 16; u++)
-        pword[u] = a.srcG[(uint64_t)min(gw * 64u + b0 + u, d.G - 1u) * d.W + pw];
+        for (uint32_t j = 0; j < 16u; j++) {
+            const ps_u4 r = ps_philox(gw * 16u + j, i, a.gen, PS_STREAM_ACC_MUT, a.k0, a.k1);
+            const uint32_t w[4] = { r.x, r.y, r.z, r.w };
 #pragma unroll
-    for (uint32_t u = 0; u < 16; u++) {
-        const uint32_t b = b0 + u;
-        const uint32_t g = gw * 64u + b;
-        if (g >= d.G) break;
-        uint32_t bit = (uint32_t)((pword[u] >> pb) & 1ull);
-        if (DO_MUT) {
-            if ((b & 3u) == 0u)
-                rnd = ps_philox(g >> 2, i, a.gen, PS_STREAM_ACC_MUT, a.k0, a.k1);
-            const uint32_t word = ((b & 3u) == 0u) ? rnd.x : ((b & 3u) == 1u) ? rnd.y
-                                  : ((b & 3u) == 2u) ? rnd.z : rnd.w;
-            uint32_t thr = 0;
-#pragma unroll
-            for (int c = 0; c < PS_MAX_COMP; c++)
-                if (c < a.plan.n_comp && g >= a.plan.comp_begin[c] && g < a.plan.comp_end[c])
-                    thr = a.plan.flip_thr[c];
-            bit ^= (word < thr) ? 1u : 0u;                 // population.rs:505
+            for (uint32_t k = 0; k < 4u; k++) {
+                const uint32_t b = 4u * j + k;
+                lt0[b >> 5] |= (w[k] < t0 ? 1u : 0u) << (b & 31u);          // population.rs:505
+                lt1[b >> 5] |= (w[k] < t1 ? 1u : 0u) << (b & 31u);
+            }
         }
-        bit = valid ? bit : 0u;
-        const uint64_t gword = __ballot(bit);
-        if (lane == 0) a.dstG[(uint64_t)g * d.W + w] = gword;
-        rowword |= (uint64_t)bit << b;
+        const uint64_t f0 = ((uint64_t)lt0[1] << 32) | lt0[0], f1 = ((uint64_t)lt1[1] << 32) | lt1[0];
+        word ^= (f1 & m1) | (f0 & m0 & ~m1);
     }
-    }
-    if (valid) a.dstI[(uint64_t)i * d.GW + gw] = rowword;
+    a.dstI[t] = word;
 }
 
 // ---------------------------------------------------------------------------

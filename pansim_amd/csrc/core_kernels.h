@@ -1479,6 +1479,142 @@ __global__ void __launch_bounds__(256) core_pair_counts_rows(const uint32_t *pac
     }
 }
 
+// ---------------------------------------------------------------------------
+// All-pairs Hamming numerators on the matrix cores (one-hot matrices, P > ~N^2 / 4: cfg5).
+// For one-hot alleles the number of MATCHING sites of two individuals is the inner product of their one-hot
+// expansions (4 x {0,1} per site), so all pairs are one X X^T contraction -- SURVEY 8(d) notes this form is
+// MFMA-eligible.  It is exact: v_mfma_i32_32x32x32_i8 multiplies i8 {0,1} and accumulates in i32 (<= L matches);
+// the reference's numerator (distances.rs:22-52: byte popcount, 2 per differing site) is 2 * (sites - matches).
+// Operands come from the individual-major 2-bit strings of core_packT_kernel (16 sites per dword; padding sites
+// hold code 0 for everybody, i.e. they match and drop out of sites - matches).
+//   * A workgroup of 8 waves owns a 256 x 256 tile of pairs (tiles with ti <= tj only) over a range of 128-site
+//     chunks; a wave owns 128 x 64 pairs: 4 + 2 operand fragments and 4 x 2 accumulator blocks of 32 x 32.
+//   * Lane l (r = l & 31, h = l >> 5) of a fragment loads 16 bytes = 64 sites of individual base + r: half h of
+//     the chunk.  Byte t of those 16 bytes (4 sites) is K-step t: a 256-entry table in LDS turns the byte into the
+//     lane's 16 i8 operand values (4 sites x 4 alleles) with ONE ds_read_b128 -- the K order (half, site, allele)
+//     is the same for both operands, which is all the contraction needs.
+//   * The table is stored 16 times, entry e of copy c at byte e * 256 + c * 16: a lane always reads copy
+//     c(lane), and the 16 lanes the LDS serves together (MI355X_MICROARCH.md, ds_read_b128 lane groups) have 16
+//     different copies = 16 different bank groups, so the data-dependent reads never conflict.  The address is
+//     one v_perm: (byte << 8) | (copy << 4).
+//   * Partial counts of a (tile, chunk range) are added to H with one atomic per pair; 32 consecutive lanes add to
+//     32 consecutive words.
+// ---------------------------------------------------------------------------
+typedef int ps_v4i __attribute__((ext_vector_type(4)));
+typedef int ps_v16i __attribute__((ext_vector_type(16)));
+#define PS_MF_TILE 256u          // individuals per workgroup tile side
+#define PS_MF_CHUNK_DW 8u        // dwords of a 2-bit string per chunk (128 sites)
+
+__device__ __forceinline__ ps_v4i ps_mf_lut_read(const uint8_t *lut, uint32_t raw, uint32_t colofs, uint32_t b)
+{
+    // address = (byte b of raw) << 8 | colofs  (colofs = copy * 16 < 256)
+    uint32_t addr;
+    switch (b) {
+    case 0: addr = __builtin_amdgcn_perm(raw, colofs, 0x0c0c0400u); break;
+    case 1: addr = __builtin_amdgcn_perm(raw, colofs, 0x0c0c0500u); break;
+    case 2: addr = __builtin_amdgcn_perm(raw, colofs, 0x0c0c0600u); break;
+    default: addr = __builtin_amdgcn_perm(raw, colofs, 0x0c0c0700u); break;
+    }
+    return *(const ps_v4i *)(lut + addr);
+}
+
+__global__ void __launch_bounds__(512) core_allpairs_mfma_kernel(const uint32_t *packT, uint32_t WT, uint32_t N, uint32_t *H,
+                                                                 uint32_t chunks_per_range, uint32_t n_chunks, uint32_t ntile)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t lut[];      // 256 entries x 16 copies x 16 bytes = 64 KB, at LDS offset 0
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // the table: entry e = four 2-bit codes c0..c3 (site k in bits 2k, 2k+1) -> dword k = 1 << (8 * ck)
+    for (uint32_t x = tid; x < 256u * 16u; x += 512u) {
+        const uint32_t e = x >> 4;
+        uint4 v;
+        v.x = 1u << (8u * (e & 3u));
+        v.y = 1u << (8u * ((e >> 2) & 3u));
+        v.z = 1u << (8u * ((e >> 4) & 3u));
+        v.w = 1u << (8u * ((e >> 6) & 3u));
+        *(uint4 *)(lut + (size_t)x * 16u) = v;       // x = e * 16 + copy
+    }
+    // copy of this lane: distinct inside each group of 16 lanes a ds_read_b128 serves in one pass
+    // ({0-3,12-15,20-27}, {4-11,16-19,28-31} and the same + 32)
+    const uint32_t l5 = lane & 31u;
+    const uint32_t copy = l5 < 4u ? l5 : l5 < 12u ? l5 - 4u : l5 < 20u ? l5 - 8u : l5 < 28u ? l5 - 12u : l5 - 16u;
+    const uint32_t colofs = copy << 4;
+    // tile pair ti <= tj, row by row
+    uint32_t ti = 0, rem = blockIdx.x;
+    while (rem >= ntile - ti) { rem -= ntile - ti; ti++; }
+    const uint32_t tj = ti + rem;
+    // wave (wi, wj) of the 2 x 4 arrangement: rows ti*256 + wi*128 .. +127, columns tj*256 + wj*64 .. +63
+    const uint32_t wi = wave >> 2, wj = wave & 3u;
+    const uint32_t r = lane & 31u, h = lane >> 5;
+    const uint32_t *src[6];
+#pragma unroll
+    for (uint32_t f = 0; f < 6u; f++) {
+        const uint32_t ind = f < 4u ? ti * PS_MF_TILE + wi * 128u + f * 32u + r : tj * PS_MF_TILE + wj * 64u + (f - 4u) * 32u + r;
+        src[f] = packT + (size_t)min(ind, N - 1u) * WT + h * 4u;      // (individuals past N repeat the last one; never stored)
+    }
+    ps_v16i acc[4][2];
+#pragma unroll
+    for (int a = 0; a < 4; a++)
+#pragma unroll
+        for (int b = 0; b < 2; b++)
+#pragma unroll
+            for (int v = 0; v < 16; v++) acc[a][b][v] = 0;
+    const uint32_t c_lo = blockIdx.y * chunks_per_range, c_hi = min(n_chunks, c_lo + chunks_per_range);
+    uint4 cur[6], nxt[6];
+    if (c_lo < c_hi) {
+#pragma unroll
+        for (uint32_t f = 0; f < 6u; f++) cur[f] = *(const uint4 *)(src[f] + (size_t)c_lo * PS_MF_CHUNK_DW);
+    }
+    __syncthreads();        // the table is complete
+    for (uint32_t c = c_lo; c < c_hi; c++) {
+        const uint32_t cn = min(c + 1u, c_hi - 1u);
+#pragma unroll
+        for (uint32_t f = 0; f < 6u; f++) nxt[f] = *(const uint4 *)(src[f] + (size_t)cn * PS_MF_CHUNK_DW);
+#pragma unroll
+        for (uint32_t t = 0; t < 16u; t++) {
+            ps_v4i op[6];
+#pragma unroll
+            for (uint32_t f = 0; f < 6u; f++) {
+                const uint32_t raw = (t >> 2) == 0u ? cur[f].x : (t >> 2) == 1u ? cur[f].y : (t >> 2) == 2u ? cur[f].z : cur[f].w;
+                op[f] = ps_mf_lut_read(lut, raw, colofs, t & 3u);
+            }
+#pragma unroll
+            for (int a = 0; a < 4; a++)
+#pragma unroll
+                for (int b = 0; b < 2; b++)
+                    acc[a][b] = __builtin_amdgcn_mfma_i32_32x32x32_i8(op[a], op[4 + b], acc[a][b], 0, 0, 0);
+        }
+#pragma unroll
+        for (uint32_t f = 0; f < 6u; f++) cur[f] = nxt[f];
+    }
+    if (c_lo >= c_hi) return;
+    // C layout of the 32 x 32 blocks (dtype independent): col = lane & 31, row = (v & 3) + 8 * (v >> 2) + 4 * (lane >> 5)
+    const uint32_t sites = (c_hi - c_lo) * PS_MF_CHUNK_DW * 16u;
+#pragma unroll
+    for (int a = 0; a < 4; a++)
+#pragma unroll
+        for (int b = 0; b < 2; b++) {
+            const uint32_t j = tj * PS_MF_TILE + wj * 64u + (uint32_t)b * 32u + r;
+#pragma unroll
+            for (int v = 0; v < 16; v++) {
+                const uint32_t i = ti * PS_MF_TILE + wi * 128u + (uint32_t)a * 32u + (uint32_t)((v & 3) + 8 * (v >> 2)) + 4u * h;
+                const uint32_t mism = sites - (uint32_t)acc[a][b][v];
+                if (i < N && j < N && mism) atomicAdd(&H[(size_t)i * N + j], 2u * mism);
+            }
+        }
+}
+
+// out[slot] = H[i][j] for the 256-tiles of core_allpairs_mfma_kernel (tiles ti <= tj were computed; a diagonal
+// tile holds both orders)
+__global__ void core_pair_lookup256_kernel(const uint32_t *H, uint32_t N, const uint32_t *r1, const uint32_t *r2,
+                                           const uint32_t *perm, uint64_t P, uint32_t *out)
+{
+    const uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= P) return;
+    const uint32_t i = r1[k], j = r2[k];
+    const bool fwd = (i >> 8) <= (j >> 8);
+    out[perm ? perm[k] : k] = fwd ? H[(size_t)i * N + j] : H[(size_t)j * N + i];
+}
+
 // generic form (any N, any byte values): one thread per pair, blockIdx.y splits the sites
 __global__ void __launch_bounds__(256) core_pair_counts_simple(
     const uint8_t *state, uint32_t pitch, uint32_t rows, const uint32_t *r1, const uint32_t *r2,

@@ -186,7 +186,8 @@ struct ps_population {
     uint64_t pack2_cap = 0;
     // accessory: bit-packed, two views, ping-pong
     acc_dims d{};
-    uint64_t *G[2] = { nullptr, nullptr };
+    uint64_t *G[2] = { nullptr, nullptr };   // gene-major view (G[0] only): rebuilt from the rows when g_valid is false
+    bool g_valid = false;
     uint64_t *I[2] = { nullptr, nullptr };
     uint32_t *d_ptab[PS_MAX_COMP] = {};  // Poisson threshold tables of the HGT event counts (ps_set_rates)
     uint32_t ptab_kmin[PS_MAX_COMP] = {}, ptab_len[PS_MAX_COMP] = {};
@@ -211,6 +212,7 @@ struct ps_population {
     double *d_Dt = nullptr;          // all-pairs Jaccard distances (D-avg), N x N
     uint64_t H_cap = 0;
     int pair_mode = 0;               // 0 auto, 1 sampled kernel, 2 all-pairs kernel (tuning/tests)
+    int last_pair_form = 0;          // kernel form of the last core pair-count call (ps_last_pair_form)
     uint32_t pair_ranges = 0;        // tests: site ranges of the tiled sampled-pair kernels (0 = choose); the 16-bit cap still applies
     int hgt_mode = 0;                // 0 auto, 1 one atomic per event, 2 binned by recipient partition + LDS images
     void *d_pairs = nullptr;         // sorted r1 | r2 | perm | outA | outB | tstart | tcount
@@ -312,10 +314,8 @@ static int pop_create_impl(const ps_config *cfg, const uint8_t *init_vec, ps_pop
         p->d.GW = (uint32_t)((C + 63) / 64);
         const uint64_t nG = std::max<uint64_t>((uint64_t)p->d.G * p->d.W, 1) * 8;
         const uint64_t nI = std::max<uint64_t>((uint64_t)p->d.N * p->d.GW, 1) * 8;
-        for (int k = 0; k < 2; k++) {
-            HIPCHK(hipMalloc(&p->G[k], nG));
-            HIPCHK(hipMalloc(&p->I[k], nI));
-        }
+        HIPCHK(hipMalloc(&p->G[0], nG));
+        for (int k = 0; k < 2; k++) HIPCHK(hipMalloc(&p->I[k], nI));
         if (C > 65536) return ps_fail(PS_ERR_INVALID, "at most 65536 accessory genes are supported");
         // events per (compartment, donor) + the dynamic item counter of the HGT kernel
         HIPCHK(hipMalloc(&p->cnt, (std::max<uint64_t>(N, 1) * PS_MAX_COMP + 64) * sizeof(uint32_t)));
@@ -326,6 +326,7 @@ static int pop_create_impl(const ps_config *cfg, const uint8_t *init_vec, ps_pop
         if (total)
             acc_init_kernel<<<(uint32_t)((total + 255) / 256), 256, 0, p->stream>>>(p->G[0], p->I[0],
                                                                                 d_vec, p->d);
+        p->g_valid = true;
     }
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(p->stream));
@@ -412,7 +413,7 @@ extern "C" int ps_set_tuning(ps_population *p, const char *key, int64_t value)
         if (value < 0 || value > 2) return ps_fail(PS_ERR_INVALID, "hgt_mode must be 0 (auto), 1 (one atomic per event) or 2 (binned by recipient partition, two passes)");
         p->hgt_mode = (int)value;
     } else if (k == "pair_mode") {
-        if (value < 0 || value > 4) return ps_fail(PS_ERR_INVALID, "pair_mode must be 0 (auto), 1 (sampled), 2 (all pairs), 3 (sampled, nibble form even for one-hot matrices) or 4 (transposed bit strings, streamed per pair)");
+        if (value < 0 || value > 6) return ps_fail(PS_ERR_INVALID, "pair_mode must be 0 (auto), 1 (sampled), 2 (all pairs), 3 (sampled, nibble form even for one-hot matrices), 4 (transposed bit strings, streamed per pair), 5 (all pairs, xor + popcount tiles even for one-hot matrices) or 6 (all pairs, matrix cores when the matrix is one-hot)");
         p->pair_mode = (int)value;
     } else if (k == "pair_ranges") {
         if (value < 0 || value > 65535) return ps_fail(PS_ERR_INVALID, "pair_ranges must be 0 (choose)..65535");
@@ -475,8 +476,7 @@ extern "C" int ps_load_matrix(ps_population *p, const uint8_t *rows)
         const uint64_t nI = (uint64_t)p->d.N * p->d.GW;
         acc_pack_rows_kernel<<<(uint32_t)((nI + 255) / 256), 256, 0, p->stream>>>(d_rows, p->I[p->cur],
                                                                               p->d);
-        dim3 grid(p->d.W, p->d.GW);
-        acc_i_to_g_kernel<<<grid, 64, 0, p->stream>>>(p->I[p->cur], p->G[p->cur], p->d);
+        p->g_valid = false;
     }
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(p->stream));
@@ -757,8 +757,7 @@ static int launch_acc_step(ps_population *p, const uint32_t *d_idx, uint32_t gen
 {
     if (p->d.G == 0) return PS_OK;
     acc_step_args a;
-    a.srcG = p->G[p->cur];
-    a.dstG = p->G[1 - p->cur];
+    a.srcI = p->I[p->cur];
     a.dstI = p->I[1 - p->cur];
     a.idx = d_idx;
     a.idx_out = idx_out;
@@ -767,12 +766,24 @@ static int launch_acc_step(ps_population *p, const uint32_t *d_idx, uint32_t gen
     a.k0 = (uint32_t)p->cfg.seed;
     a.k1 = (uint32_t)(p->cfg.seed >> 32);
     a.plan = p->aplan;
-    dim3 grid(p->d.W, p->d.GW);
-    if (ga && mu) acc_step_kernel<true, true><<<grid, 64, 0, st>>>(a);
-    else if (ga) acc_step_kernel<true, false><<<grid, 64, 0, st>>>(a);
-    else acc_step_kernel<false, true><<<grid, 64, 0, st>>>(a);
+    const uint64_t threads = (uint64_t)p->d.N * p->d.GW;
+    const uint32_t grid = (uint32_t)((threads + 255) / 256);
+    if (ga && mu) acc_step_rows_kernel<true, true><<<grid, 256, 0, st>>>(a);
+    else if (ga) acc_step_rows_kernel<true, false><<<grid, 256, 0, st>>>(a);
+    else acc_step_rows_kernel<false, true><<<grid, 256, 0, st>>>(a);
     HIPCHK(hipGetLastError());
     p->cur = 1 - p->cur;
+    p->g_valid = false;
+    return PS_OK;
+}
+
+// the gene-major view (one ballot per gene word) is only needed for gene frequencies: rebuilt on demand
+static int ensure_gene_major(ps_population *p, hipStream_t st)
+{
+    if (p->g_valid || p->d.G == 0) return PS_OK;
+    acc_i_to_g_kernel<<<dim3(p->d.W, p->d.GW), 64, 0, st>>>(p->I[p->cur], p->G[0], p->d);
+    HIPCHK(hipGetLastError());
+    p->g_valid = true;
     return PS_OK;
 }
 
@@ -919,8 +930,7 @@ static int launch_acc_hgt(ps_population *p, uint32_t gen, hipStream_t st, hipEve
             HIPCHK(hipFuncSetAttribute((const void *)acc_hgt_donor_wave_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn_lds));
         hipLaunchKernelGGL(acc_hgt_donor_wave_kernel, dim3(grid), dim3(64), dyn_lds, st, a);
     }
-    // rebuild the gene-major view from the individual-major one (one ballot per gene word)
-    acc_i_to_g_kernel<<<dim3(p->d.W, p->d.GW), 64, 0, st>>>(p->I[p->cur], p->G[p->cur], p->d);
+    p->g_valid = false;       // only the individual-major view is edited (ensure_gene_major)
     HIPCHK(hipGetLastError());
     return PS_OK;
 }
@@ -1323,13 +1333,17 @@ static int pair_counts_device(ps_population *p, uint64_t P, const uint32_t *d_r1
         // Populations too wide for an LDS tile (W == 0): the transposed form (pack once, stream two bit
         // strings per pair: ~1.25 * N * L + P * L / 2 (nibbles: P * L) bytes at ~5 TB/s) against the
         // all-pairs tiles (~0.9e15 pair-sites/s, N = 8192: 45 ms; crossover there at P ~ 350 k)
+        // (all-pairs on the matrix cores for one-hot matrices: ~3.5e14 pair-sites/s; the xor + popcount tiles: 1.3e14)
+        const bool mfma_ok = p->onehot_safe && p->pair_mode != 5;
         const double t_rows = (1.25 * (double)N * rows + (double)P * rows * (p->onehot_safe ? 0.5 : 1.0)) / 5.0e12;
-        const double t_all = all_pairs * rows / 0.9e15;
-        const bool use_rows = p->nibble_safe && p->pair_mode != 2
+        const double t_all = all_pairs * rows / (mfma_ok ? 3.5e14 : 1.3e14);
+        const bool force_all = p->pair_mode == 2 || p->pair_mode == 5 || p->pair_mode == 6;
+        const bool use_rows = p->nibble_safe && !force_all
                               && (p->pair_mode == 4 || (!W && (p->pair_mode == 1 || p->pair_mode == 3 || !all_fits || t_rows < t_all)));
         const bool use_all = !use_rows && all_fits && p->pair_mode != 1 && p->pair_mode != 3
-                             && (p->pair_mode == 2 || (double)P * 2.0 > all_pairs || !W);
+                             && (force_all || (double)P * 2.0 > all_pairs || !W);
         if (use_rows) {
+            p->last_pair_form = PS_PAIR_FORM_ROWS;
             const bool nib = !p->onehot_safe;
             const uint32_t spw = nib ? 8u : 16u;
             const uint32_t WT = ((rows + spw - 1u) / spw + PS_PT_WB - 1u) / PS_PT_WB * PS_PT_WB;
@@ -1353,7 +1367,43 @@ static int pair_counts_device(ps_population *p, uint64_t P, const uint32_t *d_r1
                 core_pair_counts_rows<false><<<blocks, 256, 0, st>>>(p->d_pack2, WT, d_r1, d_r2, d_perm, P, d_a);
             }
         } else
+        if (use_all && mfma_ok) {
+            // one-hot matrix: X X^T on the i8 matrix cores from the individual-major 2-bit strings
+            p->last_pair_form = PS_PAIR_FORM_ALLPAIRS_MFMA;
+            const uint32_t WT = ((rows + 15u) / 16u + PS_PT_WB - 1u) / PS_PT_WB * PS_PT_WB;
+            const uint64_t need = (uint64_t)N * WT;
+            if (p->pack2_cap < need) {
+                if (p->d_pack2) HIPCHK(hipFree(p->d_pack2));
+                p->d_pack2 = nullptr;
+                p->pack2_cap = 0;
+                HIPCHK(hipMalloc(&p->d_pack2, need * sizeof(uint32_t)));
+                p->pack2_cap = need;
+            }
+            const uint64_t ptiles = (uint64_t)((N + PS_PT_IB - 1u) / PS_PT_IB) * (WT / PS_PT_WB);
+            if (ptiles > 0x7FFFFFFFull) return ps_fail(PS_ERR_INVALID, "matrix too large for the transposed distance form");
+            core_packT_kernel<false><<<dim3((uint32_t)ptiles), 256, 0, st>>>(p->state, N, p->pitch, rows, p->d_pack2, WT);
+            if (p->H_cap < (uint64_t)N * N) {
+                if (p->d_H) HIPCHK(hipFree(p->d_H));
+                p->d_H = nullptr;
+                p->H_cap = 0;
+                HIPCHK(hipMalloc(&p->d_H, (uint64_t)N * N * sizeof(uint32_t)));
+                p->H_cap = (uint64_t)N * N;
+            }
+            HIPCHK(hipMemsetAsync(p->d_H, 0, (uint64_t)N * N * sizeof(uint32_t), st));
+            const uint32_t ntile = (N + PS_MF_TILE - 1u) / PS_MF_TILE;
+            const uint32_t tile_pairs = ntile * (ntile + 1u) / 2u;
+            const uint32_t n_chunks = WT / PS_MF_CHUNK_DW;
+            // enough (tile, chunk range) workgroups to fill the chip several times over: one 8-wave workgroup per CU
+            uint32_t ranges = std::max(1u, std::min(n_chunks, (256u * 6u + tile_pairs - 1u) / tile_pairs));
+            const uint32_t cpr = (n_chunks + ranges - 1u) / ranges;
+            ranges = (n_chunks + cpr - 1u) / cpr;
+            const uint32_t lds = 256u * 16u * 16u;
+            HIPCHK(hipFuncSetAttribute((const void *)core_allpairs_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL(core_allpairs_mfma_kernel, dim3(tile_pairs, ranges), dim3(512), lds, st, p->d_pack2, WT, N, p->d_H, cpr, n_chunks, ntile);
+            core_pair_lookup256_kernel<<<(uint32_t)((P + 255) / 256), 256, 0, st>>>(p->d_H, N, d_r1, d_r2, d_perm, P, d_a);
+        } else
         if (use_all) {
+            p->last_pair_form = PS_PAIR_FORM_ALLPAIRS;
             const uint32_t WA = 32u, ntile = (N + 127u) / 128u;
             const uint32_t lds = 2u * 128u * ((WA >> 2) + 1u) * 16u;
             if (p->H_cap < (uint64_t)N * N) {
@@ -1374,6 +1424,7 @@ static int pair_counts_device(ps_population *p, uint64_t P, const uint32_t *d_r1
             core_pair_lookup_kernel<<<(uint32_t)((P + 255) / 256), 256, 0, st>>>(p->d_H, N, d_r1, d_r2, d_perm, P, d_a);
         } else if (p->onehot_safe && W && p->pair_mode != 3) {
             // one-hot matrix: pack it once at 2 bits per site, then compare from packed tiles
+            p->last_pair_form = PS_PAIR_FORM_TILED2;
             constexpr int A = 32;
             constexpr uint32_t PT = 1024;
             const uint32_t n_tiles = (rows + W * 16 - 1) / (W * 16);
@@ -1406,6 +1457,7 @@ static int pair_counts_device(ps_population *p, uint64_t P, const uint32_t *d_r1
                                (uint32_t)P, d_r1 + 5 * P, d_r1 + 6 * P, p->pair_threads, part, W, tpr);
             core_pair_reduce_kernel<<<(uint32_t)((P + 255) / 256), 256, 0, st>>>(part, ranges, (uint32_t)P, d_perm, d_a);
         } else if (p->nibble_safe && W) {
+            p->last_pair_form = PS_PAIR_FORM_TILED4;
             constexpr int A = 32;
             constexpr uint32_t PT = 1024;
             const uint32_t lds = N * ((W >> 2) + 1u) * 16u;
@@ -1429,6 +1481,7 @@ static int pair_counts_device(ps_population *p, uint64_t P, const uint32_t *d_r1
                                rows, d_r1, d_r2, (uint32_t)P, d_r1 + 5 * P, d_r1 + 6 * P, p->pair_threads, part, W, tpr);
             core_pair_reduce_kernel<<<(uint32_t)((P + 255) / 256), 256, 0, st>>>(part, ranges, (uint32_t)P, d_perm, d_a);
         } else {
+            p->last_pair_form = PS_PAIR_FORM_SIMPLE;
             const uint32_t slices = std::max(1u, std::min(rows, 64u));
             const uint32_t rps = (rows + slices - 1) / slices;
             dim3 grid((uint32_t)((P + 255) / 256), (rows + rps - 1) / rps);
@@ -1465,6 +1518,8 @@ extern "C" int ps_pairwise_counts(ps_population *p, uint64_t P, const uint32_t *
     HIPCHK(hipStreamSynchronize(p->stream));
     return PS_OK;
 }
+
+extern "C" int ps_last_pair_form(ps_population *p) { return p ? p->last_pair_form : 0; }
 
 extern "C" int ps_pairwise_distances(ps_population *p, uint64_t P, const uint32_t *range1,
                                      const uint32_t *range2, double *out)
@@ -1510,7 +1565,8 @@ extern "C" int ps_gene_frequencies(ps_population *p, double *out)
     if (G) {
         uint32_t *d_c = nullptr;
         HIPCHK(hipMalloc(&d_c, G * sizeof(uint32_t)));
-        acc_gene_counts_kernel<<<(uint32_t)((G + 255) / 256), 256, 0, p->stream>>>(p->G[p->cur], d_c, p->d);
+        PSCHK(ensure_gene_major(p, p->stream));
+        acc_gene_counts_kernel<<<(uint32_t)((G + 255) / 256), 256, 0, p->stream>>>(p->G[0], d_c, p->d);
         HIPCHK(hipGetLastError());
         std::vector<uint32_t> c(G);
         HIPCHK(hipMemcpyAsync(c.data(), d_c, G * 4, hipMemcpyDeviceToHost, p->stream));

@@ -229,6 +229,10 @@ class Population:
         check(self._lib.ps_pairwise_counts(self._h, r1.size, r1, r2, C.c_void_p(out_a_ptr),
                                            C.c_void_p(out_b_ptr), 1))
 
+    def last_pair_form(self):
+        """kernel form of the last core pair-count call (include/pansim_hip.h, PS_PAIR_FORM_*)"""
+        return int(self._lib.ps_last_pair_form(self._h))
+
     def gene_frequencies(self):
         """population.rs:840-863"""
         out = np.zeros(self.ncols + self.core_genes, np.float64)
