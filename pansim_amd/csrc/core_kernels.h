@@ -1515,7 +1515,9 @@ __device__ __forceinline__ ps_v4i ps_mf_lut_read(const uint8_t *lut, uint32_t ra
     case 2: addr = __builtin_amdgcn_perm(raw, colofs, 0x0c0c0600u); break;
     default: addr = __builtin_amdgcn_perm(raw, colofs, 0x0c0c0700u); break;
     }
-    return *(const ps_v4i *)(lut + addr);
+    // (the table sits at LDS offset 0: the 32-bit value IS the LDS address; going through `lut + addr` costs a v_add of 0)
+    (void)lut;
+    return *(const __attribute__((address_space(3))) ps_v4i *)(uintptr_t)addr;
 }
 
 __global__ void __launch_bounds__(512) core_allpairs_mfma_kernel(const uint32_t *packT, uint32_t WT, uint32_t N, uint32_t *H,
@@ -1559,34 +1561,43 @@ __global__ void __launch_bounds__(512) core_allpairs_mfma_kernel(const uint32_t 
 #pragma unroll
             for (int v = 0; v < 16; v++) acc[a][b][v] = 0;
     const uint32_t c_lo = blockIdx.y * chunks_per_range, c_hi = min(n_chunks, c_lo + chunks_per_range);
+    if (c_lo >= c_hi) return;       // (wave-uniform: the whole workgroup leaves)
     uint4 cur[6], nxt[6];
-    if (c_lo < c_hi) {
 #pragma unroll
-        for (uint32_t f = 0; f < 6u; f++) cur[f] = *(const uint4 *)(src[f] + (size_t)c_lo * PS_MF_CHUNK_DW);
-    }
+    for (uint32_t f = 0; f < 6u; f++) cur[f] = *(const uint4 *)(src[f] + (size_t)c_lo * PS_MF_CHUNK_DW);
     __syncthreads();        // the table is complete
+    // Software pipeline over the K-steps: the six table reads of step t + 1 are issued before the eight MFMAs of
+    // step t (two operand sets, ping-pong by the parity of t; 16 steps per chunk, so the parity carries over the
+    // chunk loop), and the 16-byte loads of the next chunk are in flight during the whole chunk.
+    ps_v4i opA[6], opB[6];
+#pragma unroll
+    for (uint32_t f = 0; f < 6u; f++) opA[f] = ps_mf_lut_read(lut, cur[f].x, colofs, 0u);
     for (uint32_t c = c_lo; c < c_hi; c++) {
         const uint32_t cn = min(c + 1u, c_hi - 1u);
 #pragma unroll
         for (uint32_t f = 0; f < 6u; f++) nxt[f] = *(const uint4 *)(src[f] + (size_t)cn * PS_MF_CHUNK_DW);
 #pragma unroll
         for (uint32_t t = 0; t < 16u; t++) {
-            ps_v4i op[6];
+            const uint32_t tn = (t + 1u) & 15u;
 #pragma unroll
             for (uint32_t f = 0; f < 6u; f++) {
-                const uint32_t raw = (t >> 2) == 0u ? cur[f].x : (t >> 2) == 1u ? cur[f].y : (t >> 2) == 2u ? cur[f].z : cur[f].w;
-                op[f] = ps_mf_lut_read(lut, raw, colofs, t & 3u);
+                const uint4 &w = (t == 15u) ? nxt[f] : cur[f];
+                const uint32_t raw = (tn >> 2) == 0u ? w.x : (tn >> 2) == 1u ? w.y : (tn >> 2) == 2u ? w.z : w.w;
+                if (t & 1u) opA[f] = ps_mf_lut_read(lut, raw, colofs, tn & 3u);
+                else opB[f] = ps_mf_lut_read(lut, raw, colofs, tn & 3u);
             }
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int a = 0; a < 4; a++)
 #pragma unroll
                 for (int b = 0; b < 2; b++)
-                    acc[a][b] = __builtin_amdgcn_mfma_i32_32x32x32_i8(op[a], op[4 + b], acc[a][b], 0, 0, 0);
+                    acc[a][b] = (t & 1u) ? __builtin_amdgcn_mfma_i32_32x32x32_i8(opB[a], opB[4 + b], acc[a][b], 0, 0, 0)
+                                         : __builtin_amdgcn_mfma_i32_32x32x32_i8(opA[a], opA[4 + b], acc[a][b], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
 #pragma unroll
         for (uint32_t f = 0; f < 6u; f++) cur[f] = nxt[f];
     }
-    if (c_lo >= c_hi) return;
     // C layout of the 32 x 32 blocks (dtype independent): col = lane & 31, row = (v & 3) + 8 * (v >> 2) + 4 * (lane >> 5)
     const uint32_t sites = (c_hi - c_lo) * PS_MF_CHUNK_DW * 16u;
 #pragma unroll

@@ -279,12 +279,45 @@ def test_pairwise_core_kernels_agree(pa, orc, N, L, P):
     m = _rand_core(rng, N, L)
     r1, r2 = orc.sample_pairs(5, N, P)
     want = orc.pairwise_hamming_counts(m, 0, L, r1, r2)
-    for mode in (1, 2, 3):
+    for mode in (1, 2, 3, 5, 6):
         pop = pa.Population(N, L, 4, True, 0.0, 0, 0)
         pop.set_tuning("pair_mode", mode)
         pop.load_matrix(m)
         assert np.array_equal(pop.pairwise_counts(r1, r2)[0], want)
+        assert pop.last_pair_form() == {1: 1, 2: 6, 3: 3, 5: 2, 6: 6}[mode]
         pop.close()
+
+
+@pytest.mark.parametrize("N,L", [(2, 1), (33, 130), (257, 517), (300, 4100), (700, 9000), (1030, 2500)])
+def test_allpairs_matrix_core_form(pa, orc, N, L):
+    # the i8 MFMA all-pairs form (one-hot X X^T, population.rs:787-837 / distances.rs:22-52): every ordered pair
+    # (i, j) incl. i == j and both orders, populations and site counts that are not multiples of the 256-tiles /
+    # 128-site chunks, rows that differ in a structured (asymmetric) way so that a row <-> column swap or a wrong
+    # accumulator row map shows
+    rng = np.random.default_rng(N * 31 + L)
+    m = _rand_core(rng, N, L)
+    for i in range(N):                       # individual i agrees with individual 0 on its first (13 i) % L sites
+        k = (13 * i) % (L + 1)
+        m[i, :k] = m[0, :k]
+    ii, jj = np.meshgrid(np.arange(N, dtype=np.uint32), np.arange(N, dtype=np.uint32), indexing="ij")
+    r1, r2 = ii.ravel(), jj.ravel()
+    if r1.size > 300000:
+        sel = rng.choice(r1.size, 300000, replace=False)
+        r1, r2 = r1[sel], r2[sel]
+    want = orc.pairwise_hamming_counts(m, 0, L, r1, r2)
+    pop = pa.Population(N, L, 4, True, 0.0, 0, 0)
+    pop.set_tuning("pair_mode", 6)
+    pop.load_matrix(m)
+    (got,) = pop.pairwise_counts(np.ascontiguousarray(r1), np.ascontiguousarray(r2))
+    assert pop.last_pair_form() == 6
+    assert np.array_equal(got, want)
+    # a matrix that is not one-hot falls back to the xor + popcount tiles
+    m[0, 0] = 3
+    pop.load_matrix(m)
+    (got,) = pop.pairwise_counts(np.ascontiguousarray(r1), np.ascontiguousarray(r2))
+    assert pop.last_pair_form() == 2
+    assert np.array_equal(got, orc.pairwise_hamming_counts(m, 0, L, r1, r2))
+    pop.close()
 
 
 def test_pairwise_core_arbitrary_bytes(pa, orc):
