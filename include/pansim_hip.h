@@ -169,6 +169,8 @@ int ps_sync(ps_population *p);
  * "hgt_mode" (accessory recombination: 0 = choose, 1 = one atomic per event, 2 = two passes: bin
  * by recipient partition, OR in LDS images), "hgt_slices" (binned HGT: event slices, 0 = choose), "hgt_list_in_global" (0/1: donor gene lists in
  * global scratch instead of LDS; "hgt_bin_list_in_global": the same for the bin pass of the binned form),
+ * "sweep_out_of_place" (core sweeps: -1 = choose, 0 = update the matrix in place, 1 = write the new generation to a second
+ * buffer that then swaps roles with the first, 2 = the same with nontemporal row loads and stores; results are identical),
  * "lds_limit" (bytes of LDS a workgroup may use), "block_waves" (block sweep: waves per
  * workgroup, 0 = choose), "block_batch" (block sweep: segments per wave batch, 0 = choose, 2 or 4),
  * "no_block_preload" (block sweep: parent indices re-read per batch). */

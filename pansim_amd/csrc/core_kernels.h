@@ -16,7 +16,8 @@
 #include <type_traits>
 
 struct core_sweep_args {
-    uint8_t *state;
+    uint8_t *state;        // the generation that is read
+    uint8_t *out;          // where the new generation is written: == state (in place) or the second buffer (out of place)
     const uint32_t *idx;   // parents (device), DO_GATHER only
     const uint32_t *idxT;  // idxT[k * cpr + chunk] = idx[16 * chunk + k] (block sweep)
     uint32_t N, pitch, cpr, rows;
@@ -27,7 +28,27 @@ struct core_sweep_args {
     unsigned long long *stamps; // diagnostic builds (PS_STAMP) only
     uint32_t *work_ctr;        // wave sweep: 2 x 8 chunk counters, 128 bytes apart
     uint32_t launch_parity;    // which counter set this launch uses
+    uint32_t nt;               // out-of-place form: nontemporal row loads / stores (every byte is touched once per launch)
 };
+
+typedef uint32_t ps_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint4 ps_load_row16(const uint8_t *p, bool nt)
+{
+    if (nt) {
+        const ps_u32x4 v = __builtin_nontemporal_load((const ps_u32x4 *)p);      // global_load_dwordx4 ... nt
+        return make_uint4(v.x, v.y, v.z, v.w);
+    }
+    return *(const uint4 *)p;
+}
+__device__ __forceinline__ void ps_store_row16(uint8_t *p, const uint4 &v, bool nt)
+{
+    if (nt) {
+        ps_u32x4 w = { v.x, v.y, v.z, v.w };
+        __builtin_nontemporal_store(w, (ps_u32x4 *)p);
+    } else {
+        *(uint4 *)p = v;
+    }
+}
 
 __device__ __forceinline__ void ps_set_byte(uint32_t (&w)[4], uint32_t k, uint32_t v)
 {
@@ -231,7 +252,7 @@ __device__ __forceinline__ uint4 ps_strip(uint4 v, bool on)
 // so a queue entry is just (bit position | lane << 5 | row << 11) -- one v_add per pushed candidate instead
 // of the v_perm byte extraction -- and the dense pass, with every lane busy, decodes the cell address and
 // reads the byte back from the row.  The nibbles are stripped when the row leaves LDS.
-template <uint32_t PS_ROWS, bool DO_GATHER, bool DO_MUT, bool DO_HR, bool STASH>
+template <uint32_t PS_ROWS, bool DO_GATHER, bool DO_MUT, bool DO_HR, bool STASH, bool NT = false>
 __global__ void __launch_bounds__(256, PS_ROWS >= 4 ? 6 : 8) core_sweep_wave_kernel(core_sweep_args a)
 {
 #ifdef PS_STAMP
@@ -306,7 +327,7 @@ __global__ void __launch_bounds__(256, PS_ROWS >= 4 ? 6 : 8) core_sweep_wave_ker
         uint4 v[PS_ROWS];
 #pragma unroll
         for (uint32_t rr = 0; rr < PS_ROWS; rr++)
-            v[rr] = *(const uint4 *)(a.state + (size_t)min(r0 + rr, a.rows - 1u) * a.pitch + ld_off);
+            v[rr] = ps_load_row16(a.state + (size_t)min(r0 + rr, a.rows - 1u) * a.pitch + ld_off, NT);
         if (DO_GATHER) {
 #pragma unroll
             for (uint32_t rr = 0; rr < PS_ROWS; rr++) *(uint4 *)(rowbuf + rr * 1024u + i0) = v[rr];
@@ -471,7 +492,7 @@ __global__ void __launch_bounds__(256, PS_ROWS >= 4 ? 6 : 8) core_sweep_wave_ker
                 if (rr < nr) {
                     uint4 o = (DO_GATHER || events) ? *(const uint4 *)(rowbuf + rr * 1024u + i0) : v[rr];
                     if (STASH && events) { o.x &= 0x0F0F0F0Fu; o.y &= 0x0F0F0F0Fu; o.z &= 0x0F0F0F0Fu; o.w &= 0x0F0F0F0Fu; }
-                    *(uint4 *)(a.state + (size_t)(r0 + rr) * a.pitch + i0) = o;
+                    ps_store_row16(a.out + (size_t)(r0 + rr) * a.pitch + i0, o, NT);
                 }
             }
         }
@@ -830,7 +851,7 @@ __global__ void __launch_bounds__(1024) core_sweep_block_kernel(core_sweep_args 
             if (po3 < nbytes_next) *(uint4 *)(stage + po3) = pf3;
         }
         {
-            uint8_t *dstg = a.state + (size_t)r0 * a.pitch;
+            uint8_t *dstg = a.out + (size_t)r0 * a.pitch;
             const uint32_t nbytes = nr * a.pitch;
             if (pipelined) {
                 // at most PS_PF pieces per thread: the LDS reads together, then the stores

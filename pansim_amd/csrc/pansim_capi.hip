@@ -176,6 +176,10 @@ struct ps_population {
     bool rates_set = false;
     // core: site-major u8
     uint8_t *state = nullptr;
+    uint8_t *state2 = nullptr;       // second buffer of the out-of-place sweep (allocated at its first launch)
+    int sweep_oop = -1;              // 0 = in place, 1 = out of place (state <-> state2 alternate), 2 = the same with nontemporal row
+                                     // loads / stores, -1 = choose: 2 for the wave-per-row sweep (N <= 1024: at most 1 KiB x L more
+                                     // memory; measured -2 % at cfg2, -9 % at cfg3), 0 for the block sweep (no gain at N = 65536)
     uint32_t pitch = 0, cpr = 0;
     ps_core_plan cplan{};
     bool nibble_safe = true;
@@ -244,7 +248,7 @@ extern "C" void ps_population_destroy(ps_population *p)
     if (!p) return;
     (void)hipSetDevice(p->device);
     if (p->stream) (void)hipStreamSynchronize(p->stream);
-    void *ptrs[] = { p->state, p->G[0], p->G[1], p->I[0], p->I[1], p->d_ptab[0], p->d_ptab[1], p->hgt_scratch, p->cnt, p->d_idx, p->d_idxT, p->d_work,
+    void *ptrs[] = { p->state, p->state2, p->G[0], p->G[1], p->I[0], p->I[1], p->d_ptab[0], p->d_ptab[1], p->hgt_scratch, p->cnt, p->d_idx, p->d_idxT, p->d_work,
                      p->d_log1p, p->d_num_genes, p->d_logw, p->d_pairs, p->d_H, p->d_Dt, p->d_pack2, p->d_pair_part };
     for (void *q : ptrs)
         if (q) (void)hipFree(q);
@@ -276,6 +280,7 @@ static int pop_create_impl(const ps_config *cfg, const uint8_t *init_vec, ps_pop
         if (v >= 1 && v <= 8) p->sweep_blocks_per_cu = (uint32_t)v;
     }
     if (const char *e = getenv("PANSIM_HGT_MODE")) p->hgt_mode = atoi(e);
+    if (const char *e = getenv("PANSIM_SWEEP_OOP")) p->sweep_oop = std::max(-1, std::min(2, atoi(e)));
     if (const char *e = getenv("PANSIM_BLOCK_BATCH")) p->block_batch = (uint32_t)atoi(e);
     if (const char *e = getenv("PANSIM_BLOCK_WAVES")) p->block_waves = (uint32_t)atoi(e);
     if (const char *e = getenv("PANSIM_HGT_SLICES")) p->hgt_slices = (uint32_t)atoi(e);
@@ -409,6 +414,9 @@ extern "C" int ps_set_tuning(ps_population *p, const char *key, int64_t value)
     } else if (k == "sweep_rows") {
         if (value < 2 || value > 4) return ps_fail(PS_ERR_INVALID, "sweep_rows must be 2..4");
         p->sweep_rows = (uint32_t)value;
+    } else if (k == "sweep_out_of_place") {
+        if (value < -1 || value > 2) return ps_fail(PS_ERR_INVALID, "sweep_out_of_place must be -1 (choose), 0 (in place), 1 (out of place) or 2 (out of place, nontemporal loads and stores)");
+        p->sweep_oop = (int)value;
     } else if (k == "hgt_mode") {
         if (value < 0 || value > 2) return ps_fail(PS_ERR_INVALID, "hgt_mode must be 0 (auto), 1 (one atomic per event) or 2 (binned by recipient partition, two passes)");
         p->hgt_mode = (int)value;
@@ -571,10 +579,14 @@ static int launch_core_sweep_wave_r(ps_population *p, const core_sweep_args &a, 
     const uint32_t grid = std::max(8u, std::min((want + 7u) & ~7u, 256u * bpc));   // a multiple of the 8 groups
     // every candidate byte below 16 and every state byte below 16 (a loaded matrix may hold any byte): the level-1
     // nibble rides in the child byte (core_kernels.h, STASH)
-    if (a.plan.has_events && a.plan.bC <= 15u && p->nibble_safe)
-        hipLaunchKernelGGL((core_sweep_wave_kernel<ROWS, GA, MU, HR, true>), dim3(grid), dim3(block), lds, st, a);
-    else
-        hipLaunchKernelGGL((core_sweep_wave_kernel<ROWS, GA, MU, HR, false>), dim3(grid), dim3(block), lds, st, a);
+    const bool stash = a.plan.has_events && a.plan.bC <= 15u && p->nibble_safe;
+    if (a.nt) {
+        if (stash) hipLaunchKernelGGL((core_sweep_wave_kernel<ROWS, GA, MU, HR, true, true>), dim3(grid), dim3(block), lds, st, a);
+        else hipLaunchKernelGGL((core_sweep_wave_kernel<ROWS, GA, MU, HR, false, true>), dim3(grid), dim3(block), lds, st, a);
+    } else {
+        if (stash) hipLaunchKernelGGL((core_sweep_wave_kernel<ROWS, GA, MU, HR, true, false>), dim3(grid), dim3(block), lds, st, a);
+        else hipLaunchKernelGGL((core_sweep_wave_kernel<ROWS, GA, MU, HR, false, false>), dim3(grid), dim3(block), lds, st, a);
+    }
     HIPCHK(hipGetLastError());
     return PS_OK;
 }
@@ -731,6 +743,27 @@ static int launch_core_sweep(ps_population *p, const uint32_t *d_idx, uint32_t g
     if (!mu && !hr) a.plan.has_events = 0;
     if (!ga && !mu && !hr) return PS_OK;
     const bool wave = wave_sweep_eligible(p, mu, hr);
+    // Out of place: the new generation goes to the second buffer and the two swap roles (an out-of-place stream has
+    // a higher ceiling on this GPU than an in-place one, scripts/ubench/inplace_stream.hip); the inline fallback
+    // kernel and a failed allocation of the second buffer keep the in-place form -- results are identical.
+    a.out = a.state;
+    a.nt = 0;
+    core_block_geom g_probe{};
+    uint32_t lds_probe = 0, nw_probe = 0;
+    const bool inline_form = !wave && (p->force_inline_sweep || !block_sweep_geometry(p, ga, mu, hr, &g_probe, &lds_probe, &nw_probe));
+    const int oop = p->sweep_oop < 0 ? (wave ? 2 : 0) : p->sweep_oop;
+    if (oop && !inline_form) {
+        if (!p->state2 && hipMalloc(&p->state2, (uint64_t)p->cfg.ncols * p->pitch) != hipSuccess) {
+            (void)hipGetLastError();
+            p->state2 = nullptr;
+            p->sweep_oop = 0;
+        }
+        if (p->state2) {
+            a.out = p->state2;
+            a.nt = oop == 2 ? 1u : 0u;
+            std::swap(p->state, p->state2);      // (a.state / a.out hold this launch's roles)
+        }
+    }
     a.overflow_flag = p->d_flag;
     a.stamps = p->d_stamps;
     a.work_ctr = p->d_work;

@@ -96,6 +96,8 @@ def run(trials, seed=1, log=print):
             tune["no_block_preload"] = 1
         if rng.random() < 0.2:
             tune["force_inline_sweep"] = 1
+        if rng.random() < 0.5:
+            tune["sweep_out_of_place"] = int(rng.integers(-1, 3))
         if rng.random() < 0.3:
             tune["sweep_rows"] = int(rng.integers(2, 5))
             tune["sweep_blocks_per_cu"] = int(rng.integers(1, 9))
