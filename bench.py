@@ -211,7 +211,7 @@ def distance_roofline(form, N, L_local, G_acc, P, core_ms, acc_ms):
     return out
 
 
-def measure(ctx, kw, P, steps, warmup, shard_rank, shard_count, seed=0, want_pairs=False):
+def measure(ctx, kw, P, steps, warmup, shard_rank, shard_count, seed=0, want_pairs=False, exchange=None):
     """One workload: create the simulation (this rank's shard), settle, warm up, time exactly `steps` generations
     between barriers (max over ranks), then the distance phase.  Returns a dict of raw measurements."""
     import pansim_amd as pa
@@ -219,6 +219,16 @@ def measure(ctx, kw, P, steps, warmup, shard_rank, shard_count, seed=0, want_pai
     sim = pa.Simulation(pa.make_params(seed=seed, n_gen=steps + warmup, max_distances=P, shard_rank=shard_rank,
                                        shard_count=shard_count, device=ctx.local_rank, **kw))
     N = kw["pop_size"]
+    # the per-generation exchange step of a strong-scaling run (HGT donors sharded over the ranks, deltas ORed across
+    # them): "torch" = all-to-all + all-gather through torch.distributed (RCCL); "emulate" = this process plays shard 0
+    # of shard_count and device-local copies of the same volume stand in for the collectives
+    xchg = None
+    if exchange == "emulate":
+        sim.emulate_exchange(shard_count)
+    elif exchange == "torch" and shard_count > 1:
+        from pansim_amd.distributed import TorchExchange
+        xchg = TorchExchange()
+        sim.set_exchange(xchg.fn)
     sim.enable_timing(True)
     est_gen_ms = 2.0 * N * sim.core_genome.ncols / 4e9            # sweep at ~4 TB/s
     settle, prev, batch = [], None, int(max(5, min(50, 30.0 / max(est_gen_ms, 1e-3))))
@@ -239,12 +249,17 @@ def measure(ctx, kw, P, steps, warmup, shard_rank, shard_count, seed=0, want_pai
     sim.sync()
     sim.sweep_timing(reset=True)
     sim.host_timing(reset=True)
+    sim.exchange_stats(reset=True)
+    x0 = (xchg.calls, xchg.bytes) if xchg else (0, 0)
     ctx.barrier()
     t0 = time.perf_counter()
     sim.run(steps)
     sim.sync()
     ctx.barrier()
     dt = ctx.reduce(time.perf_counter() - t0, "max")
+    if xchg is not None and xchg.error is not None:
+        raise xchg.error
+    x_calls, x_bytes = (xchg.calls - x0[0], xchg.bytes - x0[1]) if xchg else sim.exchange_stats(reset=True)
     launches, sweep_ms, bytes_per_launch = sim.sweep_timing(reset=True)
     host_n, host_wait, host_weights, host_draw = sim.host_timing(reset=True)
     sim.enable_timing(False)
@@ -286,7 +301,9 @@ def measure(ctx, kw, P, steps, warmup, shard_rank, shard_count, seed=0, want_pai
          "bytes_per_launch": bytes_per_launch,
          "host": (host_n, host_wait, host_weights, host_draw), "settle": settle, "dist_dt": dist_dt,
          "dist_kernel_ms": dist_kernel_ms, "pair_form": sim.core_genome.last_pair_form(), "L_local": sim.core_genome.ncols,
-         "G_acc": sim.pan_genome.ncols, "P": P, "N": N, "kw": kw}
+         "G_acc": sim.pan_genome.ncols, "P": P, "N": N, "kw": kw,
+         "exchange": {"mode": exchange or "none (accessory chain replicated on every rank)", "calls": x_calls,
+                      "bytes_sent_plus_received_per_generation": x_bytes / max(steps, 1)}}
     if want_pairs:
         r["pairs"] = (sim.range1, sim.range2)
     sim.close()
@@ -322,7 +339,7 @@ def summary(r, label, emu=0):
                      "frac": roof["frac"], "algorithmic_bytes_per_launch": roof["algorithmic_bytes_per_launch"]},
            "exposed_non_sweep_ms": period - roof["avg_launch_ms"],
            "distance_ms": 1e3 * r["dist_dt"], "pairs": r["P"], "mpairs_per_s": r["P"] / r["dist_dt"] / 1e6,
-           "host_half_ms": host_half(r), "settle_sweep_ms": r["settle"]}
+           "host_half_ms": host_half(r), "settle_sweep_ms": r["settle"], "exchange": r["exchange"]}
     if r["dist_kernel_ms"] is not None:
         out["distance_roofline"] = distance_roofline(r["pair_form"], r["N"], r["L_local"], r["G_acc"], r["P"], *r["dist_kernel_ms"])
     if emu:
@@ -403,7 +420,12 @@ def main():
     kw["core_size"] = core_per_gpu * (1 if strong else world)
     if args.competition_strength:
         kw["competition_strength"] = args.competition_strength
-    r = measure(ctx, kw, P, steps, warmup, 0 if emu else rank, emu if emu else world, want_pairs=True)
+    # HGT donors are sharded (with the per-generation exchange) in strong-scaling runs of wide populations, where the
+    # replicated accessory chain is the Amdahl term; the weak cfg2 contract line keeps it replicated (it hides behind the sweep)
+    xmode = None
+    if strong and kw["pop_size"] >= 4096:
+        xmode = "emulate" if emu else ("torch" if world > 1 else None)
+    r = measure(ctx, kw, P, steps, warmup, 0 if emu else rank, emu if emu else world, want_pairs=True, exchange=xmode)
 
     out = None
     if rank == 0:
@@ -436,6 +458,7 @@ def main():
             "distance_roofline": droof,
             "host_half_ms": host_half(r),
             "settle_sweep_ms": r["settle"],
+            "exchange": r["exchange"],
             "roofline": roof,
         }
         if world > 1:
@@ -453,7 +476,7 @@ def main():
             okw, oP, oemu, osteps, owarm, olabel = CONFIGS[name]
             try:
                 t0 = time.perf_counter()
-                ro = measure(ctx, dict(okw), oP, osteps, owarm, 0, oemu if oemu else 1)
+                ro = measure(ctx, dict(okw), oP, osteps, owarm, 0, oemu if oemu else 1, exchange="emulate" if oemu else None)
                 others[name] = summary(ro, olabel + ": --pop_size %d --core_size %d --pan_genes %d --HR_rate %g --HGT_rate %g, P = %d"
                                        % (okw["pop_size"], okw["core_size"], okw["pan_genes"], okw["HR_rate"], okw["HGT_rate"], oP),
                                        emu=oemu)
@@ -465,7 +488,7 @@ def main():
     # ---- the north-star's scaling workload at this world size: --pop_size 65536, 1.2 M core sites split over the ranks
     if default_wl and world > 1:
         okw, oP, _e, osteps, owarm, olabel = CONFIGS["cfg4"]
-        ro = measure(ctx, dict(okw), oP, 10, 2, rank, world)
+        ro = measure(ctx, dict(okw), oP, 10, 2, rank, world, exchange="torch")
         if rank == 0:
             ns = summary(ro, "BASELINE configs[3] / north_star scaling: --pop_size 65536, %d core sites split over %d ranks (strong "
                              "scaling), P = %d" % (okw["core_size"], world, oP))
@@ -473,9 +496,10 @@ def main():
             ns["scaling"] = "strong"
             ns["unit"] = "generations/s of the whole simulation"
             ns["sweep"]["avg_launch_ms_over_ranks"] = {"min": ro["sweep_avg_ms_min_over_ranks"], "max": ro["sweep_avg_ms_max_over_ranks"]}
-            ns["collective_bytes_per_generation"] = 0
-            ns["collectives"] = ("none per generation (accessory matrix replicated, every rank draws the same parents); distance "
-                                 "phase: one all-reduce of %d u32 numerators" % oP)
+            ns["collective_bytes_per_generation"] = ro["exchange"]["bytes_sent_plus_received_per_generation"]
+            ns["collectives"] = ("per generation: HGT donors sharded over the ranks, the delta bit matrices (N x G bits) ORed with one "
+                                 "all-to-all + one all-gather (bytes above: sent + received per rank); every rank draws the same "
+                                 "parents; distance phase: one all-reduce of %d u32 numerators" % oP)
             out["north_star_scaling"] = ns
 
     if rank == 0:

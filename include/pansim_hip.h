@@ -100,6 +100,16 @@ int ps_next_generation(ps_population *p, const uint32_t *sample);
 int ps_mutate_alleles(ps_population *p, uint32_t generation);
 /* Population::recombine (population.rs:544-751) */
 int ps_recombine(ps_population *p, uint32_t generation);
+/* HGT donors sharded over the ranks / shards of one run (the exchange step of the path).  Events are
+ * keyed per donor and the recipient's bit is ORed (population.rs:632: the value is always 1), so any partition of the
+ * donors gives the unsharded result: this handle generates the events of donors [N r / K, N (r + 1) / K) into a delta
+ * buffer of `n_words` u64 (the individual-major bit matrix, zero padded), calls `fn` -- which must leave the bitwise
+ * OR of all shards' buffers in every shard's buffer, ordered on `hip_stream` (hipStream_t) -- and ORs the result into
+ * its replica of the matrix.  Providers: ps_multi (device-to-device reads between the shards of one process),
+ * pansim_amd/distributed.py (torch.distributed: all-to-all + all-gather over RCCL), or any host's own transport.
+ * fn == NULL applies the own donors' events only; shard_count == 1 switches sharding off. */
+typedef int (*ps_exchange_fn)(void *ctx, void *d_words, uint64_t n_words, void *hip_stream);
+int ps_set_donor_shard(ps_population *acc, uint32_t shard_rank, uint32_t shard_count, ps_exchange_fn fn, void *ctx);
 /* Fused next_generation + mutate_alleles + recombine in one pass over HBM
  * (main.rs:445-464 for one matrix); bit-identical to the three calls in order.
  * do_recombine mirrors the `HR_rate > 0.0` / `HGT_rate > 0.0` guards (main.rs:459-464). */
@@ -247,6 +257,14 @@ void ps_sim_destroy(ps_sim *s);
  * mutate x2, HR, HGT.  Asynchronous on the device; ps_sim_sync() waits. */
 int ps_sim_run(ps_sim *s, uint32_t first_generation, uint32_t count);
 int ps_sim_sync(ps_sim *s);
+/* Shard the HGT donors over the site shards of this run (shard_rank / shard_count of the parameters) and exchange the
+ * deltas through `fn` once per generation (ps_set_donor_shard).  Every shard of the run must do the same. */
+int ps_sim_set_exchange(ps_sim *s, ps_exchange_fn fn, void *ctx);
+/* bench.py --emulate-shard K: play shard 0 of K with the exchange stood in for by device-local copies of the same
+ * volume (timing only: the other shards' events never arrive). */
+int ps_sim_emulate_exchange(ps_sim *s, int n_shards);
+/* exchange calls and bytes this shard sent + received in them since the last reset */
+int ps_sim_exchange_stats(ps_sim *s, int reset, uint64_t *calls, uint64_t *bytes);
 ps_population *ps_sim_core(ps_sim *s);
 ps_population *ps_sim_acc(ps_sim *s);
 const double *ps_sim_selection(ps_sim *s);                     /* pan_size values */

@@ -56,6 +56,8 @@ _i32p = np.ctypeslib.ndpointer(np.int32, flags="C_CONTIGUOUS")
 _u64p = np.ctypeslib.ndpointer(np.uint64, flags="C_CONTIGUOUS")
 _f64p = np.ctypeslib.ndpointer(np.float64, flags="C_CONTIGUOUS")
 _vp, _u64, _u32, _i32, _f64, _int = C.c_void_p, C.c_uint64, C.c_uint32, C.c_int32, C.c_double, C.c_int
+# ps_exchange_fn: int (*)(void *ctx, void *d_words, uint64_t n_words, void *hip_stream)
+EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p)
 
 SIGNATURES = {
     "ps_last_error": (C.c_char_p, []),
@@ -71,6 +73,7 @@ SIGNATURES = {
     "ps_mutate_alleles": (_int, [_vp, _u32]),
     "ps_recombine": (_int, [_vp, _u32]),
     "ps_step": (_int, [_vp, _u32, _u32p, _int]),
+    "ps_set_donor_shard": (_int, [_vp, _u32, _u32, _vp, _vp]),
     "ps_sample_indices": (_int, [_vp, _u32, _i32, _f64p, _f64p, _int, _int, _f64, _f64, _u32p]),
     "ps_fitness_terms": (_int, [_vp, _f64p, _i32p, _f64p]),
     "ps_sample_weights": (_int, [_i32p, _f64p, _u64, _u64, _i32, _f64p, _int, _f64, _f64, _f64p]),
@@ -99,6 +102,9 @@ SIGNATURES = {
     "ps_sim_destroy": (None, [_vp]),
     "ps_sim_run": (_int, [_vp, _u32, _u32]),
     "ps_sim_sync": (_int, [_vp]),
+    "ps_sim_set_exchange": (_int, [_vp, _vp, _vp]),
+    "ps_sim_emulate_exchange": (_int, [_vp, _int]),
+    "ps_sim_exchange_stats": (_int, [_vp, _int, C.POINTER(_u64), C.POINTER(_u64)]),
     "ps_sim_core": (_vp, [_vp]),
     "ps_sim_acc": (_vp, [_vp]),
     "ps_sim_selection": (C.POINTER(_f64), [_vp]),

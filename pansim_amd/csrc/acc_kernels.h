@@ -170,6 +170,9 @@ struct acc_hgt_args {
     uint32_t *overflow_flag;
     uint16_t *list_scratch;        // null: donor lists in LDS; else [grid][list_stride] in global memory
     uint32_t list_stride;
+    // donor shard: this launch serves the donors [dn_lo, dn_lo + dn_cnt) only (all of them: 0, N).  Events are keyed per
+    // donor and the recipient's bit is ORed, so the union over any partition of the donors is the unsharded result.
+    uint32_t dn_lo, dn_cnt;
 };
 
 // k_d for every (compartment, donor): kmin + number of thresholds <= u (ps_poisson_table).
@@ -241,14 +244,14 @@ __global__ void __launch_bounds__(64) acc_hgt_donor_wave_kernel(acc_hgt_args a)
     uint16_t *glist = a.list_scratch ? a.list_scratch + (uint64_t)blockIdx.x * a.list_stride : lds_list;
     const acc_dims d = a.d;
     const uint32_t lane = threadIdx.x;
-    const uint32_t items = a.n_comp * d.N;
+    const uint32_t items = a.n_comp * a.dn_cnt;
     for (;;) {
         uint32_t item = 0;
         if (lane == 0) item = atomicAdd(a.work_ctr, 1u);
         item = __builtin_amdgcn_readfirstlane(item);
         if (item >= items) break;
-        const uint32_t c = item / d.N, dn = item % d.N;
-        const uint32_t k = a.kcnt[item];
+        const uint32_t c = item / a.dn_cnt, dn = a.dn_lo + item % a.dn_cnt;
+        const uint32_t k = a.kcnt[c * d.N + dn];
         if (k == 0u) continue;
         __threadfence_block();                             // the previous item's list reads are done
         const uint32_t n = ps_wave_gene_list(a.srcI + (uint64_t)dn * d.GW, d.GW, a.gb[c], a.ge[c], glist, lane);
@@ -283,14 +286,14 @@ __global__ void __launch_bounds__(256) acc_hgt_donor_bin_kernel(acc_hgt_args a)
     __shared__ uint32_t sh_n;
     const acc_dims d = a.d;
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
-    const uint32_t items = a.n_comp * d.N;
+    const uint32_t items = a.n_comp * a.dn_cnt;
     const uint32_t cap = a.bin_cap;
     uint32_t *mybins = a.bins + (uint64_t)blockIdx.x * a.parts * cap;
     for (uint32_t q = tid; q < a.parts; q += blockDim.x) fill[q] = 0u;
     for (uint32_t item = blockIdx.x; item < items; item += gridDim.x) {
         __syncthreads();                                   // previous list is no longer read; fill[] is zeroed
-        const uint32_t c = item / d.N, dn = item % d.N;
-        const uint32_t k = a.kcnt[item];
+        const uint32_t c = item / a.dn_cnt, dn = a.dn_lo + item % a.dn_cnt;
+        const uint32_t k = a.kcnt[c * d.N + dn];
         if (k == 0u) continue;
         if (tid < 64u) {
             const uint32_t m = ps_wave_gene_list(a.srcI + (uint64_t)dn * d.GW, d.GW, a.gb[c], a.ge[c], glist, lane);
@@ -356,15 +359,26 @@ __global__ void __launch_bounds__(1024) acc_hgt_apply_kernel(acc_hgt_args a, uin
     for (uint32_t w = threadIdx.x; w < (r_hi - r_lo) * W32; w += blockDim.x) img[w] = lrow[w];
 }
 
-// dstI |= OR over the slice images written by acc_hgt_apply_kernel (scratch[slice][N][GW] u64)
+// dstI |= OR over the slice images written by acc_hgt_apply_kernel (scratch[slice][N][GW] u64); `assign`: dstI = that
+// OR (the delta buffer of a donor-sharded run, merged into the matrix after the exchange)
 __global__ void __launch_bounds__(256) acc_hgt_reduce_kernel(const uint64_t *scratch, uint64_t *dstI, uint64_t words,
-                                                             uint32_t n_slices)
+                                                             uint32_t n_slices, int assign)
 {
     const uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (w >= words) return;
     uint64_t v = 0;
     for (uint32_t sl = 0; sl < n_slices; sl++) v |= scratch[(uint64_t)sl * words + w];
-    if (v) dstI[w] |= v;
+    if (assign) dstI[w] = v;
+    else if (v) dstI[w] |= v;
+}
+
+// dst |= src (a donor shard's exchanged HGT delta into the matrix; a peer shard's delta into this shard's)
+__global__ void __launch_bounds__(256) acc_or_kernel(uint64_t *dst, const uint64_t *src, uint64_t words)
+{
+    const uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= words) return;
+    const uint64_t v = src[w];
+    if (v) dst[w] |= v;
 }
 
 // population.rs:282-322: gene count and left-to-right f64 sum of ln(1+s_g) over

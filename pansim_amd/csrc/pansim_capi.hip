@@ -11,6 +11,8 @@
 #include <algorithm>
 #include <charconv>
 #include <chrono>
+#include <condition_variable>
+#include <mutex>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -204,6 +206,14 @@ struct ps_population {
     uint32_t *cnt = nullptr;
     int cur = 0;
     ps_acc_plan aplan{};
+    // HGT donors sharded over the ranks / shards of a run (ps_set_donor_shard): this handle generates the events of the
+    // donors [donor_lo, donor_lo + donor_cnt) into d_delta, the exchange ORs the shards' deltas, the result is ORed
+    // into the matrix
+    uint32_t donor_lo = 0, donor_cnt = 0;      // donor_cnt == 0: all donors, events applied directly
+    uint64_t *d_delta = nullptr;
+    uint64_t delta_words = 0;                  // N * GW rounded up to a multiple of 4096 words
+    ps_exchange_fn exchange = nullptr;
+    void *exchange_ctx = nullptr;
     // scratch
     uint32_t *d_idx = nullptr;       // N parents
     uint32_t *d_idxT = nullptr;      // transposed parents for the block sweep (16 x cpr)
@@ -248,7 +258,7 @@ extern "C" void ps_population_destroy(ps_population *p)
     if (!p) return;
     (void)hipSetDevice(p->device);
     if (p->stream) (void)hipStreamSynchronize(p->stream);
-    void *ptrs[] = { p->state, p->state2, p->G[0], p->G[1], p->I[0], p->I[1], p->d_ptab[0], p->d_ptab[1], p->hgt_scratch, p->cnt, p->d_idx, p->d_idxT, p->d_work,
+    void *ptrs[] = { p->state, p->state2, p->d_delta, p->G[0], p->G[1], p->I[0], p->I[1], p->d_ptab[0], p->d_ptab[1], p->hgt_scratch, p->cnt, p->d_idx, p->d_idxT, p->d_work,
                      p->d_log1p, p->d_num_genes, p->d_logw, p->d_pairs, p->d_H, p->d_Dt, p->d_pack2, p->d_pair_part };
     for (void *q : ptrs)
         if (q) (void)hipFree(q);
@@ -856,7 +866,17 @@ static int launch_acc_hgt(ps_population *p, uint32_t gen, hipStream_t st, hipEve
     a.kcnt = p->cnt;
     a.work_ctr = p->cnt + (uint64_t)PS_MAX_COMP * p->d.N;
     a.overflow_flag = p->d_flag;
-    const uint32_t items = a.n_comp * p->d.N;
+    const bool sharded = p->donor_cnt != 0;
+    a.dn_lo = sharded ? p->donor_lo : 0u;
+    a.dn_cnt = sharded ? p->donor_cnt : p->d.N;
+    const uint32_t items = a.n_comp * a.dn_cnt;           // work items of THIS launch: (compartment, own donor)
+    const uint32_t items_all = a.n_comp * p->d.N;
+    const uint64_t mat_words = (uint64_t)p->d.N * p->d.GW;
+    if (sharded && !p->d_delta) {
+        p->delta_words = (mat_words + 4095) & ~4095ull;
+        HIPCHK(hipMalloc(&p->d_delta, p->delta_words * 8));
+        HIPCHK(hipMemsetAsync(p->d_delta, 0, p->delta_words * 8, st));
+    }
     const uint32_t list_lds = ((max_comp * 2u + 15u) & ~15u);
     if (list_lds > p->lds_limit)
         return ps_fail(PS_ERR_INVALID, "a compartment of %u genes needs %u bytes of LDS (limit %u)", max_comp, list_lds, p->lds_limit);
@@ -875,7 +895,7 @@ static int launch_acc_hgt(ps_population *p, uint32_t gen, hipStream_t st, hipEve
     // event counts per donor; the light form's snapshot copy rides along (donors read the
     // pre-recombination matrix, population.rs:693-695, while recipients are edited in place)
     {
-        const uint32_t blocks = std::max((items + 255) / 256, binned ? 1u : 64u);
+        const uint32_t blocks = std::max((items_all + 255) / 256, binned ? 1u : 64u);
         acc_hgt_counts_kernel<<<blocks, 256, 0, st>>>(a, binned ? nullptr : p->I[p->cur], binned ? nullptr : p->I[1 - p->cur]);
     }
     if (binned) {
@@ -890,7 +910,7 @@ static int launch_acc_hgt(ps_population *p, uint32_t gen, hipStream_t st, hipEve
         // receives rows_per_part / (N - 1) of them
         double per_block = 0.0;
         for (int c = 0; c < p->aplan.n_comp; c++)
-            if (a.ptab[c]) per_block += p->aplan.lam_rec[c] * (double)((p->d.N + donor_blocks - 1) / donor_blocks);
+            if (a.ptab[c]) per_block += p->aplan.lam_rec[c] * (double)((a.dn_cnt + donor_blocks - 1) / donor_blocks);
         const double mean = per_block * (double)rows_per_part / (double)(p->d.N - 1);
         const uint32_t cap = (uint32_t)(((uint64_t)(mean + 10.0 * std::sqrt(mean) + 64.0) + 63) & ~63ull);
         const uint64_t bin_words = (uint64_t)donor_blocks * parts * cap;
@@ -931,16 +951,19 @@ static int launch_acc_hgt(ps_population *p, uint32_t gen, hipStream_t st, hipEve
             HIPCHK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(kern, dim3(parts * n_slices), dim3(1024), lds, st, a, donor_blocks, n_slices);
         acc_hgt_reduce_kernel<<<(uint32_t)((words + 255) / 256), 256, 0, st>>>((const uint64_t *)p->hgt_scratch,
-                                                                              p->I[p->cur], words, n_slices);
+                                                                              sharded ? p->d_delta : p->I[p->cur], words, n_slices,
+                                                                              sharded ? 1 : 0);
     } else {
         a.srcI = p->I[1 - p->cur];          // the snapshot written by acc_hgt_counts_kernel
-        a.dstI = p->I[p->cur];
+        a.dstI = sharded ? p->d_delta : p->I[p->cur];
+        if (sharded) HIPCHK(hipMemsetAsync(p->d_delta, 0, mat_words * 8, st));
         // beside a long core sweep (ps_sim sets hgt_events_per_thread) the kernel is launched narrow --
         // one-wave workgroups, a fixed number of events per thread over the generation: the same events
         // then disturb the sweep for longer but far less; stand-alone calls use the whole chip
         uint32_t grid = std::min(items, 256u * 32u);
         if (p->hgt_events_per_thread) {
-            const uint64_t want = (uint64_t)(expected / ((double)p->hgt_events_per_thread * 64.0)) + 1;
+            const double expected_here = expected * (double)a.dn_cnt / (double)p->d.N;
+            const uint64_t want = (uint64_t)(expected_here / ((double)p->hgt_events_per_thread * 64.0)) + 1;
             grid = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(want, 1), grid);
         }
         uint32_t dyn_lds = list_lds;
@@ -963,8 +986,46 @@ static int launch_acc_hgt(ps_population *p, uint32_t gen, hipStream_t st, hipEve
             HIPCHK(hipFuncSetAttribute((const void *)acc_hgt_donor_wave_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn_lds));
         hipLaunchKernelGGL(acc_hgt_donor_wave_kernel, dim3(grid), dim3(64), dyn_lds, st, a);
     }
-    p->g_valid = false;       // only the individual-major view is edited (ensure_gene_major)
     HIPCHK(hipGetLastError());
+    if (sharded) {
+        // the exchange step of the path: OR of the shards' deltas (in place in d_delta, ordered on st), then
+        // the union goes into the matrix.  Without a hook the own donors' events alone are applied.
+        if (p->exchange) {
+            const std::string prev = g_err;
+            g_err.clear();
+            const int rc = p->exchange(p->exchange_ctx, p->d_delta, p->delta_words, (void *)st);
+            if (rc != 0) {
+                const std::string inner = g_err;
+                return ps_fail(PS_ERR_STATE, "the HGT delta exchange failed (%d)%s%s", rc, inner.empty() ? "" : ": ", inner.c_str());
+            }
+            g_err = prev;
+        }
+        acc_or_kernel<<<(uint32_t)((mat_words + 255) / 256), 256, 0, st>>>(p->I[p->cur], p->d_delta, mat_words);
+        HIPCHK(hipGetLastError());
+    }
+    p->g_valid = false;       // only the individual-major view is edited (ensure_gene_major)
+    return PS_OK;
+}
+
+extern "C" int ps_set_donor_shard(ps_population *p, uint32_t shard_rank, uint32_t shard_count, ps_exchange_fn fn, void *ctx)
+{
+    if (!p) return ps_fail(PS_ERR_INVALID, "null handle");
+    if (p->cfg.core) return ps_fail(PS_ERR_INVALID, "donor shards apply to the accessory matrix (HGT, population.rs:544-751)");
+    if (shard_count < 1 || shard_rank >= shard_count) return ps_fail(PS_ERR_INVALID, "bad donor shard %u of %u", shard_rank, shard_count);
+    const uint64_t N = p->cfg.pop_size;
+    if (shard_count == 1) {
+        p->donor_lo = 0;
+        p->donor_cnt = 0;
+        p->exchange = nullptr;
+        p->exchange_ctx = nullptr;
+        return PS_OK;
+    }
+    const uint64_t lo = N * shard_rank / shard_count, hi = N * ((uint64_t)shard_rank + 1) / shard_count;
+    if (hi <= lo) return ps_fail(PS_ERR_INVALID, "more donor shards than individuals");
+    p->donor_lo = (uint32_t)lo;
+    p->donor_cnt = (uint32_t)(hi - lo);
+    p->exchange = fn;
+    p->exchange_ctx = ctx;
     return PS_OK;
 }
 
@@ -1983,6 +2044,11 @@ struct ps_sim {
     // host half of a generation, accumulated since the last reset (ps_sim_host_timing)
     uint64_t host_calls = 0;
     double host_wait_ms = 0.0, host_weights_ms = 0.0, host_draw_ms = 0.0;
+    // exchange of the donor-sharded HGT deltas: emulation (bench.py --emulate-shard) and traffic counters
+    int emu_shards = 0;
+    void *emu_buf = nullptr;
+    uint64_t emu_cap = 0;
+    uint64_t exchange_calls = 0, exchange_bytes = 0;   // bytes this rank SENDS + RECEIVES in the exchange (providers add to it)
     // sweep timing
     bool timing = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> tev;
@@ -2011,6 +2077,7 @@ extern "C" void ps_sim_destroy(ps_sim *s)
     if (s->h_cnt) (void)hipHostFree(s->h_cnt);
     for (auto e : s->ev_dist) if (e) (void)hipEventDestroy(e);
     if (s->d_avg) (void)hipFree(s->d_avg);
+    if (s->emu_buf) (void)hipFree(s->emu_buf);
     if (s->d_log1p) (void)hipFree(s->d_log1p);
     for (auto &pr : s->tev) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
     for (auto e : s->ev_pool) (void)hipEventDestroy(e);
@@ -2272,6 +2339,54 @@ static int sim_one_generation(ps_sim *s, uint32_t gen)
     return PS_OK;
 }
 
+extern "C" int ps_sim_set_exchange(ps_sim *s, ps_exchange_fn fn, void *ctx)
+{
+    if (!s) return ps_fail(PS_ERR_INVALID, "null handle");
+    if (s->prm.shard_count < 2) return ps_fail(PS_ERR_INVALID, "the HGT donors are sharded over the site shards of a run: shard_count must be >= 2");
+    return ps_set_donor_shard(s->acc, (uint32_t)s->prm.shard_rank, (uint32_t)s->prm.shard_count, fn, ctx);
+}
+
+// bench.py --emulate-shard K: this process plays shard 0 of K.  Its HGT serves donors [0, N / K) and the exchange is
+// stood in for by device-local copies of the same volume a K-rank all-to-all + all-gather of the delta moves per rank
+// (2 x (K - 1) / K of the buffer).  A timing stand-in only: the other shards' events never arrive.
+static int emulated_exchange(void *ctx, void *d_words, uint64_t n_words, void *hip_stream)
+{
+    ps_sim *s = (ps_sim *)ctx;
+    const uint64_t bytes = n_words * 8;
+    if (s->emu_cap < bytes) {
+        if (s->emu_buf) HIPCHK(hipFree(s->emu_buf));
+        s->emu_buf = nullptr;
+        s->emu_cap = 0;
+        HIPCHK(hipMalloc(&s->emu_buf, bytes));
+        s->emu_cap = bytes;
+    }
+    const uint64_t part = bytes / (uint64_t)s->emu_shards * (uint64_t)(s->emu_shards - 1);
+    hipStream_t st = (hipStream_t)hip_stream;
+    HIPCHK(hipMemcpyAsync(s->emu_buf, d_words, part, hipMemcpyDeviceToDevice, st));                        // "all-to-all"
+    HIPCHK(hipMemcpyAsync((uint8_t *)s->emu_buf + (bytes - part), (uint8_t *)d_words + (bytes - part), part,
+                          hipMemcpyDeviceToDevice, st));                                                   // "all-gather"
+    s->exchange_calls++;
+    s->exchange_bytes += 2 * part;
+    return PS_OK;
+}
+
+extern "C" int ps_sim_emulate_exchange(ps_sim *s, int n_shards)
+{
+    if (!s) return ps_fail(PS_ERR_INVALID, "null handle");
+    if (n_shards < 2) return ps_fail(PS_ERR_INVALID, "n_shards must be >= 2");
+    s->emu_shards = n_shards;
+    return ps_set_donor_shard(s->acc, 0u, (uint32_t)n_shards, emulated_exchange, s);
+}
+
+extern "C" int ps_sim_exchange_stats(ps_sim *s, int reset, uint64_t *calls, uint64_t *bytes)
+{
+    if (!s) return ps_fail(PS_ERR_INVALID, "null handle");
+    if (calls) *calls = s->exchange_calls;
+    if (bytes) *bytes = s->exchange_bytes;
+    if (reset) s->exchange_calls = s->exchange_bytes = 0;
+    return PS_OK;
+}
+
 extern "C" int ps_sim_run(ps_sim *s, uint32_t first_generation, uint32_t count)
 {
     if (!s) return ps_fail(PS_ERR_INVALID, "null handle");
@@ -2433,13 +2548,71 @@ extern "C" int ps_sim_sweep_timing(ps_sim *s, int reset, uint64_t *launches, dou
 // shards on one GPU), each driven by its own host thread for the duration of a call.  The shards never
 // talk to each other during a generation (the accessory matrix is replicated and every shard draws the
 // same parents); the one exchange step is the sum of the P Hamming numerators of the distance phase.
+struct ps_multi;
+struct multi_ctx { ps_multi *m; size_t k; };
 struct ps_multi {
     ps_sim_params prm{};
     std::vector<ps_sim *> shard;
     std::vector<uint32_t *> d_cnt;      // per shard, on its device: P numerators
-    uint32_t *d_tmp = nullptr;          // on shard 0's device: landing buffer of the peer copies
+    uint32_t *d_tmp = nullptr;          // on shard 0's device: landing buffers of the peer copies (K - 1 x P)
     uint64_t cnt_cap = 0;
+    // rendezvous of the shard threads inside one call, and the exchange of the donor-sharded HGT deltas between the
+    // shards' devices (ps_set_donor_shard): every shard ORs its peers' delta buffers into its own, reading them where
+    // they are (peer access over xGMI between GPUs, plain loads inside one)
+    std::mutex mu;
+    std::condition_variable cv;
+    size_t bar_count = 0;
+    uint64_t bar_gen = 0;
+    bool failed = false;
+    bool donor_sharded = false;
+    bool peers_ok = true;               // every shard's device can read every other's memory
+    std::vector<uint64_t *> delta;
+    std::vector<hipEvent_t> ev_ready, ev_read;
+    std::vector<multi_ctx> ctx;
 };
+
+// barrier of the shard threads; fails (instead of hanging) once any shard has failed
+static int multi_barrier(ps_multi *m)
+{
+    std::unique_lock<std::mutex> lk(m->mu);
+    if (m->failed) return ps_fail(PS_ERR_STATE, "another shard failed");
+    const uint64_t gen = m->bar_gen;
+    if (++m->bar_count == m->shard.size()) {
+        m->bar_count = 0;
+        m->bar_gen++;
+        m->cv.notify_all();
+        return PS_OK;
+    }
+    m->cv.wait(lk, [&] { return m->bar_gen != gen || m->failed; });
+    if (m->bar_gen == gen) return ps_fail(PS_ERR_STATE, "another shard failed");
+    return PS_OK;
+}
+
+// ps_exchange_fn of the shards of one process.  OR is idempotent and the buffers only ever gain bits that belong to the
+// union, so a shard may OR into its buffer while its peers read it (aligned 8-byte accesses): in place, no staging.
+static int multi_exchange(void *vctx, void *d_words, uint64_t n_words, void *hip_stream)
+{
+    multi_ctx *c = (multi_ctx *)vctx;
+    ps_multi *m = c->m;
+    const size_t k = c->k, K = m->shard.size();
+    hipStream_t st = (hipStream_t)hip_stream;
+    m->delta[k] = (uint64_t *)d_words;
+    HIPCHK(hipEventRecord(m->ev_ready[k], st));
+    PSCHK(multi_barrier(m));                     // every shard's buffer is published and its "complete" event recorded
+    for (size_t j = 0; j < K; j++) {
+        if (j == k) continue;
+        HIPCHK(hipStreamWaitEvent(st, m->ev_ready[j], 0));
+        acc_or_kernel<<<(uint32_t)((n_words + 255) / 256), 256, 0, st>>>((uint64_t *)d_words, m->delta[j], n_words);
+        HIPCHK(hipGetLastError());
+    }
+    HIPCHK(hipEventRecord(m->ev_read[k], st));
+    PSCHK(multi_barrier(m));                     // every shard has queued its reads
+    for (size_t j = 0; j < K; j++)               // nobody rewrites its buffer (next generation) before its peers have read it
+        if (j != k) HIPCHK(hipStreamWaitEvent(st, m->ev_read[j], 0));
+    m->shard[k]->exchange_calls++;
+    m->shard[k]->exchange_bytes += (uint64_t)(K - 1) * n_words * 8;
+    return PS_OK;
+}
 
 // run fn(k) for every shard on its own host thread; the first failure (with its message) is returned
 template <typename F>
@@ -2448,9 +2621,19 @@ static int multi_for_each(ps_multi *m, F fn)
     const size_t n = m->shard.size();
     std::vector<int> rc(n, PS_OK);
     std::vector<std::string> err(n);
+    {
+        std::lock_guard<std::mutex> lk(m->mu);
+        m->failed = false;
+        m->bar_count = 0;
+    }
     auto body = [&](size_t k) {
         rc[k] = fn(k);
-        if (rc[k] != PS_OK) err[k] = g_err;      // g_err is thread local
+        if (rc[k] != PS_OK) {
+            err[k] = g_err;      // g_err is thread local
+            std::lock_guard<std::mutex> lk(m->mu);
+            m->failed = true;    // peers waiting in multi_barrier give up
+            m->cv.notify_all();
+        }
     };
     if (n == 1) {
         body(0);
@@ -2459,6 +2642,9 @@ static int multi_for_each(ps_multi *m, F fn)
         for (size_t k = 0; k < n; k++) th.emplace_back(body, k);
         for (auto &t : th) t.join();
     }
+    // report the root cause, not a peer's "another shard failed"
+    for (size_t k = 0; k < n; k++)
+        if (rc[k] != PS_OK && err[k].find("another shard failed") == std::string::npos) { g_err = err[k]; return rc[k]; }
     for (size_t k = 0; k < n; k++)
         if (rc[k] != PS_OK) { g_err = err[k]; return rc[k]; }
     return PS_OK;
@@ -2471,6 +2657,8 @@ extern "C" void ps_multi_destroy(ps_multi *m)
         if (m->shard[k] && m->shard[k]->core) (void)hipSetDevice(m->shard[k]->core->device);
         if (k < m->d_cnt.size() && m->d_cnt[k]) (void)hipFree(m->d_cnt[k]);
         if (k == 0 && m->d_tmp) (void)hipFree(m->d_tmp);
+        if (k < m->ev_ready.size() && m->ev_ready[k]) (void)hipEventDestroy(m->ev_ready[k]);
+        if (k < m->ev_read.size() && m->ev_read[k]) (void)hipEventDestroy(m->ev_read[k]);
         ps_sim_destroy(m->shard[k]);
     }
     delete m;
@@ -2505,16 +2693,46 @@ extern "C" int ps_multi_create(const ps_sim_params *p, int n_shards, const int *
             return rc;
         }
     }
-    // direct xGMI copies for the sum of the distance numerators (without peer access the runtime stages the
-    // copies through host memory: still correct, only slower)
-    const int dev0 = m->shard[0]->core->device;
-    for (int k = 1; k < n_shards; k++) {
-        const int devk = m->shard[(size_t)k]->core->device;
-        int can = 0;
-        if (devk != dev0 && hipSetDevice(dev0) == hipSuccess && hipDeviceCanAccessPeer(&can, dev0, devk) == hipSuccess && can) {
-            const hipError_t e = hipDeviceEnablePeerAccess(devk, 0);
-            if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) (void)hipGetLastError();
+    // direct xGMI access between the shards' devices (the sum of the distance numerators, the HGT delta exchange);
+    // without peer access the copies are staged by the runtime, and the delta exchange is not switched on
+    bool &peers_ok = m->peers_ok;
+    for (int a = 0; a < n_shards; a++)
+        for (int b = 0; b < n_shards; b++) {
+            const int da = m->shard[(size_t)a]->core->device, db = m->shard[(size_t)b]->core->device;
+            if (da == db) continue;
+            int can = 0;
+            if (hipSetDevice(da) == hipSuccess && hipDeviceCanAccessPeer(&can, da, db) == hipSuccess && can) {
+                const hipError_t e = hipDeviceEnablePeerAccess(db, 0);
+                if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) { (void)hipGetLastError(); peers_ok = false; }
+            } else {
+                peers_ok = false;
+            }
         }
+    (void)hipGetLastError();
+    // HGT donors sharded over the shards (each generates 1/K of the events, the deltas are ORed across the devices);
+    // PANSIM_MULTI_REPLICATED_HGT=1 keeps round 2's form (every shard generates every event, no exchange)
+    if (n_shards > 1 && peers_ok && !getenv("PANSIM_MULTI_REPLICATED_HGT") && (uint64_t)n_shards <= p->pop_size) {
+        m->delta.assign((size_t)n_shards, nullptr);
+        m->ev_ready.assign((size_t)n_shards, nullptr);
+        m->ev_read.assign((size_t)n_shards, nullptr);
+        m->ctx.resize((size_t)n_shards);
+        int rc = PS_OK;
+        for (int k = 0; k < n_shards && rc == PS_OK; k++) {
+            m->ctx[(size_t)k] = multi_ctx{ m, (size_t)k };
+            if (hipSetDevice(m->shard[(size_t)k]->core->device) != hipSuccess
+                || hipEventCreateWithFlags(&m->ev_ready[(size_t)k], hipEventDisableTiming) != hipSuccess
+                || hipEventCreateWithFlags(&m->ev_read[(size_t)k], hipEventDisableTiming) != hipSuccess)
+                rc = ps_fail(PS_ERR_NO_DEVICE, "cannot create the exchange events of shard %d", k);
+            else
+                rc = ps_sim_set_exchange(m->shard[(size_t)k], multi_exchange, &m->ctx[(size_t)k]);
+        }
+        if (rc != PS_OK) {
+            const std::string keep = g_err;
+            ps_multi_destroy(m);
+            g_err = keep;
+            return rc;
+        }
+        m->donor_sharded = true;
     }
     (void)hipGetLastError();
     *out = m;
@@ -2566,8 +2784,14 @@ static int multi_core_counts(ps_multi *m, uint32_t **d_total)
     }));
     PSCHK(use_device(c0));
     for (size_t k = 1; k < m->shard.size(); k++) {
-        HIPCHK(hipMemcpyPeerAsync(m->d_tmp, c0->device, m->d_cnt[k], m->shard[k]->core->device, P * sizeof(uint32_t), c0->stream));
-        u32_add_kernel<<<(uint32_t)((P + 255) / 256), 256, 0, c0->stream>>>(m->d_cnt[0], m->d_tmp, P);
+        if (m->peers_ok) {
+            // shard 0's device adds the peer's numerators where they are (xGMI reads; the shards' kernels have completed:
+            // ps_pairwise_counts synchronises)
+            u32_add_kernel<<<(uint32_t)((P + 255) / 256), 256, 0, c0->stream>>>(m->d_cnt[0], m->d_cnt[k], P);
+        } else {
+            HIPCHK(hipMemcpyPeerAsync(m->d_tmp, c0->device, m->d_cnt[k], m->shard[k]->core->device, P * sizeof(uint32_t), c0->stream));
+            u32_add_kernel<<<(uint32_t)((P + 255) / 256), 256, 0, c0->stream>>>(m->d_cnt[0], m->d_tmp, P);
+        }
         HIPCHK(hipGetLastError());
     }
     *d_total = m->d_cnt[0];

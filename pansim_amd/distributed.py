@@ -2,12 +2,84 @@
 
 SURVEY 8(e): every per-generation core operator is site-local in the site-major layout, so
 each rank owns a contiguous range of core sites for ALL individuals.  The accessory matrix is
-replicated and every rank draws the same parents from the same seeded stream, so a generation
-needs NO data-path collective.  The only exchange step is the distance phase: the integer
-Hamming numerators of the sampled pairs are summed over ranks (all-reduce, u32), after which
-every rank applies the reference's `/2` and `/ncols` (population.rs:817-822).
+replicated and every rank draws the same parents from the same seeded stream.  Two exchange steps:
+  * per generation (when HGT is on): the HGT donors are sharded over the ranks -- rank r generates the events of
+    donors [N r / K, N (r + 1) / K) into a delta bit matrix (33 MB at N = 65536) -- and the deltas are ORed across
+    the ranks: an all-to-all of the K row slices, a local OR, and an all-gather of the merged slices over RCCL
+    (`TorchExchange`; the north-star's "all-gather of donor tiles").  Events are keyed per donor and ORed into the
+    recipient, so the result equals the replicated form bit for bit;
+  * the distance phase: the integer Hamming numerators of the sampled pairs are summed over ranks (all-reduce,
+    u32), after which every rank applies the reference's `/2` and `/ncols` (population.rs:817-822).
 """
+import ctypes as C
+
 import numpy as np
+
+
+class _DevWords:
+    """a device buffer of int64 words as a __cuda_array_interface__ object (zero copy into torch)"""
+
+    def __init__(self, ptr, n_words):
+        self.__cuda_array_interface__ = {"shape": (int(n_words),), "typestr": "<i8", "data": (int(ptr), False), "version": 2}
+
+
+def or_all_reduce(buf, group=None):
+    """in-place bitwise OR of the int64 tensor `buf` over the ranks of `group`: all-to-all of the K slices, local OR,
+    all-gather of the merged slices (NCCL / RCCL has no OR reduction; gloo has, and takes it on CPU tensors).
+    Returns the bytes this rank sent + received."""
+    import torch
+    import torch.distributed as dist
+    K = dist.get_world_size(group)
+    if K == 1:
+        return 0
+    n = buf.numel()
+    if dist.get_backend(group) != "nccl":
+        host = buf if buf.device.type == "cpu" else buf.cpu()
+        dist.all_reduce(host, op=dist.ReduceOp.BOR, group=group)
+        if host is not buf:
+            buf.copy_(host)
+        return 2 * n * 8 * (K - 1) // K
+    part = (n + K - 1) // K
+    send = torch.zeros(K * part, dtype=buf.dtype, device=buf.device)
+    send[:n] = buf
+    recv = torch.empty_like(send)
+    dist.all_to_all_single(recv, send, group=group)             # slice k of every rank's delta arrives at rank k
+    mine = recv[:part].clone()
+    for k in range(1, K):
+        mine |= recv[k * part:(k + 1) * part]
+    dist.all_gather_into_tensor(send, mine, group=group)        # the merged slices, everywhere
+    buf.copy_(send[:n])
+    return 2 * part * 8 * (K - 1)
+
+
+class TorchExchange:
+    """ps_exchange_fn over torch.distributed: `fn` is the ctypes thunk to hand to Simulation.set_exchange."""
+
+    def __init__(self, group=None):
+        from ._lib import EXCHANGE_FN
+        self.group = group
+        self.calls = 0
+        self.bytes = 0
+        self.error = None
+        self.fn = EXCHANGE_FN(self._call)
+
+    def _call(self, ctx, d_words, n_words, hip_stream):
+        try:
+            import torch
+            stream = torch.cuda.ExternalStream(int(hip_stream or 0)) if hip_stream else torch.cuda.current_stream()
+            with torch.cuda.stream(stream):
+                buf = torch.as_tensor(_DevWords(d_words, n_words), device="cuda")
+                import torch.distributed as dist
+                if dist.get_backend(self.group) != "nccl":
+                    stream.synchronize()                # the delta is complete before it leaves the device
+                self.bytes += or_all_reduce(buf, self.group)
+                if dist.get_backend(self.group) != "nccl":
+                    stream.synchronize()
+            self.calls += 1
+            return 0
+        except Exception as e:          # never let an exception cross the C boundary
+            self.error = e
+            return -1
 
 
 def shard_bounds(core_size, rank, world):
@@ -26,7 +98,7 @@ class ShardedSimulation:
     the HIP-backed pansim_amd.Simulation (tests inject a CPU double to exercise the exchange
     logic over gloo)."""
 
-    def __init__(self, rank, world, engine=None, group=None, **params):
+    def __init__(self, rank, world, engine=None, group=None, shard_hgt_donors=None, **params):
         if engine is None:
             from .simulation import Simulation, make_params
 
@@ -36,9 +108,20 @@ class ShardedSimulation:
         self.core_size = params["core_size"]
         self.bounds = shard_bounds(self.core_size, rank, world)
         self.sim = engine(shard_rank=rank, shard_count=world, **params)
+        # the per-generation exchange step: HGT donors sharded over the ranks, deltas ORed across them.  By default only
+        # where the replicated HGT is worth more than two small collectives per generation (wide populations: it is the
+        # Amdahl term of the N = 65536 run; at N = 1000 the whole HGT hides behind the sweep)
+        self.exchange = None
+        if shard_hgt_donors is None:
+            shard_hgt_donors = params.get("pop_size", 0) >= 4096
+        if shard_hgt_donors and world > 1 and hasattr(self.sim, "set_exchange") and world <= params.get("pop_size", world):
+            self.exchange = TorchExchange(group)
+            self.sim.set_exchange(self.exchange.fn)
 
     def run(self, count):
         self.sim.run(count)
+        if self.exchange is not None and self.exchange.error is not None:
+            raise self.exchange.error
 
     def sync(self):
         self.sim.sync()

@@ -229,6 +229,13 @@ class Population:
         check(self._lib.ps_pairwise_counts(self._h, r1.size, r1, r2, C.c_void_p(out_a_ptr),
                                            C.c_void_p(out_b_ptr), 1))
 
+    def set_donor_shard(self, shard_rank, shard_count, fn=None):
+        """HGT donors [N r / K, N (r + 1) / K) only (ps_set_donor_shard); `fn`: an _lib.EXCHANGE_FN object or None
+        (own donors' events only).  The caller keeps `fn` alive."""
+        ptr = C.cast(fn, C.c_void_p) if fn is not None else None
+        self._exchange_fn = fn
+        check(self._lib.ps_set_donor_shard(self._h, int(shard_rank), int(shard_count), ptr, None))
+
     def last_pair_form(self):
         """kernel form of the last core pair-count call (include/pansim_hip.h, PS_PAIR_FORM_*)"""
         return int(self._lib.ps_last_pair_form(self._h))

@@ -113,6 +113,22 @@ class Simulation:
         check(self._lib.ps_sim_last_parents(self._h, out))
         return out
 
+    def set_exchange(self, fn):
+        """shard the HGT donors over the site shards of this run; `fn` (an _lib.EXCHANGE_FN object) ORs the shards'
+        delta buffers once per generation (ps_sim_set_exchange).  Every shard of the run must install one."""
+        self._exchange_fn = fn          # keep the ctypes thunk alive
+        check(self._lib.ps_sim_set_exchange(self._h, C.cast(fn, C.c_void_p), None))
+
+    def emulate_exchange(self, n_shards):
+        """bench.py --emulate-shard: shard 0 of n_shards, exchange stood in for by device-local copies (timing only)"""
+        check(self._lib.ps_sim_emulate_exchange(self._h, int(n_shards)))
+
+    def exchange_stats(self, reset=True):
+        """(exchange calls, bytes sent + received by this shard in them) since the last reset -- library providers only"""
+        n, b = C.c_uint64(), C.c_uint64()
+        check(self._lib.ps_sim_exchange_stats(self._h, int(reset), C.byref(n), C.byref(b)))
+        return n.value, b.value
+
     def enable_timing(self, on=True):
         check(self._lib.ps_sim_enable_timing(self._h, int(on)))
 

@@ -109,3 +109,33 @@ def test_shard_bounds_partition():
             assert all(b[i][1] == b[i + 1][0] for i in range(w - 1))
     # integer /2 before the float divide (population.rs:817-822)
     assert core_distances_from_counts([2, 3, 10], 9).tolist() == [1 / 9, 1 / 9, 5 / 9]
+
+
+def _or_worker(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from pansim_amd.distributed import or_all_reduce
+    rng = np.random.default_rng(100 + rank)
+    for n in (1, 7, 4096, 10001):
+        mine = torch.from_numpy(rng.integers(-2**62, 2**62, n, dtype=np.int64) & rng.integers(-2**62, 2**62, n, dtype=np.int64))
+        buf = mine.clone()
+        sent = or_all_reduce(buf)
+        np.save(os.path.join(out, "or_%d_%d.npy" % (n, rank)), buf.numpy())
+        np.save(os.path.join(out, "in_%d_%d.npy" % (n, rank)), mine.numpy())
+        assert sent > 0
+    dist.destroy_process_group()
+
+
+def test_or_all_reduce_of_hgt_deltas(tmp_path):
+    # the per-generation exchange step of the donor-sharded HGT: every rank ends with the OR of all ranks' buffers
+    world = 3
+    port = 27000 + os.getpid() % 2000
+    mp.spawn(_or_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    for n in (1, 7, 4096, 10001):
+        want = np.zeros(n, np.int64)
+        for r in range(world):
+            want |= np.load(tmp_path / ("in_%d_%d.npy" % (n, r)))
+        for r in range(world):
+            assert np.array_equal(np.load(tmp_path / ("or_%d_%d.npy" % (n, r))), want)

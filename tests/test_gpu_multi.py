@@ -76,13 +76,15 @@ def _hip_worker(rank, world, port, out):
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from pansim_amd.distributed import ShardedSimulation
-    s = ShardedSimulation(rank, world, seed=21, n_gen=3, max_distances=900, device=0, **_MP_KW)
+    s = ShardedSimulation(rank, world, seed=21, n_gen=3, max_distances=900, device=0, shard_hgt_donors=True, **_MP_KW)
     s.run(3)
+    assert s.exchange is not None and s.exchange.calls == 3 and s.exchange.error is None
     agree = s.parents_agree()
     core, acc = s.final_distances()
     np.save(os.path.join(out, "core_%d.npy" % rank), core)
     np.save(os.path.join(out, "acc_%d.npy" % rank), acc)
     np.save(os.path.join(out, "shard_%d.npy" % rank), s.sim.core_genome.read_matrix())
+    np.save(os.path.join(out, "accm_%d.npy" % rank), s.sim.pan_genome.read_matrix())
     open(os.path.join(out, "agree_%d" % rank), "w").write(str(int(agree)))
     s.close()
     dist.destroy_process_group()
@@ -111,6 +113,7 @@ def test_two_processes_with_the_hip_engine(pa, orc, tmp_path):
         assert (tmp_path / ("agree_%d" % r)).read_text() == "1"
         assert np.array_equal(np.load(tmp_path / ("core_%d.npy" % r)), want_core)
         assert np.array_equal(np.load(tmp_path / ("acc_%d.npy" % r)), want_acc)
+        assert np.array_equal(np.load(tmp_path / ("accm_%d.npy" % r)), full.acc)      # donor-sharded HGT + OR exchange over gloo
 
 
 @pytest.mark.parametrize("kw,n_shards", [
@@ -135,3 +138,64 @@ def test_multi_edge_shapes(pa, orc, kw, n_shards):
     want_acc = orc.pairwise_distances(ref.acc, False, kw["core_genes"], r1, r2)
     assert np.array_equal(acc_d, want_acc, equal_nan=True)
     multi.close()
+
+
+@pytest.mark.parametrize("N,G,K,mode", [(50, 300, 2, 1), (130, 1000, 3, 2), (700, 4000, 8, 1), (2500, 4000, 5, 2), (2500, 300, 7, 0)])
+def test_hgt_donor_shards_union_is_the_unsharded_result(pa, orc, N, G, K, mode):
+    # HGT events are keyed per donor and ORed into the recipient (population.rs:599, :632): the union of the K donor
+    # shards' results is the unsharded result, in both kernel forms.  (No exchange hook here: every handle applies its
+    # own donors' events to its copy of the same matrix; ps_multi / distributed.py supply the exchange.)
+    rng = np.random.default_rng(N + G + K)
+    a = (rng.random((N, G)) < 0.3).astype(np.uint8)
+    g1 = G * 9 // 10
+    cb, ce, lr = [0, g1], [g1, G], [40.0, 6.5]
+    seed, gen = 77, 12
+    want = a.copy()
+    orc.recombine_acc(want, seed, gen, cb, ce, lr)
+    union = a.copy()
+    for r in range(K):
+        acc = pa.Population(N, G, 2, False, 0.3, seed, 0)
+        acc.set_tuning("hgt_mode", mode)
+        acc.set_rates([0.0, 0.0], lr, cb, ce)
+        acc.load_matrix(a)
+        acc.set_donor_shard(r, K)
+        acc.recombine(gen)
+        got = acc.read_matrix()
+        assert (got >= a).all()                      # gain only
+        union |= got
+        if K > 1:
+            assert not np.array_equal(got, want) or N < 10
+        acc.close()
+    assert np.array_equal(union, want)
+
+
+@pytest.mark.parametrize("env", [{}, {"PANSIM_MULTI_REPLICATED_HGT": "1"}, {"PANSIM_HEAVY_HGT": "1", "PANSIM_HGT_MODE": "2"},
+                                 {"PANSIM_HEAVY_HGT": "1", "PANSIM_HGT_MODE": "1"}])
+def test_multi_donor_sharded_hgt_forms(pa, orc, env):
+    # ps_multi with the HGT donors sharded over the shards and the deltas ORed between them (default), against the
+    # replicated form and in both HGT kernel forms / schedules: always the unsharded oracle run
+    from orc_sim import OracleSim
+    kw = dict(pop_size=300, core_size=900, pan_genes=700, core_genes=100, HR_rate=0.2, HGT_rate=0.6)
+    old = {k: os.environ.get(k) for k in ("PANSIM_MULTI_REPLICATED_HGT", "PANSIM_HEAVY_HGT", "PANSIM_HGT_MODE")}
+    try:
+        for k in old:
+            os.environ.pop(k, None)
+        os.environ.update(env)
+        ref = OracleSim(seed=5, **kw)
+        multi = pa.MultiSimulation(pa.make_params(seed=5, n_gen=4, max_distances=200, **kw), 3, devices=[0, 0, 0])
+        multi.run(4)
+        multi.sync()
+        for g in range(4):
+            ref.generation(g)
+        assert np.array_equal(np.concatenate([s.core_genome.read_matrix() for s in multi.shards], axis=1), ref.core)
+        for s in multi.shards:
+            assert np.array_equal(s.pan_genome.read_matrix(), ref.acc)
+            assert np.array_equal(s.last_parents(), ref.last_idx)
+        calls = [s.exchange_stats()[0] for s in multi.shards]
+        assert calls == ([0, 0, 0] if "PANSIM_MULTI_REPLICATED_HGT" in env else [4, 4, 4])
+        multi.close()
+    finally:
+        for k, v in old.items():
+            os.environ.pop(k, None)
+            if v is not None:
+                os.environ[k] = v
