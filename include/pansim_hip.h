@@ -179,6 +179,9 @@ int ps_sync(ps_population *p);
  * "hgt_mode" (accessory recombination: 0 = choose, 1 = one atomic per event, 2 = two passes: bin
  * by recipient partition, OR in LDS images), "hgt_slices" (binned HGT: event slices, 0 = choose), "hgt_list_in_global" (0/1: donor gene lists in
  * global scratch instead of LDS; "hgt_bin_list_in_global": the same for the bin pass of the binned form),
+ * "hgt_bin_cap" (tests: the bins of the binned HGT hold at most this many events; the rest take the overflow image),
+ * "sweep_queue_cap" (tests: the sweeps treat their candidate queues and HR lists as this short, so that the queue-free
+ * redo of a batch / row group -- what a full queue falls back to -- runs; 0 = real size),
  * "sweep_out_of_place" (core sweeps: -1 = choose, 0 = update the matrix in place, 1 = write the new generation to a second
  * buffer that then swaps roles with the first, 2 = the same with nontemporal row loads and stores; results are identical),
  * "lds_limit" (bytes of LDS a workgroup may use), "block_waves" (block sweep: waves per

@@ -167,6 +167,7 @@ struct acc_hgt_args {
     uint32_t parts, rows_per_part;
     uint32_t part_magic;           // floor(2^32 / rows_per_part) + 1: rc / rows_per_part = mulhi(rc, magic) for rc < 2^16
     uint32_t *scratch;             // slice images [n_slices][N][2*GW]
+    unsigned long long *ovf_img;   // binned form: one more image, all zero between launches, for the events of a full bin
     uint32_t *overflow_flag;
     uint16_t *list_scratch;        // null: donor lists in LDS; else [grid][list_stride] in global memory
     uint32_t list_stride;
@@ -312,13 +313,14 @@ __global__ void __launch_bounds__(256) acc_hgt_donor_bin_kernel(acc_hgt_args a)
             const uint32_t part = ps_mulhi(rc, a.part_magic);           // rc / rows_per_part
             const uint32_t pos = atomicAdd(&fill[part], 1u);
             if (pos < cap) mybins[(uint64_t)part * cap + pos] = ((rc - part * a.rows_per_part) << 16) | gene;
+            // a full bin (sized for mean + 10 sigma) drops nothing: the event goes to the overflow image, which the reduce
+            // pass ORs in like one more slice image and clears again
+            else atomicOr(&a.ovf_img[(uint64_t)rc * d.GW + (gene >> 6)], 1ull << (gene & 63u));
         }
     }
     __syncthreads();
     for (uint32_t q = tid; q < a.parts; q += blockDim.x) {
-        uint32_t f = fill[q];
-        if (f > cap) { atomicOr(a.overflow_flag, 8u); f = cap; }
-        a.counts[(uint64_t)blockIdx.x * a.parts + q] = f;
+        a.counts[(uint64_t)blockIdx.x * a.parts + q] = min(fill[q], cap);
     }
 }
 
@@ -362,11 +364,12 @@ __global__ void __launch_bounds__(1024) acc_hgt_apply_kernel(acc_hgt_args a, uin
 // dstI |= OR over the slice images written by acc_hgt_apply_kernel (scratch[slice][N][GW] u64); `assign`: dstI = that
 // OR (the delta buffer of a donor-sharded run, merged into the matrix after the exchange)
 __global__ void __launch_bounds__(256) acc_hgt_reduce_kernel(const uint64_t *scratch, uint64_t *dstI, uint64_t words,
-                                                             uint32_t n_slices, int assign)
+                                                             uint32_t n_slices, int assign, unsigned long long *ovf_img)
 {
     const uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (w >= words) return;
-    uint64_t v = 0;
+    uint64_t v = ovf_img[w];            // events of full bins (all zero unless a bin overflowed); left zero for the next launch
+    if (v) ovf_img[w] = 0ull;
     for (uint32_t sl = 0; sl < n_slices; sl++) v |= scratch[(uint64_t)sl * words + w];
     if (assign) dstI[w] = v;
     else if (v) dstI[w] |= v;

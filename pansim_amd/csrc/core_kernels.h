@@ -29,6 +29,7 @@ struct core_sweep_args {
     uint32_t *work_ctr;        // wave sweep: 2 x 8 chunk counters, 128 bytes apart
     uint32_t launch_parity;    // which counter set this launch uses
     uint32_t nt;               // out-of-place form: nontemporal row loads / stores (every byte is touched once per launch)
+    uint32_t qcap_limit;       // tests: pretend the candidate queues / HR lists hold only this many entries (0 = their real size)
 };
 
 typedef uint32_t ps_u32x4 __attribute__((ext_vector_type(4)));
@@ -404,11 +405,50 @@ __global__ void __launch_bounds__(256, PS_ROWS >= 4 ? 6 : 8) core_sweep_wave_ker
         PS_T(3);   // queue push
         ps_wave_sync();
 
-        if (events) {
-            if (qn > PS_QCAP) {
-                if (lane == 0) atomicOr(a.overflow_flag, 1u);
-                qn = PS_QCAP;
+        // Queue overflow (the host sizes the queue for mean + 10 sigma of the candidate count, so this is a
+        // once-in-the-age-of-the-universe event at the rates it admits -- and every batch under the test hook
+        // `sweep_queue_cap`): nothing is dropped; the batch is redone by the queue-free method of
+        // core_sweep_inline_kernel, every candidate handled by its owner lane.
+        const uint32_t qcap = a.qcap_limit ? min(PS_QCAP, a.qcap_limit) : PS_QCAP;
+        if (events && qn > qcap) {
+#pragma unroll 1
+            for (uint32_t rr = 0; rr < PS_ROWS; rr++) {
+                uint8_t *row = rowbuf + rr * 1024u;
+                const uint32_t site = a.site_offset + min(r0 + rr, a.rows - 1u);
+                const ps_u4 l1r = ps_philox(site, lane, a.gen, PS_STREAM_CORE_L1, a.k0, a.k1);
+                uint32_t cmr = ps_candidates_swar(l1r, c4) & vperm;
+                uint32_t hm = 0;
+                while (cmr) {
+                    const uint32_t p = __builtin_ctz(cmr);
+                    cmr &= cmr - 1u;
+                    const uint32_t k = 4u * (7u - (p & 7u)) + (p >> 3), cellidx = i0 + k;
+                    const ps_u4 l2 = ps_philox(site, cellidx, a.gen, PS_STREAM_CORE_L2, a.k0, a.k1);
+                    const ps_cell cell = ps_classify((ps_l1_byte(l1r, k) << 24) | (l2.x >> 8), pl);
+                    if (DO_MUT && cell.mut) row[cellidx] = (uint8_t)cell.mut;       // (a STASH nibble goes with the old byte)
+                    if (DO_HR && cell.hr) hm |= 1u << k;
+                }
+                if (DO_HR) {
+                    ps_wave_sync();       // the row is the post-mutation snapshot (population.rs:693-695)
+                    uint32_t dv[4] = { 0u, 0u, 0u, 0u };
+                    for (uint32_t tmp = hm; tmp;) {
+                        const uint32_t k = __builtin_ctz(tmp), cellidx = i0 + k;
+                        tmp &= tmp - 1u;
+                        const ps_u4 l2 = ps_philox(site, cellidx, a.gen, PS_STREAM_CORE_L2, a.k0, a.k1);
+                        uint32_t donor = ps_mulhi(l2.y, a.N - 1u);
+                        donor += (donor >= cellidx) ? 1u : 0u;                       // population.rs:618
+                        ps_set_byte(dv, k, (uint32_t)row[donor] & (STASH ? 15u : 255u));
+                    }
+                    ps_wave_sync();       // all donor reads are done
+                    for (uint32_t tmp = hm; tmp;) {
+                        const uint32_t k = __builtin_ctz(tmp);
+                        tmp &= tmp - 1u;
+                        row[i0 + k] = (uint8_t)((dv[k >> 2] >> (8u * (k & 3u))) & 0xFFu);
+                    }
+                }
             }
+            ps_wave_sync();
+        } else
+        if (events) {
             // dense pass: a candidate whose byte lies strictly inside one "mutate only"
             // interval is decided by the byte; the others are compacted in place to the
             // front of the queue (the write index never passes the read index)
@@ -534,6 +574,7 @@ struct core_block_geom {
     uint32_t QW;       // candidate queue entries per wave (one batch of PS_SB segments)
     uint32_t HW;       // HR list entries per wave (one row group)
     uint32_t SB;       // segments per wave batch (template parameter PS_SB: 4, or 2 when LDS is short)
+    uint32_t ovf_off;  // LDS byte offset of the workgroup's "a queue or an HR list was full" word (the last 4 bytes)
 };
 
 // mask (in the permuted bit order of ps_candidates_swar) of the cells i0 .. i0+15 that exist (< N)
@@ -564,6 +605,10 @@ __global__ void __launch_bounds__(1024) core_sweep_block_kernel(core_sweep_args 
 #endif
     const ps_core_plan pl = a.plan;
     constexpr bool events = DO_MUT || DO_HR;      // (the host launches these variants only for plans with events)
+    uint32_t *ovf = (uint32_t *)(lds + g.ovf_off);
+    // (the last entry of an HR list is never used: the last wave's holds the overflow word, see block_sweep_geometry)
+    const uint32_t qcap = a.qcap_limit ? min(g.QW, a.qcap_limit) : g.QW, hcap = a.qcap_limit ? min(g.HW - 1u, a.qcap_limit) : g.HW - 1u;
+    if (tid == 0) *ovf = 0u;        // (ordered before any use by the barrier that follows the first staging)
     const uint32_t c4 = (pl.bC + 1u) * 0x01010101u;
     const uint32_t t0b = pl.T[0] >> 24, t1b = pl.T[1] >> 24, t2b = pl.T[2] >> 24;
     unsigned long long lut = 0;     // 2-bit code per byte value < 32 (see the wave sweep)
@@ -747,9 +792,10 @@ __global__ void __launch_bounds__(1024) core_sweep_block_kernel(core_sweep_args 
             PS_T(2);   // push loop
             if (!events) continue;
             ps_wave_sync();
-            if (qn > g.QW) {
-                if (lane == 0) atomicOr(a.overflow_flag, 2u);
-                qn = g.QW;
+            if (qn > qcap) {
+                // nothing is dropped: the whole row group is redone below by the queue-free method
+                if (lane == 0) *ovf = 1u;
+                continue;
             }
             // dense pass: byte-decided mutations; the others compacted in place
             uint32_t n2 = 0;
@@ -814,7 +860,7 @@ __global__ void __launch_bounds__(1024) core_sweep_block_kernel(core_sweep_args 
                     const uint64_t bal = __ballot(hr);
                     if (hr) {
                         const uint32_t pos = nhr + ps_lane_prefix(bal);
-                        if (pos < g.HW) { hr_a[pos] = off; hr_b[pos] = rbase + donor; }
+                        if (pos < hcap) { hr_a[pos] = off; hr_b[pos] = rbase + donor; }
                     }
                     nhr += (uint32_t)__popcll(bal);
                 }
@@ -822,12 +868,82 @@ __global__ void __launch_bounds__(1024) core_sweep_block_kernel(core_sweep_args 
             ps_wave_sync();
         }
         PS_T(4);   // exact pass
-        if (DO_HR && events) {
-            if (nhr > g.HW) {
-                if (lane == 0) atomicOr(a.overflow_flag, 4u);
-                nhr = g.HW;
-            }
-            ps_block_sync_lds();    // every segment is mutated: rowS is the snapshot (population.rs:693-695)
+        bool redo = false;
+        if (events) {
+            if (DO_HR && nhr > hcap && lane == 0) *ovf = 1u;
+            ps_block_sync_lds();    // every segment is mutated: rowS is the snapshot (population.rs:693-695); *ovf is final
+            redo = *ovf != 0u;      // workgroup-uniform
+        }
+        if (events && redo) {
+            // A candidate queue or an HR list of this row group was full (the host sizes them for mean + 10 sigma, so
+            // in production never; under the test hook `sweep_queue_cap` all the time).  Nothing is dropped: the row group
+            // is redone by the queue-free method of core_sweep_inline_kernel -- every candidate handled by its owner
+            // lane, HR cells remembered in a 16-bit mask per chunk (in the now dead queue memory), donors read from the
+            // post-mutation snapshot in LDS, the final bytes stored straight to global memory.
+            uint16_t *hrm = (uint16_t *)(lds + (DO_GATHER ? 2u : 1u) * g.R * a.pitch);
+            auto for_chunks = [&](auto fn) {
+                for (uint32_t item0 = wave * PS_SB; item0 < items; item0 += nw * PS_SB)
+                    for (uint32_t s = 0; s < PS_SB; s++) {
+                        const uint32_t item = item0 + s;
+                        if (item >= items) break;
+                        const uint32_t rr = item / g.segs, chunk = (item % g.segs) * 64u + lane;
+                        if (chunk < a.cpr) fn(rr, chunk);
+                    }
+            };
+            for_chunks([&](uint32_t rr, uint32_t chunk) {
+                const uint32_t site = a.site_offset + r0 + rr, i0 = chunk * 16u;
+                uint8_t *row = rowS + rr * a.pitch;
+                uint32_t d[4];
+                if (DO_GATHER) {
+                    const uint8_t *par = rowA + rr * a.pitch;
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        uint32_t w = 0;
+#pragma unroll
+                        for (int b = 0; b < 4; b++) {
+                            const uint32_t i = i0 + 4 * j + b;
+                            w |= ((i < a.N) ? (uint32_t)par[a.idx[i]] : 0u) << (8 * b);
+                        }
+                        d[j] = w;
+                    }
+                } else {
+                    // the row itself: cells already mutated keep their (identical) value; STASH nibbles are dropped
+                    const uint4 cur = ps_strip(*(const uint4 *)(row + i0), STASH);
+                    d[0] = cur.x; d[1] = cur.y; d[2] = cur.z; d[3] = cur.w;
+                }
+                const ps_u4 l1 = ps_philox(site, chunk, a.gen, PS_STREAM_CORE_L1, a.k0, a.k1);
+                uint32_t cm = ps_candidate_mask(l1, pl.bC), hm = 0;
+                while (cm) {
+                    const uint32_t k = __builtin_ctz(cm);
+                    cm &= cm - 1u;
+                    const uint32_t i = i0 + k;
+                    if (i >= a.N) continue;
+                    const ps_u4 l2 = ps_philox(site, i, a.gen, PS_STREAM_CORE_L2, a.k0, a.k1);
+                    const ps_cell cell = ps_classify((ps_l1_byte(l1, k) << 24) | (l2.x >> 8), pl);
+                    if (DO_MUT && cell.mut) ps_set_byte(d, k, cell.mut);
+                    if (DO_HR && cell.hr) hm |= 1u << k;
+                }
+                *(uint4 *)(row + i0) = make_uint4(d[0], d[1], d[2], d[3]);
+                hrm[rr * a.cpr + chunk] = (uint16_t)hm;
+            });
+            ps_block_sync_lds();    // rowS is the post-mutation snapshot again, the masks are complete
+            for_chunks([&](uint32_t rr, uint32_t chunk) {
+                const uint32_t site = a.site_offset + r0 + rr, i0 = chunk * 16u;
+                const uint8_t *row = rowS + rr * a.pitch;
+                const uint4 v = *(const uint4 *)(row + i0);
+                uint32_t d[4] = { v.x, v.y, v.z, v.w };
+                for (uint32_t hm = hrm[rr * a.cpr + chunk]; hm;) {
+                    const uint32_t k = __builtin_ctz(hm), i = i0 + k;
+                    hm &= hm - 1u;
+                    const ps_u4 l2 = ps_philox(site, i, a.gen, PS_STREAM_CORE_L2, a.k0, a.k1);
+                    uint32_t donor = ps_mulhi(l2.y, a.N - 1u);
+                    donor += (donor >= i) ? 1u : 0u;                     // population.rs:618
+                    ps_set_byte(d, k, (uint32_t)row[donor]);             // snapshot read, :693-695
+                }
+                *(uint4 *)(a.out + (size_t)(r0 + rr) * a.pitch + i0) = make_uint4(d[0], d[1], d[2], d[3]);
+            });
+            if (tid == 0) *ovf = 0u;
+        } else if (DO_HR && events) {
             for (uint32_t e = lane; e < nhr; e += 64u) hr_b[e] = (uint32_t)rowS[hr_b[e]] & (STASH ? 15u : 255u);
             ps_block_sync_lds();    // all donor reads done
             for (uint32_t e = lane; e < nhr; e += 64u) rowS[hr_a[e]] = (uint8_t)hr_b[e];
@@ -853,7 +969,9 @@ __global__ void __launch_bounds__(1024) core_sweep_block_kernel(core_sweep_args 
         {
             uint8_t *dstg = a.out + (size_t)r0 * a.pitch;
             const uint32_t nbytes = nr * a.pitch;
-            if (pipelined) {
+            if (redo) {
+                // (the redo pass has stored the row group itself)
+            } else if (pipelined) {
                 // at most PS_PF pieces per thread: the LDS reads together, then the stores
                 uint4 o0 = make_uint4(0, 0, 0, 0), o1 = o0, o2 = o0, o3 = o0;
                 if (po0 < nbytes) o0 = ps_strip(*(const uint4 *)(rowS + po0), STASH && events);

@@ -197,6 +197,8 @@ struct ps_population {
     uint64_t *I[2] = { nullptr, nullptr };
     uint32_t *d_ptab[PS_MAX_COMP] = {};  // Poisson threshold tables of the HGT event counts (ps_set_rates)
     uint32_t ptab_kmin[PS_MAX_COMP] = {}, ptab_len[PS_MAX_COMP] = {};
+    void *hgt_ovf_img = nullptr;         // binned HGT: image of the events that met a full bin (zero between launches)
+    uint32_t hgt_bin_cap = 0;            // tests: bins of the binned HGT hold at most this many events (0 = sized for mean + 10 sigma)
     void *hgt_scratch = nullptr;         // slice images of the LDS-partitioned HGT kernel
     uint64_t hgt_scratch_cap = 0;
     uint32_t hgt_slices = 0;             // tuning: event slices of the LDS-partitioned HGT kernel (0 = choose)
@@ -243,6 +245,7 @@ struct ps_population {
     uint32_t block_waves = 0;           // block sweep: waves per workgroup (0 = auto: 4, 8 or 16)
     bool no_block_preload = false;      // tests: block sweep reads its parent indices per batch
     uint32_t block_batch = 0;           // block sweep: segments per wave batch (0 = 4, falling back to 2; 2 = force 2)
+    uint32_t sweep_queue_cap = 0;       // tests: the sweeps treat their candidate queues / HR lists as this short (0 = real size)
     uint32_t *h_flag = nullptr, *d_flag = nullptr;   // host-mapped sticky device error word
     unsigned long long *h_stamps = nullptr, *d_stamps = nullptr;   // diagnostic phase stamps
 };
@@ -258,7 +261,7 @@ extern "C" void ps_population_destroy(ps_population *p)
     if (!p) return;
     (void)hipSetDevice(p->device);
     if (p->stream) (void)hipStreamSynchronize(p->stream);
-    void *ptrs[] = { p->state, p->state2, p->d_delta, p->G[0], p->G[1], p->I[0], p->I[1], p->d_ptab[0], p->d_ptab[1], p->hgt_scratch, p->cnt, p->d_idx, p->d_idxT, p->d_work,
+    void *ptrs[] = { p->state, p->state2, p->d_delta, p->hgt_ovf_img, p->G[0], p->G[1], p->I[0], p->I[1], p->d_ptab[0], p->d_ptab[1], p->hgt_scratch, p->cnt, p->d_idx, p->d_idxT, p->d_work,
                      p->d_log1p, p->d_num_genes, p->d_logw, p->d_pairs, p->d_H, p->d_Dt, p->d_pack2, p->d_pair_part };
     for (void *q : ptrs)
         if (q) (void)hipFree(q);
@@ -396,8 +399,7 @@ extern "C" int ps_init_vector(uint64_t seed, int core, uint64_t col_offset, uint
 static int check_device_flag(ps_population *p)
 {
     if (p->h_flag && *p->h_flag != 0)
-        return ps_fail(PS_ERR_STATE, "a device queue overflowed (flag %u: 1 sweep wave queue, 2 sweep block queue, 4 HR list, 8 HGT bin): results are invalid",
-                       *p->h_flag);
+        return ps_fail(PS_ERR_STATE, "a device error flag is set (%u)", *p->h_flag);
     return PS_OK;
 }
 
@@ -446,6 +448,12 @@ extern "C" int ps_set_tuning(ps_population *p, const char *key, int64_t value)
     } else if (k == "block_batch") {
         if (value != 0 && value != 2 && value != 4) return ps_fail(PS_ERR_INVALID, "block_batch must be 0 (choose), 2 or 4");
         p->block_batch = (uint32_t)value;
+    } else if (k == "hgt_bin_cap") {
+        if (value < 0 || value > (1 << 30)) return ps_fail(PS_ERR_INVALID, "hgt_bin_cap must be 0 (sized by the rates)..2^30");
+        p->hgt_bin_cap = (uint32_t)value;
+    } else if (k == "sweep_queue_cap") {
+        if (value < 0 || value > 65536) return ps_fail(PS_ERR_INVALID, "sweep_queue_cap must be 0 (real size)..65536");
+        p->sweep_queue_cap = (uint32_t)value;
     } else if (k == "hgt_list_in_global") {
         p->hgt_list_in_global = value != 0;
     } else if (k == "hgt_bin_list_in_global") {
@@ -659,7 +667,14 @@ static bool block_sweep_geometry(const ps_population *p, bool ga, bool mu, bool 
             const double mh = (double)batches_per_wave * SB * 1024.0 * hr_frac;
             g->R = R;
             g->HW = std::max(16u, up16(mh + 10.0 * std::sqrt(mh) + 16.0));
-            *lds = (ga ? 2u : 1u) * R * p->pitch + nw * (g->QW + 2u * g->HW) * 4u;
+            // queues and HR lists of the waves; the same memory holds the 16-bit HR mask per chunk when a full queue makes
+            // the workgroup redo a row group by the queue-free method; then the workgroup's overflow word
+            // (at N = 65536 two 64 KB rows + 16 x 2 KB of queues are exactly the CU's 160 KB: the overflow word takes the last
+            // entry of the last wave's HR list -- the kernel uses HW - 1 entries per list -- not 16 bytes of its own)
+            const uint32_t rows_bytes = (ga ? 2u : 1u) * R * p->pitch;
+            const uint32_t scratch = (std::max(nw * (g->QW + 2u * g->HW) * 4u, R * p->cpr * 2u + 16u) + 15u) & ~15u;
+            g->ovf_off = rows_bytes + scratch - 4u;
+            *lds = rows_bytes + scratch;
             if (*lds <= p->lds_limit) return true;
             if (R == 1) break;
         }
@@ -775,6 +790,7 @@ static int launch_core_sweep(ps_population *p, const uint32_t *d_idx, uint32_t g
         }
     }
     a.overflow_flag = p->d_flag;
+    a.qcap_limit = p->sweep_queue_cap;
     a.stamps = p->d_stamps;
     a.work_ctr = p->d_work;
     a.launch_parity = (uint32_t)(p->sweep_launches++ & 1u);
@@ -912,7 +928,8 @@ static int launch_acc_hgt(ps_population *p, uint32_t gen, hipStream_t st, hipEve
         for (int c = 0; c < p->aplan.n_comp; c++)
             if (a.ptab[c]) per_block += p->aplan.lam_rec[c] * (double)((a.dn_cnt + donor_blocks - 1) / donor_blocks);
         const double mean = per_block * (double)rows_per_part / (double)(p->d.N - 1);
-        const uint32_t cap = (uint32_t)(((uint64_t)(mean + 10.0 * std::sqrt(mean) + 64.0) + 63) & ~63ull);
+        uint32_t cap = (uint32_t)(((uint64_t)(mean + 10.0 * std::sqrt(mean) + 64.0) + 63) & ~63ull);
+        if (p->hgt_bin_cap) cap = std::min(cap, std::max(1u, p->hgt_bin_cap));
         const uint64_t bin_words = (uint64_t)donor_blocks * parts * cap;
         const uint64_t cnt_bytes = ((uint64_t)donor_blocks * parts * 4 + 255) & ~255ull;
         // (measured at the cfg4 population: the bin pass running beside the block sweep this way makes the generation
@@ -926,6 +943,12 @@ static int launch_acc_hgt(ps_population *p, uint32_t gen, hipStream_t st, hipEve
             HIPCHK(hipMalloc(&p->hgt_scratch, need));
             p->hgt_scratch_cap = need;
         }
+        if (!p->hgt_ovf_img) {
+            // the overflow image of the bin pass: zero now, and left zero by every reduce pass
+            HIPCHK(hipMalloc(&p->hgt_ovf_img, words * 8));
+            HIPCHK(hipMemsetAsync(p->hgt_ovf_img, 0, words * 8, st));
+        }
+        a.ovf_img = (unsigned long long *)p->hgt_ovf_img;
         a.scratch = (uint32_t *)p->hgt_scratch;
         a.bins = (uint32_t *)((uint8_t *)p->hgt_scratch + img_bytes);
         a.counts = (uint32_t *)((uint8_t *)p->hgt_scratch + img_bytes + bin_words * 4);
@@ -952,7 +975,7 @@ static int launch_acc_hgt(ps_population *p, uint32_t gen, hipStream_t st, hipEve
         hipLaunchKernelGGL(kern, dim3(parts * n_slices), dim3(1024), lds, st, a, donor_blocks, n_slices);
         acc_hgt_reduce_kernel<<<(uint32_t)((words + 255) / 256), 256, 0, st>>>((const uint64_t *)p->hgt_scratch,
                                                                               sharded ? p->d_delta : p->I[p->cur], words, n_slices,
-                                                                              sharded ? 1 : 0);
+                                                                              sharded ? 1 : 0, (unsigned long long *)p->hgt_ovf_img);
     } else {
         a.srcI = p->I[1 - p->cur];          // the snapshot written by acc_hgt_counts_kernel
         a.dstI = sharded ? p->d_delta : p->I[p->cur];

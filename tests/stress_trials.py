@@ -58,6 +58,8 @@ def run(trials, seed=1, log=print):
             acc.set_tuning("lds_limit", int(min(160 * 1024, max(1024 + int(rng.integers(2, 40)) * row_bytes, 2 * G + 8192))))
         if rng.random() < 0.3:
             acc.set_tuning("hgt_slices", int(rng.integers(1, 9)))
+        if rng.random() < 0.25:
+            acc.set_tuning("hgt_bin_cap", int(rng.choice([1, 5, 64])))        # full bins: the overflow image
         acc.set_rates([0.0] * len(comps), lr, cb, ce)
         acc.load_matrix(a)
         acc.recombine(gen)
@@ -98,6 +100,8 @@ def run(trials, seed=1, log=print):
             tune["force_inline_sweep"] = 1
         if rng.random() < 0.5:
             tune["sweep_out_of_place"] = int(rng.integers(-1, 3))
+        if rng.random() < 0.25:
+            tune["sweep_queue_cap"] = int(rng.choice([1, 8, 32, 100]))      # full queues: the queue-free redo path
         if rng.random() < 0.3:
             tune["sweep_rows"] = int(rng.integers(2, 5))
             tune["sweep_blocks_per_cu"] = int(rng.integers(1, 9))

@@ -642,6 +642,64 @@ def test_sweeps_carry_bytes_above_15(pa, orc, N, L, tune):
     pop.close()
 
 
+@pytest.mark.parametrize("N,L,tune", [(1000, 60, {}), (1000, 45, {"sweep_rows": 2}), (1000, 33, {"sweep_rows": 4}),
+                                      (3000, 40, {}), (1000, 50, {"force_block_sweep": 1}), (9000, 24, {"block_batch": 2}),
+                                      (9000, 20, {"no_block_preload": 1}), (5000, 40, {"block_waves": 4}),
+                                      (20000, 6, {}), (1500, 30, {"sweep_out_of_place": 1, "force_block_sweep": 1})])
+@pytest.mark.parametrize("ops", ["step", "calls"])
+def test_full_queues_fall_back_to_the_queue_free_redo(pa, orc, N, L, tune, ops):
+    # A full candidate queue or HR list must not drop events (round 2: a sticky PS_ERR_STATE with the matrix already
+    # modified): the wave redoes its batch / the workgroup its row group by the queue-free method.  `sweep_queue_cap`
+    # makes the kernels treat their queues as 8 entries long, so the redo path runs for (nearly) every batch.
+    rng = np.random.default_rng(N * 7 + L)
+    m0 = _rand_core(rng, N, L)
+    sample = rng.integers(0, N, N).astype(np.uint32)
+    LG = 1200000
+    lm, lh = 0.05 * LG, 0.02 * LG
+    plan = orc.core_plan(lm, lh, LG)
+    want = orc.next_generation(m0, sample)
+    orc.mutate_core(want, 7, 3, 11, plan)
+    orc.recombine_core(want, 7, 3, 11, plan)
+    pop = pa.Population(N, L, 4, True, 0.0, 3, 0, col_offset=7, global_cols=LG)
+    for k, v in tune.items():
+        pop.set_tuning(k, v)
+    pop.set_tuning("sweep_queue_cap", 8)
+    pop.set_rates([lm], [lh])
+    pop.load_matrix(m0)
+    if ops == "step":
+        pop.step(11, sample, True)
+    else:
+        pop.next_generation(sample)
+        pop.mutate_alleles(11)
+        pop.recombine(11)
+    assert np.array_equal(pop.read_matrix(), want)
+    pop.close()
+
+
+@pytest.mark.parametrize("N,G,cap", [(700, 1000, 1), (2500, 4000, 7), (130, 300, 3)])
+def test_full_hgt_bins_take_the_overflow_image(pa, orc, N, G, cap):
+    # binned HGT with bins far too small for the events: nothing may be dropped (population.rs:544-751, accessory path)
+    rng = np.random.default_rng(N + G)
+    a = (rng.random((N, G)) < 0.3).astype(np.uint8)
+    cb, ce, lr = [0, G // 2], [G // 2, G], [60.0, 9.0]
+    for gen in (4, 5):                      # twice: the overflow image must be clean again for the second launch
+        want = a.copy()
+        orc.recombine_acc(want, 31, gen, cb, ce, lr)
+        acc = pa.Population(N, G, 2, False, 0.3, 31, 0)
+        acc.set_tuning("hgt_mode", 2)
+        acc.set_tuning("hgt_bin_cap", cap)
+        acc.set_rates([0.0, 0.0], lr, cb, ce)
+        acc.load_matrix(a)
+        acc.recombine(gen)
+        mid = acc.read_matrix()
+        assert np.array_equal(mid, want)
+        want2 = mid.copy()
+        orc.recombine_acc(want2, 31, gen + 10, cb, ce, lr)
+        acc.recombine(gen + 10)
+        assert np.array_equal(acc.read_matrix(), want2)
+        acc.close()
+
+
 # ----------------------------------------------------------------------------- BASELINE full sizes
 def _crc(a):
     import zlib
