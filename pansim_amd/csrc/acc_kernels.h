@@ -475,31 +475,8 @@ __global__ void acc_pair_counts_kernel(const uint64_t *accI, const uint32_t *r1,
     uni[o] = un;
 }
 
-// population.rs:753-784 on the accessory matrix: mean Jaccard distance of i to all
-// others, summed in ascending j like the reference's fold (:770).
-__global__ void acc_average_distance_kernel(const uint64_t *accI, double *out, acc_dims d,
-                                            double core_genes)
-{
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= d.N) return;
-    const uint64_t *x = accI + (uint64_t)i * d.GW;
-    double sum = 0.0;
-    for (uint32_t j = 0; j < d.N; j++) {
-        if (j == i) continue;
-        const uint64_t *y = accI + (uint64_t)j * d.GW;
-        uint32_t in = 0, un = 0;
-        for (uint32_t gw = 0; gw < d.GW; gw++) {
-            in += __popcll(x[gw] & y[gw]);
-            un += __popcll(x[gw] | y[gw]);
-        }
-        const double pd = 1.0 - (((double)in + 0.0 + core_genes) / ((double)un + 0.0 + core_genes));
-        sum = sum + pd;
-    }
-    double fd = sum / (double)(d.N - 1u);
-    if (fd == 0.0) fd = 2.2250738585072014e-308;   // f64::MIN_POSITIVE, population.rs:774-776
-    out[i] = fd;
-}
-
+// D-avg, population.rs:753-784 on the accessory matrix: mean Jaccard distance of i to all others, summed in ascending j
+// like the reference's fold (:770).
 // D-avg in two steps for populations whose N x N distance matrix fits in memory:
 // (1) every pair's Jaccard distance, written transposed (the distance is symmetric bit for bit),
 // (2) one thread per individual sums its column in ascending j -- the reference's left-to-right
@@ -517,11 +494,11 @@ __global__ void __launch_bounds__(256) acc_pair_matrix_tiled_kernel(const uint64
     if (bj < bi) return;
     const uint32_t tid = threadIdx.x, tx = tid & 15u, ty = tid >> 4;
     const uint32_t i0 = bi * 64u, j0 = bj * 64u;
-    uint32_t in[4][4], un[4][4];
+    uint32_t in[4][4], cx[4] = { 0, 0, 0, 0 }, cy[4] = { 0, 0, 0, 0 };
 #pragma unroll
     for (int a = 0; a < 4; a++)
 #pragma unroll
-        for (int b = 0; b < 4; b++) { in[a][b] = 0; un[a][b] = 0; }
+        for (int b = 0; b < 4; b++) in[a][b] = 0;
     for (uint32_t g0 = 0; g0 < d.GW; g0 += PS_PM_CH) {
         __syncthreads();
         for (uint32_t t = tid; t < 64u * PS_PM_CH; t += 256u) {
@@ -538,13 +515,15 @@ __global__ void __launch_bounds__(256) acc_pair_matrix_tiled_kernel(const uint64
             for (int a = 0; a < 4; a++) x[a] = TA[(ty + 16u * a) * (PS_PM_CH + 1u) + c];
 #pragma unroll
             for (int b = 0; b < 4; b++) y[b] = TB[(tx + 16u * b) * (PS_PM_CH + 1u) + c];
+            // |x u y| = |x| + |y| - |x n y|: only the intersections are counted per pair
+#pragma unroll
+            for (int a = 0; a < 4; a++) cx[a] += __popcll(x[a]);
+#pragma unroll
+            for (int b = 0; b < 4; b++) cy[b] += __popcll(y[b]);
 #pragma unroll
             for (int a = 0; a < 4; a++)
 #pragma unroll
-                for (int b = 0; b < 4; b++) {
-                    in[a][b] += __popcll(x[a] & y[b]);
-                    un[a][b] += __popcll(x[a] | y[b]);
-                }
+                for (int b = 0; b < 4; b++) in[a][b] += __popcll(x[a] & y[b]);
         }
     }
 #pragma unroll
@@ -553,11 +532,77 @@ __global__ void __launch_bounds__(256) acc_pair_matrix_tiled_kernel(const uint64
         for (int b = 0; b < 4; b++) {
             const uint32_t i = i0 + ty + 16u * a, j = j0 + tx + 16u * b;
             if (i < d.N && j < d.N) {
-                const double pd = 1.0 - (((double)in[a][b] + 0.0 + core_genes) / ((double)un[a][b] + 0.0 + core_genes));
+                const double pd = 1.0 - (((double)in[a][b] + 0.0 + core_genes) / ((double)(cx[a] + cy[b] - in[a][b]) + 0.0 + core_genes));
                 Dt[(uint64_t)i * d.N + j] = pd;
                 if (bi != bj) Dt[(uint64_t)j * d.N + i] = pd;
             }
         }
+}
+
+// D-avg for populations whose N x N matrix of doubles is too large to keep (N > 8192): workgroup = 64 individuals i,
+// all j in ascending tiles of 64.  Per tile the 64 x 64 Jaccard distances are counted from LDS tiles as in
+// acc_pair_matrix_tiled_kernel and parked in LDS; then one thread per i adds its 64 values in ascending j -- the
+// reference's left-to-right f64 fold (population.rs:770) is kept, only the counting is parallel.  (Round 2's
+// one-thread-per-individual kernel re-read all N rows per individual from L2.)
+__global__ void __launch_bounds__(256) acc_average_distance_tiled_kernel(const uint64_t *accI, double *out, acc_dims d,
+                                                                         double core_genes)
+{
+    __shared__ uint64_t TA[64u * (PS_PM_CH + 1u)], TB[64u * (PS_PM_CH + 1u)];
+    __shared__ double D[64u * 65u];
+    const uint32_t tid = threadIdx.x, tx = tid & 15u, ty = tid >> 4;
+    const uint32_t i0 = blockIdx.x * 64u;
+    double sum = 0.0;                                   // threads 0..63: running sum of individual i0 + tid
+    for (uint32_t j0 = 0; j0 < d.N; j0 += 64u) {
+        uint32_t in[4][4], cx[4] = { 0, 0, 0, 0 }, cy[4] = { 0, 0, 0, 0 };
+#pragma unroll
+        for (int a = 0; a < 4; a++)
+#pragma unroll
+            for (int b = 0; b < 4; b++) in[a][b] = 0;
+        for (uint32_t g0 = 0; g0 < d.GW; g0 += PS_PM_CH) {
+            __syncthreads();
+            for (uint32_t t = tid; t < 64u * PS_PM_CH; t += 256u) {
+                const uint32_t r = t / PS_PM_CH, c = t % PS_PM_CH;
+                const bool okc = g0 + c < d.GW;
+                TA[r * (PS_PM_CH + 1u) + c] = (okc && i0 + r < d.N) ? accI[(uint64_t)(i0 + r) * d.GW + g0 + c] : 0ull;
+                TB[r * (PS_PM_CH + 1u) + c] = (okc && j0 + r < d.N) ? accI[(uint64_t)(j0 + r) * d.GW + g0 + c] : 0ull;
+            }
+            __syncthreads();
+#pragma unroll 4
+            for (uint32_t c = 0; c < PS_PM_CH; c++) {
+                uint64_t x[4], y[4];
+#pragma unroll
+                for (int a = 0; a < 4; a++) x[a] = TA[(ty + 16u * a) * (PS_PM_CH + 1u) + c];
+#pragma unroll
+                for (int b = 0; b < 4; b++) y[b] = TB[(tx + 16u * b) * (PS_PM_CH + 1u) + c];
+                // |x u y| = |x| + |y| - |x n y|: only the intersections are counted per pair
+#pragma unroll
+                for (int a = 0; a < 4; a++) cx[a] += __popcll(x[a]);
+#pragma unroll
+                for (int b = 0; b < 4; b++) cy[b] += __popcll(y[b]);
+#pragma unroll
+                for (int a = 0; a < 4; a++)
+#pragma unroll
+                    for (int b = 0; b < 4; b++) in[a][b] += __popcll(x[a] & y[b]);
+            }
+        }
+#pragma unroll
+        for (int a = 0; a < 4; a++)
+#pragma unroll
+            for (int b = 0; b < 4; b++)
+                D[(ty + 16u * a) * 65u + tx + 16u * b] = 1.0 - (((double)in[a][b] + 0.0 + core_genes) / ((double)(cx[a] + cy[b] - in[a][b]) + 0.0 + core_genes));
+        __syncthreads();
+        if (tid < 64u) {
+            const uint32_t i = i0 + tid, jn = min(64u, d.N - j0);
+            for (uint32_t j = 0; j < jn; j++)
+                if (j0 + j != i) sum = sum + D[tid * 65u + j];
+        }
+        // (the next tile's first __syncthreads() orders these reads before D is rewritten)
+    }
+    if (tid < 64u && i0 + tid < d.N) {
+        double fd = sum / (double)(d.N - 1u);
+        if (fd == 0.0) fd = 2.2250738585072014e-308;    // f64::MIN_POSITIVE, population.rs:774-776
+        out[i0 + tid] = fd;
+    }
 }
 
 __global__ void __launch_bounds__(64) acc_average_from_matrix_kernel(const double *Dt, double *out, acc_dims d)

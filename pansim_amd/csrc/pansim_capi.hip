@@ -1300,8 +1300,8 @@ static int average_distance_device(ps_population *p, double *d_out, hipStream_t 
         acc_pair_matrix_tiled_kernel<<<dim3(nt, nt), 256, 0, st>>>(p->I[p->cur], p->d_Dt, p->d, (double)p->cfg.core_genes);
         acc_average_from_matrix_kernel<<<(uint32_t)((N + 63) / 64), 64, 0, st>>>(p->d_Dt, d_out, p->d);
     } else {
-        acc_average_distance_kernel<<<(uint32_t)((N + 63) / 64), 64, 0, st>>>(p->I[p->cur], d_out, p->d,
-                                                                         (double)p->cfg.core_genes);
+        acc_average_distance_tiled_kernel<<<(uint32_t)((N + 63) / 64), 256, 0, st>>>(p->I[p->cur], d_out, p->d,
+                                                                                (double)p->cfg.core_genes);
     }
     HIPCHK(hipGetLastError());
     return PS_OK;

@@ -19,7 +19,8 @@ for mode in (0, 1, 2):
     acc.set_rates([3600.0, 400000.0], [2700.0, 299.99999999999994], [0, 3600], [3600, 4000])
     res = {"N": N, "hgt_mode": mode}
     for name, fn in (("step(gather+mut)", lambda g: acc.step(g, idx, False)), ("recombine(HGT)", lambda g: acc.recombine(g)),
-                     ("fitness_terms", lambda g: acc.fitness_terms(np.zeros(G)))):
+                     ("fitness_terms", lambda g: acc.fitness_terms(np.zeros(G))),
+                     ("average_distance", lambda g: acc.average_distance())):
         for g in range(2):
             fn(g)
         acc.sync()
