@@ -539,6 +539,74 @@ __global__ void __launch_bounds__(256) acc_pair_matrix_tiled_kernel(const uint64
         }
 }
 
+// All-pairs Jaccard numerators for P > ~N^2 / 4 sampled pairs (cfg5: one thread per sampled pair re-read two 504-byte
+// rows per pair -- 34 GB of L2 traffic at P = 2^25, and slowed the core kernels beside it): the intersections of every
+// pair of a 64 x 64 tile from LDS tiles (as acc_pair_matrix_tiled_kernel, upper triangle only, both orders written) and
+// the row counts; the lookup takes |x u y| = |x| + |y| - |x n y| (distances.rs:55-77 counts both directly).
+__global__ void __launch_bounds__(256) acc_pair_inter_tiled_kernel(const uint64_t *accI, uint32_t *In, uint32_t *rowcnt, acc_dims d)
+{
+    __shared__ uint64_t TA[64u * (PS_PM_CH + 1u)], TB[64u * (PS_PM_CH + 1u)];
+    const uint32_t bi = blockIdx.y, bj = blockIdx.x;
+    if (bj < bi) return;
+    const uint32_t tid = threadIdx.x, tx = tid & 15u, ty = tid >> 4;
+    const uint32_t i0 = bi * 64u, j0 = bj * 64u;
+    uint32_t in[4][4], cx[4] = { 0, 0, 0, 0 };
+#pragma unroll
+    for (int a = 0; a < 4; a++)
+#pragma unroll
+        for (int b = 0; b < 4; b++) in[a][b] = 0;
+    for (uint32_t g0 = 0; g0 < d.GW; g0 += PS_PM_CH) {
+        __syncthreads();
+        for (uint32_t t = tid; t < 64u * PS_PM_CH; t += 256u) {
+            const uint32_t r = t / PS_PM_CH, c = t % PS_PM_CH;
+            const bool okc = g0 + c < d.GW;
+            TA[r * (PS_PM_CH + 1u) + c] = (okc && i0 + r < d.N) ? accI[(uint64_t)(i0 + r) * d.GW + g0 + c] : 0ull;
+            TB[r * (PS_PM_CH + 1u) + c] = (okc && j0 + r < d.N) ? accI[(uint64_t)(j0 + r) * d.GW + g0 + c] : 0ull;
+        }
+        __syncthreads();
+#pragma unroll 4
+        for (uint32_t c = 0; c < PS_PM_CH; c++) {
+            uint64_t x[4], y[4];
+#pragma unroll
+            for (int a = 0; a < 4; a++) x[a] = TA[(ty + 16u * a) * (PS_PM_CH + 1u) + c];
+#pragma unroll
+            for (int b = 0; b < 4; b++) y[b] = TB[(tx + 16u * b) * (PS_PM_CH + 1u) + c];
+#pragma unroll
+            for (int a = 0; a < 4; a++) cx[a] += __popcll(x[a]);
+#pragma unroll
+            for (int a = 0; a < 4; a++)
+#pragma unroll
+                for (int b = 0; b < 4; b++) in[a][b] += __popcll(x[a] & y[b]);
+        }
+    }
+#pragma unroll
+    for (int a = 0; a < 4; a++) {
+        const uint32_t i = i0 + ty + 16u * a;
+        if (bi == bj && tx == 0 && i < d.N) rowcnt[i] = cx[a];          // (every row block has its diagonal tile)
+#pragma unroll
+        for (int b = 0; b < 4; b++) {
+            const uint32_t j = j0 + tx + 16u * b;
+            if (i < d.N && j < d.N) {
+                In[(uint64_t)i * d.N + j] = in[a][b];
+                if (bi != bj) In[(uint64_t)j * d.N + i] = in[a][b];
+            }
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256) acc_pair_lookup_kernel(const uint32_t *In, const uint32_t *rowcnt, uint32_t N, const uint32_t *r1,
+                                                              const uint32_t *r2, const uint32_t *perm, uint64_t P, uint32_t *inter,
+                                                              uint32_t *uni)
+{
+    const uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= P) return;
+    const uint32_t i = r1[k], j = r2[k];
+    const uint32_t in = In[(uint64_t)i * N + j];
+    const uint64_t o = perm ? perm[k] : k;
+    inter[o] = in;
+    uni[o] = rowcnt[i] + rowcnt[j] - in;
+}
+
 // D-avg for populations whose N x N matrix of doubles is too large to keep (N > 8192): workgroup = 64 individuals i,
 // all j in ascending tiles of 64.  Per tile the 64 x 64 Jaccard distances are counted from LDS tiles as in
 // acc_pair_matrix_tiled_kernel and parked in LDS; then one thread per i adds its 64 values in ascending j -- the

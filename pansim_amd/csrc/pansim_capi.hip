@@ -1605,8 +1605,26 @@ static int pair_counts_device(ps_population *p, uint64_t P, const uint32_t *d_r1
             core_pair_counts_simple<<<grid, 256, 0, st>>>(p->state, p->pitch, rows, d_r1, d_r2, d_perm, P, d_a, rps);
         }
     } else {
-        acc_pair_counts_kernel<<<(uint32_t)((P + 255) / 256), 256, 0, st>>>(p->I[p->cur], d_r1, d_r2, d_perm, P,
-                                                                         d_a, d_b, p->d);
+        // more sampled pairs than a quarter of all pairs (cfg5) and room for the N x N matrix: all intersections from LDS
+        // tiles, then a lookup; otherwise one thread per sampled pair
+        const bool all = p->pair_mode != 1 && (uint64_t)N * N * 4 <= (2ull << 30)
+                         && (p->pair_mode == 2 || (double)P * 4.0 > (double)N * (double)N);
+        if (all) {
+            if (p->H_cap < (uint64_t)N * N + N) {
+                if (p->d_H) HIPCHK(hipFree(p->d_H));
+                p->d_H = nullptr;
+                p->H_cap = 0;
+                HIPCHK(hipMalloc(&p->d_H, ((uint64_t)N * N + N) * sizeof(uint32_t)));
+                p->H_cap = (uint64_t)N * N + N;
+            }
+            uint32_t *rowcnt = p->d_H + (uint64_t)N * N;
+            const uint32_t nt = (N + 63u) / 64u;
+            acc_pair_inter_tiled_kernel<<<dim3(nt, nt), 256, 0, st>>>(p->I[p->cur], p->d_H, rowcnt, p->d);
+            acc_pair_lookup_kernel<<<(uint32_t)((P + 255) / 256), 256, 0, st>>>(p->d_H, rowcnt, N, d_r1, d_r2, d_perm, P, d_a, d_b);
+        } else {
+            acc_pair_counts_kernel<<<(uint32_t)((P + 255) / 256), 256, 0, st>>>(p->I[p->cur], d_r1, d_r2, d_perm, P,
+                                                                             d_a, d_b, p->d);
+        }
     }
     HIPCHK(hipGetLastError());
     return PS_OK;

@@ -700,6 +700,29 @@ def test_full_hgt_bins_take_the_overflow_image(pa, orc, N, G, cap):
         acc.close()
 
 
+@pytest.mark.parametrize("N,G,mode", [(2, 1, 2), (65, 129, 2), (300, 4000, 2), (1000, 700, 0), (130, 64, 1)])
+def test_pairwise_accessory_all_pairs_form(pa, orc, N, G, mode):
+    # accessory Jaccard numerators (distances.rs:55-77) for more sampled pairs than a quarter of all pairs: all
+    # intersections from LDS tiles + lookup, unions from the row counts -- every ordered pair incl. i == j
+    rng = np.random.default_rng(N * 5 + G)
+    m = _rand_acc(rng, N, G, 0.4)
+    m[0, :] = 0                                # an empty row: union = the other row's count, NaN distance with itself at core_genes 0
+    ii, jj = np.meshgrid(np.arange(N, dtype=np.uint32), np.arange(N, dtype=np.uint32), indexing="ij")
+    r1, r2 = np.ascontiguousarray(ii.ravel()), np.ascontiguousarray(jj.ravel())
+    if r1.size > 200000:
+        sel = rng.choice(r1.size, 200000, replace=False)
+        r1, r2 = np.ascontiguousarray(r1[sel]), np.ascontiguousarray(r2[sel])
+    pop = pa.Population(N, G, 2, False, 0.4, 0, 0)
+    pop.set_tuning("pair_mode", mode)
+    pop.load_matrix(m)
+    inter, uni = pop.pairwise_counts(r1, r2)
+    a, b = m[r1].astype(bool), m[r2].astype(bool)
+    assert np.array_equal(inter, (a & b).sum(1).astype(np.uint32))
+    assert np.array_equal(uni, (a | b).sum(1).astype(np.uint32))
+    assert np.array_equal(pop.pairwise_distances(r1.size, r1, r2), orc.pairwise_distances(m, False, 0, r1, r2), equal_nan=True)
+    pop.close()
+
+
 # ----------------------------------------------------------------------------- BASELINE full sizes
 def _crc(a):
     import zlib
