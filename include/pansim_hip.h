@@ -226,6 +226,10 @@ typedef struct {
      * [core_size*shard_rank/shard_count, core_size*(shard_rank+1)/shard_count) */
     int32_t shard_rank, shard_count;
     int32_t device;                                            /* HIP device, -1 = current */
+    /* opt-in, UNPINNED: draw what precedes sample_beta -- the selection coefficients, main.rs:289-319 --
+     * from the reference's own seeded stream (rand 0.8.5 StdRng = ChaCha12 after seed_from_u64, rand's Uniform,
+     * statrs' ziggurat Exp) instead of the build's Philox stream.  Everything from main.rs:370 on keeps the build's streams. */
+    int32_t reference_seed_stream;
 } ps_sim_params;
 
 typedef struct {
@@ -248,6 +252,13 @@ int ps_sim_derive(const ps_sim_params *p, ps_derived *d);      /* main.rs:259-36
 /* main.rs:287-319 (build's seeded host stream) */
 int ps_selection_coefficients(uint64_t seed, uint64_t n_genes, double prop_positive,
                               double pos_lambda, double neg_lambda, double *out);
+/* The same draws from the reference's own seeded stream (ChaCha12 StdRng; see ps_sim_params.reference_seed_stream).
+ * Restated from the published algorithms of rand 0.8.5 / rand_chacha 0.3 / statrs 0.16, which are not available here:
+ * UNPINNED. */
+int ps_reference_selection_coefficients(uint64_t seed, uint64_t n_genes, double prop_positive,
+                                        double pos_lambda, double neg_lambda, double *out);
+/* the ChaCha block function behind it (rounds = 12 for StdRng; 20 reproduces the RFC 7539 vectors): 16 output words */
+void ps_chacha_block(const uint32_t key[8], uint64_t counter, uint64_t stream, int rounds, uint32_t out[16]);
 /* main.rs:413-427 */
 int ps_sample_pairs(uint64_t seed, uint64_t pop_size, uint64_t max_distances, uint32_t *range1,
                     uint32_t *range2);

@@ -38,7 +38,7 @@ class SimParams(C.Structure):
                 ("print_selection", C.c_int32), ("verbose", C.c_int32),
                 ("no_control_genome_size", C.c_int32), ("genome_size_penalty", C.c_double),
                 ("competition_strength", C.c_double), ("shard_rank", C.c_int32),
-                ("shard_count", C.c_int32), ("device", C.c_int32)]
+                ("shard_count", C.c_int32), ("device", C.c_int32), ("reference_seed_stream", C.c_int32)]
 
 
 class Derived(C.Structure):
@@ -98,6 +98,8 @@ SIGNATURES = {
     "ps_sim_derive": (_int, [C.POINTER(SimParams), C.POINTER(Derived)]),
     "ps_selection_coefficients": (_int, [_u64, _u64, _f64, _f64, _f64, _f64p]),
     "ps_sample_pairs": (_int, [_u64, _u64, _u64, _u32p, _u32p]),
+    "ps_reference_selection_coefficients": (_int, [_u64, _u64, _f64, _f64, _f64, _f64p]),
+    "ps_chacha_block": (None, [_u32p, _u64, _u64, _int, _u32p]),
     "ps_sim_create": (_int, [C.POINTER(SimParams), C.POINTER(_vp)]),
     "ps_sim_destroy": (None, [_vp]),
     "ps_sim_run": (_int, [_vp, _u32, _u32]),

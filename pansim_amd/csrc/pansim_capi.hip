@@ -58,7 +58,7 @@ static int ps_fail(int code, const char *fmt, ...)
     } while (0)
 
 extern "C" const char *ps_last_error(void) { return g_err.c_str(); }
-extern "C" int ps_abi_version(void) { return 1; }
+extern "C" int ps_abi_version(void) { return 2; }
 extern "C" int ps_device_count(void)
 {
     int n = 0;
@@ -2032,6 +2032,124 @@ extern "C" int ps_selection_coefficients(uint64_t seed, uint64_t G, double prop_
     return PS_OK;
 }
 
+// ---------------------------------------------------------------------------
+// SURVEY 8f-3, opt-in and UNPINNED: the reference's own seeded stream for what precedes sample_beta (main.rs:289-319).
+// `StdRng::seed_from_u64(seed)` (rand 0.8.5): the u64 is expanded to a 32-byte key by PCG32 steps (rand_core 0.6),
+// StdRng = ChaCha12 (rand_chacha 0.3: 64-bit block counter in words 12-13, stream id 0 in words 14-15, four blocks
+// per refill of a 64-word buffer, next_u64 = two consecutive words, low word first).  `Uniform::new(0.0, 1.0)` takes the
+// top 52 bits of a u64 as the mantissa of [1, 2) and subtracts 1; statrs 0.16 `Exp::sample` is ziggurat exp(1) / rate
+// with the 256-layer tables of rand's utils/ziggurat_tables.py (recomputed here with libm, as that script does), `gen::<f64>`
+// = top 53 bits x 2^-53.  All of this is restated from the published algorithms of un-vendored crates that cannot be
+// built or read here: nothing pins it against a Pansim binary.  Everything from sample_beta on (main.rs:370: a rejection
+// sampler with a data-dependent number of draws) stays on the build's own streams.
+// ---------------------------------------------------------------------------
+static inline uint32_t rotl32(uint32_t x, int k) { return (x << k) | (x >> (32 - k)); }
+
+extern "C" void ps_chacha_block(const uint32_t key[8], uint64_t counter, uint64_t stream, int rounds, uint32_t out[16])
+{
+    uint32_t st[16] = { 0x61707865u, 0x3320646eu, 0x79622d32u, 0x6b206574u, key[0], key[1], key[2], key[3], key[4], key[5], key[6],
+                        key[7], (uint32_t)counter, (uint32_t)(counter >> 32), (uint32_t)stream, (uint32_t)(stream >> 32) };
+    uint32_t x[16];
+    memcpy(x, st, sizeof x);
+    auto qr = [&](int a, int b, int c, int d) {
+        x[a] += x[b]; x[d] = rotl32(x[d] ^ x[a], 16);
+        x[c] += x[d]; x[b] = rotl32(x[b] ^ x[c], 12);
+        x[a] += x[b]; x[d] = rotl32(x[d] ^ x[a], 8);
+        x[c] += x[d]; x[b] = rotl32(x[b] ^ x[c], 7);
+    };
+    for (int r = 0; r < rounds; r += 2) {
+        qr(0, 4, 8, 12); qr(1, 5, 9, 13); qr(2, 6, 10, 14); qr(3, 7, 11, 15);
+        qr(0, 5, 10, 15); qr(1, 6, 11, 12); qr(2, 7, 8, 13); qr(3, 4, 9, 14);
+    }
+    for (int k = 0; k < 16; k++) out[k] = x[k] + st[k];
+}
+
+struct ref_std_rng {
+    uint32_t key[8];
+    uint64_t counter = 0;
+    uint32_t buf[64];
+    uint32_t index = 64;
+    explicit ref_std_rng(uint64_t state)               // SeedableRng::seed_from_u64
+    {
+        for (int k = 0; k < 8; k++) {
+            state = state * 6364136223846793005ull + 11634580027462260723ull;
+            const uint32_t xorshifted = (uint32_t)(((state >> 18) ^ state) >> 27), rot = (uint32_t)(state >> 59);
+            key[k] = (xorshifted >> rot) | (xorshifted << ((32 - rot) & 31));
+        }
+    }
+    void refill(uint32_t index_after)
+    {
+        for (int b = 0; b < 4; b++) ps_chacha_block(key, counter + (uint64_t)b, 0, 12, buf + 16 * b);
+        counter += 4;
+        index = index_after;
+    }
+    uint64_t next_u64()                                 // BlockRng::next_u64
+    {
+        if (index < 63) { const uint64_t v = ((uint64_t)buf[index + 1] << 32) | buf[index]; index += 2; return v; }
+        if (index >= 64) { refill(2); return ((uint64_t)buf[1] << 32) | buf[0]; }
+        const uint64_t lo = buf[63];
+        refill(1);
+        return ((uint64_t)buf[0] << 32) | lo;
+    }
+    double gen_f64() { return (double)(next_u64() >> 11) * (1.0 / 9007199254740992.0); }                 // Standard
+    double uniform01()                                                                                   // Uniform::new(0.0, 1.0)
+    {
+        const uint64_t bits = (next_u64() >> 12) | 0x3FF0000000000000ull;
+        double v;
+        memcpy(&v, &bits, 8);
+        return (v - 1.0) * 1.0 + 0.0;
+    }
+};
+
+static void zig_exp_tables(double *x, double *f)        // rand utils/ziggurat_tables.py, exponential, 256 layers
+{
+    const double R = 7.69711747013104972, V = 0.0039496598225815571993;
+    x[0] = V / std::exp(-R);
+    x[1] = R;
+    for (int i = 2; i < 256; i++) x[i] = -std::log(V / x[i - 1] + std::exp(-x[i - 1]));
+    x[256] = 0.0;
+    for (int i = 0; i <= 256; i++) f[i] = std::exp(-x[i]);
+}
+
+static double zig_exp_1(ref_std_rng &rng, const double *xt, const double *ft)     // statrs ziggurat::sample_exp_1
+{
+    for (;;) {
+        const uint64_t bits = rng.next_u64();
+        const unsigned i = (unsigned)(bits & 0xff);
+        const double u = (double)(bits >> 11) / 9007199254740992.0;
+        const double x = u * xt[i];
+        if (x < xt[i + 1]) return x;
+        if (i == 0) return 7.69711747013104972 - std::log(rng.gen_f64());
+        if (ft[i + 1] + (ft[i] - ft[i + 1]) * rng.gen_f64() < std::exp(-x)) return x;
+    }
+}
+
+extern "C" int ps_reference_selection_coefficients(uint64_t seed, uint64_t G, double prop_positive, double pos_lambda,
+                                                   double neg_lambda, double *out)
+{
+    if (!out && G) return ps_fail(PS_ERR_INVALID, "null output");
+    for (uint64_t g = 0; g < G; g++) out[g] = 0.0;                   // main.rs:287
+    if (!(prop_positive >= 0.0)) return PS_OK;                       // :292
+    if (!(pos_lambda > 0.0) || !(neg_lambda > 0.0)) return ps_fail(PS_ERR_INVALID, "Exp::new(lambda).unwrap() panics for lambda <= 0");
+    static double xt[257], ft[257];
+    static std::once_flag once;
+    std::call_once(once, [] { zig_exp_tables(xt, ft); });
+    ref_std_rng rng(seed);                                            // :289
+    for (uint64_t g = 0; g < G; g++) {
+        const double weight = rng.uniform01();                        // :298
+        double s;
+        if (weight <= prop_positive) {                                // :303
+            s = zig_exp_1(rng, xt, ft) / pos_lambda;
+        } else {
+            s = zig_exp_1(rng, xt, ft) / neg_lambda;
+            while (s > 1.0) s = zig_exp_1(rng, xt, ft) / neg_lambda;  // :309-311
+            s = -1.0 * s;                                             // :315
+        }
+        out[g] = s;
+    }
+    return PS_OK;
+}
+
 extern "C" int ps_sample_pairs(uint64_t seed, uint64_t N, uint64_t P, uint32_t *range1, uint32_t *range2)
 {
     if (!range1 || !range2) return ps_fail(PS_ERR_INVALID, "null output");
@@ -2139,7 +2257,10 @@ static int sim_create_impl(const ps_sim_params *p, ps_sim *s)
     const ps_derived &d = s->der;
     const uint64_t N = p->pop_size, L = p->core_size, G = d.pan_size;
     s->sel.assign(std::max<uint64_t>(G, 1), 0.0);
-    PSCHK(ps_selection_coefficients(p->seed, G, p->prop_positive, p->pos_lambda, p->neg_lambda, s->sel.data()));
+    if (p->reference_seed_stream)     // opt-in, unpinned: the reference's own ChaCha12 stream for main.rs:289-319
+        PSCHK(ps_reference_selection_coefficients(p->seed, G, p->prop_positive, p->pos_lambda, p->neg_lambda, s->sel.data()));
+    else
+        PSCHK(ps_selection_coefficients(p->seed, G, p->prop_positive, p->pos_lambda, p->neg_lambda, s->sel.data()));
     for (uint64_t g = 0; g < G; g++)
         if (std::log(1.0 + s->sel[g]) != 0.0) s->need_logw = true;
     // site shard of this process

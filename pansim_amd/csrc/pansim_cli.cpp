@@ -48,6 +48,7 @@ static const Flag FLAGS[] = {
 // visible GPUs (include/pansim_hip.h, ps_multi); results do not depend on it
 static const Flag EXT_FLAGS[] = {
     { "gpus", "Number of core-site shards, one per GPU (more shards than GPUs share them). Results do not depend on it.", "1", true },
+    { "reference_seed_stream", "Draw the selection coefficients from the reference's own seeded stream (ChaCha12 StdRng, restated from the rand / statrs crates: unpinned) instead of the build's Philox stream.", nullptr, false },
 };
 
 static void print_help()
@@ -60,7 +61,10 @@ static void print_help()
     }
     printf("    -h, --help\n            Print help information\n\n    -V, --version\n            Print version information\n");
     printf("\nMI355X OPTIONS (not in the reference):\n");
-    for (const Flag &f : EXT_FLAGS) printf("        --%s <%s>\n            %s [default: %s]\n\n", f.name, f.name, f.help, f.def);
+    for (const Flag &f : EXT_FLAGS) {
+        if (f.takes_value) printf("        --%s <%s>\n            %s [default: %s]\n\n", f.name, f.name, f.help, f.def);
+        else printf("        --%s\n            %s\n\n", f.name, f.help);
+    }
 }
 
 [[noreturn]] static void die(int code, const std::string &msg)
@@ -149,7 +153,10 @@ int main(int argc, char **argv)
         if (f.takes_value) val[f.name] = f.def;
         else present[f.name] = false;
     }
-    for (const Flag &f : EXT_FLAGS) val[f.name] = f.def;
+    for (const Flag &f : EXT_FLAGS) {
+        if (f.takes_value) val[f.name] = f.def;
+        else present[f.name] = false;
+    }
     for (int i = 1; i < argc; i++) {
         std::string a = argv[i];
         if (a == "-h" || a == "--help") { print_help(); return 0; }
@@ -216,6 +223,7 @@ int main(int argc, char **argv)
     p.no_control_genome_size = present["no_control_genome_size"];
     p.genome_size_penalty = as_f64(val, "genome_size_penalty");
     p.competition_strength = as_f64(val, "competition_strength");
+    p.reference_seed_stream = present["reference_seed_stream"];
 
     // main.rs:195-247: message on stdout, exit status 0, no files
     char msg[2048];

@@ -15,7 +15,8 @@ DEFAULTS = dict(pop_size=1000, core_size=1200000, pan_genes=6000, core_genes=200
                 rate_genes1=1.0, rate_genes2=1000.0, prop_genes2=0.1, prop_positive=-0.1,
                 pos_lambda=10.0, neg_lambda=10.0, seed=0, genome_size_penalty=0.99,
                 competition_strength=0.0, print_dist=0, print_matrices=0, print_selection=0,
-                verbose=0, no_control_genome_size=0, shard_rank=0, shard_count=1, device=-1)
+                verbose=0, no_control_genome_size=0, shard_rank=0, shard_count=1, device=-1,
+                reference_seed_stream=0)
 
 
 def make_params(**kw):

@@ -120,3 +120,24 @@ def test_outputs_match_oracle(exe, orc, tmp_path):
     # no header, tab separated, as scripts/plot_distances.R:15-16 reads it
     first = (tmp_path / "run.tsv").read_text().splitlines()[0].split("\t")
     assert len(first) == 2 and all(0.0 <= float(x) <= 1.0 for x in first)
+
+
+@pytest.mark.gpu
+def test_reference_seed_stream_flag(exe, tmp_path):
+    # SURVEY 8f-3, opt-in and unpinned: --reference_seed_stream draws _selection.tsv (main.rs:289-331) from the
+    # reference's own ChaCha12 stream as restated in tests/test_reference_stream.py; without the flag the build's
+    # Philox stream is used
+    import ctypes as C
+    import pansim_amd as pa
+    from test_reference_stream import selection
+    base = ["--pop_size", 40, "--core_size", 200, "--pan_genes", 260, "--core_genes", 60, "--n_gen", 2, "--seed", 9,
+            "--prop_positive", 0.25, "--max_distances", 20, "--print_selection"]
+    r = run(exe, *base, "--reference_seed_stream", "--outpref", tmp_path / "ref")
+    assert r.returncode == 0, r.stderr
+    got = (tmp_path / "ref_selection.tsv").read_text().split("\n")
+    want = selection(9, 200, 0.25, 10.0, 10.0)
+    assert got[-1] == "" and len(got) == 201
+    assert got[:-1] == [pa.fmt_f64(x) for x in want]
+    r = run(exe, *base, "--outpref", tmp_path / "own")
+    assert r.returncode == 0, r.stderr
+    assert (tmp_path / "own_selection.tsv").read_text() != (tmp_path / "ref_selection.tsv").read_text()

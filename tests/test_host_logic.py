@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol(pa):
     assert not missing, "declared in include/pansim_hip.h but not exported: %s" % missing
     from pansim_amd import _lib
     assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
-    assert lib.ps_abi_version() == 1
+    assert lib.ps_abi_version() == 2      # round 3: ps_sim_params gained reference_seed_stream
 
 
 def test_no_cpu_fallback_without_device(pa):
