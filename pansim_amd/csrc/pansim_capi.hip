@@ -2203,6 +2203,9 @@ struct ps_sim {
     // host half of a generation, accumulated since the last reset (ps_sim_host_timing)
     uint64_t host_calls = 0;
     double host_wait_ms = 0.0, host_weights_ms = 0.0, host_draw_ms = 0.0;
+    // several shards in one process: the weights of sample_indices computed once (ps_multi)
+    int (*weights_hook)(void *ctx, ps_sim *s, uint32_t gen, double *w) = nullptr;
+    void *weights_ctx = nullptr;
     // exchange of the donor-sharded HGT deltas: emulation (bench.py --emulate-shard) and traffic counters
     int emu_shards = 0;
     void *emu_buf = nullptr;
@@ -2387,21 +2390,22 @@ extern "C" int ps_sim_create(const ps_sim_params *p, ps_sim **out)
     return PS_OK;
 }
 
-static int sim_one_generation(ps_sim *s, uint32_t gen)
+// main.rs:435-443 up to the weights: D-avg when competition is on, the device half of sample_indices (gene counts and
+// log-fitness per individual, written straight into host-mapped memory), then the three softmaxes on the host
+static int sim_host_weights(ps_sim *s, uint32_t gen, double *w)
 {
-    ps_population *core = s->core, *acc = s->acc;
+    (void)gen;
+    ps_population *acc = s->acc;
     const ps_sim_params &p = s->prm;
-    const uint64_t N = p.pop_size, G = acc->cfg.ncols;
-    hipStream_t sa = acc->stream, sc = core->stream;
-    const int slot = (int)(s->step_count % PS_RING);
-    // main.rs:435-440
-    for (uint64_t i = 0; i < N; i++) s->h_avg[i] = 1.0;
-    if (p.competition_strength > 0.0) {
+    const uint64_t N = p.pop_size;
+    hipStream_t sa = acc->stream;
+    using clk = std::chrono::steady_clock;
+    auto ms_since = [](clk::time_point t0) { return std::chrono::duration<double, std::milli>(clk::now() - t0).count(); };
+    for (uint64_t i = 0; i < N; i++) s->h_avg[i] = 1.0;                 // main.rs:435
+    if (p.competition_strength > 0.0) {                                  // :438-440
         PSCHK(average_distance_device(acc, s->d_avg, sa));
         HIPCHK(hipMemcpyAsync(s->h_avg, s->d_avg, N * sizeof(double), hipMemcpyDeviceToHost, sa));
     }
-    // main.rs:442-443: device half of sample_indices ...
-    // the kernel writes its 12*N bytes straight into host-mapped pinned memory (no copy kernels)
     if (s->need_logw)
         acc_fitness_kernel<<<(uint32_t)((N + 255) / 256), 256, 0, sa>>>(acc->I[acc->cur], s->d_log1p, 1,
                                                                      s->m_num_genes, s->m_logw, acc->d);
@@ -2409,19 +2413,34 @@ static int sim_one_generation(ps_sim *s, uint32_t gen)
         acc_gene_count_rows_kernel<<<(uint32_t)((N + 3) / 4), 256, 0, sa>>>(acc->I[acc->cur], s->m_num_genes,
                                                                          s->m_logw, acc->d);
     HIPCHK(hipGetLastError());
-    // the slot's previous core sweep must have consumed its indices
-    using clk = std::chrono::steady_clock;
-    auto ms_since = [](clk::time_point t0) { return std::chrono::duration<double, std::milli>(clk::now() - t0).count(); };
     auto th0 = clk::now();
-    if (s->slot_used[slot]) HIPCHK(hipEventSynchronize(s->ev_core[slot]));
     HIPCHK(hipStreamSynchronize(sa));
     s->host_wait_ms += ms_since(th0);
-    // ... host half: three softmaxes and N seeded draws
     th0 = clk::now();
-    std::vector<double> w(N);
     PSCHK(ps_sample_weights(s->h_num_genes, s->h_logw, N, acc->cfg.ncols, s->der.avg_gene_num, s->h_avg,
-                            p.no_control_genome_size, p.genome_size_penalty, p.competition_strength, w.data()));
+                            p.no_control_genome_size, p.genome_size_penalty, p.competition_strength, w));
     s->host_weights_ms += ms_since(th0);
+    return PS_OK;
+}
+
+static int sim_one_generation(ps_sim *s, uint32_t gen)
+{
+    ps_population *core = s->core, *acc = s->acc;
+    const ps_sim_params &p = s->prm;
+    const uint64_t N = p.pop_size, G = acc->cfg.ncols;
+    hipStream_t sa = acc->stream, sc = core->stream;
+    const int slot = (int)(s->step_count % PS_RING);
+    using clk = std::chrono::steady_clock;
+    auto ms_since = [](clk::time_point t0) { return std::chrono::duration<double, std::milli>(clk::now() - t0).count(); };
+    // the slot's previous core sweep must have consumed its indices
+    auto th0 = clk::now();
+    if (s->slot_used[slot]) HIPCHK(hipEventSynchronize(s->ev_core[slot]));
+    s->host_wait_ms += ms_since(th0);
+    // main.rs:435-443: the weights of sample_indices -- from this shard's own replica of the accessory matrix, or (several
+    // shards in one process) computed once by shard 0 and handed to the others, whose replicas are bit-identical
+    std::vector<double> w(N);
+    if (s->weights_hook) PSCHK(s->weights_hook(s->weights_ctx, s, gen, w.data()));
+    else PSCHK(sim_host_weights(s, gen, w.data()));
     th0 = clk::now();
     s->last_slot = slot;
     if (s->device_draw) {
@@ -2731,6 +2750,11 @@ struct ps_multi {
     std::vector<uint64_t *> delta;
     std::vector<hipEvent_t> ev_ready, ev_read;
     std::vector<multi_ctx> ctx;
+    // the host half of a generation (three softmaxes over N individuals) is computed by shard 0 and shared: the shards'
+    // replicas of the accessory matrix are bit-identical, and K shards x up to 16 threads each oversubscribe the host
+    std::vector<double> shared_w;
+    int shared_rc = PS_OK;
+    std::string shared_err;
 };
 
 // barrier of the shard threads; fails (instead of hanging) once any shard has failed
@@ -2774,6 +2798,23 @@ static int multi_exchange(void *vctx, void *d_words, uint64_t n_words, void *hip
     m->shard[k]->exchange_calls++;
     m->shard[k]->exchange_bytes += (uint64_t)(K - 1) * n_words * 8;
     return PS_OK;
+}
+
+static int multi_weights(void *vctx, ps_sim *s, uint32_t gen, double *w)
+{
+    multi_ctx *c = (multi_ctx *)vctx;
+    ps_multi *m = c->m;
+    const uint64_t N = m->prm.pop_size;
+    if (c->k == 0) {
+        m->shared_rc = sim_host_weights(s, gen, m->shared_w.data());
+        if (m->shared_rc != PS_OK) m->shared_err = g_err;
+    }
+    PSCHK(multi_barrier(m));                     // shard 0 has published the weights
+    const int rc = m->shared_rc;
+    if (rc == PS_OK) memcpy(w, m->shared_w.data(), N * sizeof(double));
+    else g_err = m->shared_err;
+    PSCHK(multi_barrier(m));                     // every shard has its copy: shard 0 may compute the next generation's
+    return rc;
 }
 
 // run fn(k) for every shard on its own host thread; the first failure (with its message) is returned
@@ -2895,6 +2936,17 @@ extern "C" int ps_multi_create(const ps_sim_params *p, int n_shards, const int *
             return rc;
         }
         m->donor_sharded = true;
+    }
+    if (n_shards > 1 && !getenv("PANSIM_MULTI_OWN_WEIGHTS")) {
+        if (m->ctx.empty()) {
+            m->ctx.resize((size_t)n_shards);
+            for (int k = 0; k < n_shards; k++) m->ctx[(size_t)k] = multi_ctx{ m, (size_t)k };
+        }
+        m->shared_w.assign(p->pop_size, 0.0);
+        for (int k = 0; k < n_shards; k++) {
+            m->shard[(size_t)k]->weights_hook = multi_weights;
+            m->shard[(size_t)k]->weights_ctx = &m->ctx[(size_t)k];
+        }
     }
     (void)hipGetLastError();
     *out = m;

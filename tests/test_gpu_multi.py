@@ -193,6 +193,10 @@ def test_multi_donor_sharded_hgt_forms(pa, orc, env):
             assert np.array_equal(s.last_parents(), ref.last_idx)
         calls = [s.exchange_stats()[0] for s in multi.shards]
         assert calls == ([0, 0, 0] if "PANSIM_MULTI_REPLICATED_HGT" in env else [4, 4, 4])
+        # the three softmaxes of a generation run once per process (shard 0) and are handed to the other shards
+        for k, s in enumerate(multi.shards):
+            gens, _wait, weights_ms, _draw = s.host_timing()
+            assert gens == 4 and (weights_ms > 0.0) == (k == 0)
         multi.close()
     finally:
         for k, v in old.items():
