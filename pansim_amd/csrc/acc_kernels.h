@@ -415,11 +415,11 @@ __global__ void acc_fitness_kernel(const uint64_t *accI, const double *log1p_s, 
 // P-draw on the device (population.rs:440-443, WeightedIndex::sample): parent k = number of cumulative
 // weights <= x_k over the first N-1 of them, x_k = f64_k * total with the k-th f64 of the seeded PARENTS
 // stream.  The cumulative table is built by the host (sequential f64 sums, libm softmaxes); the draw itself
-// is one IEEE multiplication and comparisons, so it equals the host's bit for bit.  Written to device memory
-// (the gather kernels) and to host-mapped memory (ps_sim_last_parents).
+// is one IEEE multiplication and comparisons, so it equals the host's bit for bit.  ps_sim stores the children of a
+// generation in ascending parent order, so the draws are counted per parent here (cnt zeroed by the
+// caller) and laid out by idx_scan_kernel / idx_fill_kernel: a counting sort.
 __global__ void __launch_bounds__(256) acc_draw_parents_kernel(const double *cum, double total, uint32_t N,
-                                                               uint32_t k0, uint32_t k1, uint32_t gen,
-                                                               uint32_t *idx_dev, uint32_t *idx_host)
+                                                               uint32_t k0, uint32_t k1, uint32_t gen, uint32_t *cnt)
 {
     const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= N) return;
@@ -428,6 +428,41 @@ __global__ void __launch_bounds__(256) acc_draw_parents_kernel(const double *cum
     while (lo < hi) {
         const uint32_t mid = lo + ((hi - lo) >> 1);
         if (cum[mid] <= x) lo = mid + 1u; else hi = mid;
+    }
+    atomicAdd(&cnt[lo], 1u);
+}
+
+// cnt[p] (children of parent p) -> inclusive prefix sums, in place; one workgroup: thread t owns the E consecutive
+// parents t*E .. t*E+E-1, the 1024 partial sums are scanned through LDS
+__global__ void __launch_bounds__(1024) idx_scan_kernel(uint32_t *cnt, uint32_t N)
+{
+    __shared__ uint32_t part[1024];
+    const uint32_t t = threadIdx.x, E = (N + 1023u) / 1024u;
+    const uint32_t b = t * E, e = min(N, b + E);
+    uint32_t sum = 0;
+    for (uint32_t p = b; p < e; p++) sum += cnt[p];
+    part[t] = sum;
+    __syncthreads();
+    for (uint32_t off = 1; off < 1024u; off <<= 1) {          // Hillis-Steele inclusive scan of the partial sums
+        const uint32_t v = (t >= off) ? part[t - off] : 0u;
+        __syncthreads();
+        part[t] += v;
+        __syncthreads();
+    }
+    uint32_t run = part[t] - sum;                             // children of all parents before this thread's range
+    for (uint32_t p = b; p < e; p++) { run += cnt[p]; cnt[p] = run; }
+}
+
+// child k belongs to the first parent whose inclusive prefix exceeds k; written to device memory (the gather kernels)
+// and to host-mapped memory (ps_sim_last_parents)
+__global__ void __launch_bounds__(256) idx_fill_kernel(const uint32_t *incl, uint32_t N, uint32_t *idx_dev, uint32_t *idx_host)
+{
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= N) return;
+    uint32_t lo = 0, hi = N - 1u;
+    while (lo < hi) {
+        const uint32_t mid = lo + ((hi - lo) >> 1);
+        if (incl[mid] <= k) lo = mid + 1u; else hi = mid;
     }
     idx_dev[k] = lo;
     idx_host[k] = lo;

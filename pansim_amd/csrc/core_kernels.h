@@ -547,6 +547,360 @@ __global__ void __launch_bounds__(256, PS_ROWS >= 4 ? 6 : 8) core_sweep_wave_ker
 }
 
 // ---------------------------------------------------------------------------
+// Window sweep: the wave-per-row design for populations WIDER than one wavefront (N > 1024), available when the
+// children are stored in ascending parent order (ps_sim sorts the parents it draws: DESIGN.md 3.5).  A wave owns one
+// 1024-child SEGMENT for the whole launch; sorted parents mean the segment's parents lie in one window
+// [idx[first child], idx[last child]] of the parent row -- ~1024 + a few dozen bytes under drift, whatever N is -- so
+// the gather needs a ~1.1 KB window in wave-private LDS instead of the whole row (64 KB at N = 65536) in
+// workgroup-shared LDS: no workgroup barriers, 24 waves per CU instead of 16, the wave sweep's instruction stream.
+//   * the new generation goes to a second buffer (the windows of neighbouring segments overlap, and HR donors are
+//     read from the old generation), i.e. the sweep is out of place;
+//   * HR: the donor of a cell may sit in any segment.  Its post-mutation value is RECOMPUTED instead of read from a
+//     shared snapshot: parent byte old[row][idx[donor]] (two dependent global loads, L2 / Infinity Cache hits: the
+//     row is being streamed by the other waves) and the donor's own level-1 / level-2 words (the
+//     mutation of a cell is a pure function of (seed, generation, site, individual));
+//   * a window wider than WCAP (parents far apart: strong selection against a stretch of the population) is staged
+//     and gathered in pieces.
+// Everything from the candidate queue on is the wave sweep's code (same entry formats; child rows at a 1024-byte
+// stride in LDS, the window buffer beside them).
+// ---------------------------------------------------------------------------
+#define PS_WCAP 1536u     // bytes of parent window staged at a time (per row)
+#define PS_WSTRIDE (PS_WCAP + 16u)   // row buffer stride in LDS: 16 zero bytes behind the window (what cells past N gather)
+
+// post-mutation, pre-recombination value of cell (site row, individual donor), from the old generation
+__device__ __forceinline__ uint32_t ps_donor_value(const core_sweep_args &a, const ps_core_plan &pl, const uint8_t *old_row,
+                                                   uint32_t site, uint32_t donor, bool do_mut)
+{
+    uint32_t val = old_row[a.idx[donor]];                       // population.rs:450-465: the donor's gathered byte
+    if (do_mut) {
+        const ps_u4 l1 = ps_philox(site, donor >> 4, a.gen, PS_STREAM_CORE_L1, a.k0, a.k1);
+        const uint32_t byte = ps_l1_byte(l1, donor & 15u);
+        if (byte <= pl.bC) {
+            const ps_u4 l2 = ps_philox(site, donor, a.gen, PS_STREAM_CORE_L2, a.k0, a.k1);
+            const ps_cell cell = ps_classify((byte << 24) | (l2.x >> 8), pl);
+            if (cell.mut) val = cell.mut;                        // population.rs:511-540
+        }
+    }
+    return val;
+}
+
+// one 16-byte piece per lane straight into LDS (global_load_lds_dwordx4: no VGPR, asynchronous; the LDS destination is
+// the wave-uniform base + lane * 16)
+__device__ __forceinline__ void ps_dma16(const uint8_t *gsrc, uint8_t *lds_base, bool nt)
+{
+    if (nt) __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)gsrc,
+                                             (__attribute__((address_space(3))) void *)lds_base, 16, 0, 2);
+    else __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)gsrc,
+                                          (__attribute__((address_space(3))) void *)lds_base, 16, 0, 0);
+}
+
+// the donor's own mutation of this generation (0: none): level-1 byte of its block, level-2 word if that is a candidate
+__device__ __forceinline__ uint32_t ps_donor_mutation(const core_sweep_args &a, const ps_core_plan &pl, uint32_t site, uint32_t donor,
+                                                      bool do_mut)
+{
+    if (!do_mut) return 0u;
+    const ps_u4 l1 = ps_philox(site, donor >> 4, a.gen, PS_STREAM_CORE_L1, a.k0, a.k1);
+    const uint32_t byte = ps_l1_byte(l1, donor & 15u);
+    if (byte > pl.bC) return 0u;
+    const ps_u4 l2 = ps_philox(site, donor, a.gen, PS_STREAM_CORE_L2, a.k0, a.k1);
+    return ps_classify((byte << 24) | (l2.x >> 8), pl).mut;
+}
+
+// WIDE = false: the segments whose window fits the row buffer (all of them under drift); WIDE = true: a second launch for
+// the others (parents far apart: strong selection against a stretch of the population) -- same code, the bytes gathered
+// straight from the old row in global memory; ascending parents keep every load instruction's 64 addresses in one compact
+// range.  A wave whose segment belongs to the other launch leaves at once.
+template <uint32_t PS_ROWS, bool DO_MUT, bool DO_HR, bool STASH, bool NT, bool WIDE>
+__global__ void __launch_bounds__(256, 6) core_sweep_window_kernel(core_sweep_args a)
+{
+    constexpr uint32_t PS_QCAP = ps_qcap(PS_ROWS);
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    // per wave: PS_ROWS row buffers of PS_WCAP bytes -- the parents' window arrives there by LDS-DMA, the child row
+    // (1024 bytes) overwrites its start once the gather has read it -- and the candidate queue
+    uint8_t *rowbuf = lds + wave * (PS_ROWS * PS_WSTRIDE + PS_QCAP * 4u);
+    uint32_t *q = (uint32_t *)(rowbuf + PS_ROWS * PS_WSTRIDE);
+    if (lane < PS_ROWS) *(uint4 *)(rowbuf + lane * PS_WSTRIDE + PS_WCAP) = make_uint4(0, 0, 0, 0);     // the zero bytes (never rewritten)
+    const ps_core_plan pl = a.plan;
+    // the wave's segment, fixed for the launch
+    const uint32_t segs = (a.N + 1023u) >> 10;
+    const uint32_t wg = __builtin_amdgcn_readfirstlane(blockIdx.x * 4u + wave);
+    const uint32_t sg = wg % segs;
+    const uint32_t c_first = sg * 1024u, c_last = min(c_first + 1023u, a.N - 1u);
+    const uint32_t chunk = sg * 64u + lane;                 // the lane's 16-cell chunk of the row (Philox counter word)
+    const bool has_chunk = chunk < a.cpr;
+    const uint32_t i0 = lane * 16u, c0 = c_first + i0;      // cell offset inside the segment / global index of the first cell
+    const uint32_t nvalid = (c0 >= a.N) ? 0u : min(16u, a.N - c0);
+    uint32_t vperm = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < 16; k++)
+        if (k < nvalid) vperm |= 1u << (8u * (k & 3u) + 7u - (k >> 2));
+    // the parents' window [w_lo, w_hi] of the parent row, staged from its 16-byte aligned start
+    const uint32_t w_lo = __builtin_amdgcn_readfirstlane(a.idx[c_first]) & ~15u;
+    const uint32_t w_hi = __builtin_amdgcn_readfirstlane(a.idx[c_last]);
+    const uint32_t wbytes = w_hi - w_lo + 1u;
+    const bool wide = wbytes > PS_WCAP;                     // wave-uniform
+    uint32_t pidx[16];      // parents relative to the window start; cells past N gather a zero byte behind the window
+#pragma unroll
+    for (uint32_t k = 0; k < 16; k++) pidx[k] = (k < nvalid) ? a.idx[c0 + k] - w_lo : PS_WCAP;
+    const uint32_t c4 = (pl.bC + 1u) * 0x01010101u;
+    const uint32_t t0b = pl.T[0] >> 24, t1b = pl.T[1] >> 24, t2b = pl.T[2] >> 24;
+    unsigned long long lut = 0;     // 2-bit code per byte value < 32 (see the wave sweep)
+    for (uint32_t bb = 0; bb < 32u; bb++) {
+        const unsigned long long code = (bb < t0b) ? 1ull : (bb > t0b && bb < t1b) ? 2ull : (bb > t1b && bb < t2b) ? 3ull : 0ull;
+        lut |= code << (2u * bb);
+    }
+    const bool use_lut = pl.bC < 32u;
+    const bool ld0 = !WIDE && i0 < wbytes, ld1 = !WIDE && 1024u + i0 < wbytes;
+    // LDS address of a queue entry's cell: (cell | row << 10) -> row * PS_WCAP + cell
+    auto cell_addr = [](uint32_t ent) -> uint32_t { return (ent & 1023u) + ((ent >> 10) & 3u) * PS_WSTRIDE; };
+
+    // rows: the waves of a segment share the segment's chunk counter (two counter sets alternate by launch parity; this
+    // launch zeroes the next one's)
+    constexpr uint32_t PS_CHUNK = 4u;
+    const uint32_t batches = (a.rows + PS_ROWS - 1u) / PS_ROWS;
+    uint32_t *ctr = a.work_ctr + (a.launch_parity * segs + sg) * 32u;
+    if (wg < segs && lane == 0) a.work_ctr[((a.launch_parity ^ 1u) * segs + wg) * 32u] = 0u;
+    if (wide != WIDE) return;                               // the segment belongs to the other launch (no workgroup barriers here)
+    uint32_t nrec = 0;                                   // wave-uniform: HR records waiting at the tail of the queue
+    uint32_t hr_pd0 = 0, hr_slot0 = 0xFFFFFFFFu;
+    uint32_t next_chunk = 0;
+    if (lane == 0) next_chunk = __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (;;) {
+        const uint32_t chk = __builtin_amdgcn_readfirstlane(next_chunk);
+        if (chk * PS_CHUNK >= batches) break;
+        if (lane == 0) next_chunk = __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (uint32_t cb = 0; cb < PS_CHUNK; cb++) {
+        const uint32_t batch = chk * PS_CHUNK + cb;
+        if (batch >= batches) break;
+        const uint32_t r0 = batch * PS_ROWS;
+        const uint32_t nr = min(PS_ROWS, a.rows - r0);
+        // the first window piece of every row of the batch by LDS-DMA: two 16-byte pieces per lane, the second only where
+        // the window is longer than 1 KiB (rows past the end of the last batch are processed as copies, never stored)
+#pragma unroll
+        for (uint32_t rr = 0; rr < PS_ROWS; rr++) {
+            const uint8_t *src = a.state + (size_t)min(r0 + rr, a.rows - 1u) * a.pitch + w_lo;
+            if (ld0) ps_dma16(src + i0, rowbuf + rr * PS_WSTRIDE, NT);
+            if (ld1) ps_dma16(src + 1024u + i0, rowbuf + rr * PS_WSTRIDE + 1024u, NT);
+        }
+        // HR cells of the PREVIOUS batch (records at the tail of the queue, see the exact pass): their donors' bytes are
+        // fetched from the old generation while this batch's windows are in flight, the donors' own mutation words are
+        // recomputed meanwhile, and the values patch the child rows already stored (same wave, same address, later store)
+        uint32_t h_row = 0, h_cell = 0, h_mut = 0, h_b0 = 0;
+        const bool h_have = DO_HR && lane < nrec;
+        if (DO_HR && nrec) {
+            if (h_have) {
+                const uint4 rec = *(const uint4 *)(q + PS_QCAP - 4u * (lane + 1u));
+                h_row = rec.x; h_cell = rec.y;
+                const uint32_t pd = (rec.w != 0xFFFFFFFFu) ? rec.w : a.idx[rec.z];
+                h_b0 = a.state[(size_t)h_row * a.pitch + pd];
+                h_mut = ps_donor_mutation(a, pl, a.site_offset + h_row, rec.z, DO_MUT);
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // (the compiler does not track LDS-DMA)
+        ps_wave_sync();
+        if (DO_HR && nrec) {
+            if (h_have) a.out[(size_t)h_row * a.pitch + h_cell] = (uint8_t)(h_mut ? h_mut : h_b0);
+            for (uint32_t rix = 64u + lane; rix < nrec; rix += 64u) {          // (more than 64 records: high HR rates)
+                const uint4 rec = *(const uint4 *)(q + PS_QCAP - 4u * (rix + 1u));
+                a.out[(size_t)rec.x * a.pitch + rec.y] =
+                    (uint8_t)ps_donor_value(a, pl, a.state + (size_t)rec.x * a.pitch, a.site_offset + rec.x, rec.z, DO_MUT);
+            }
+            ps_wave_sync();                                  // the records are consumed before the queue is reused
+            nrec = 0;
+        }
+        uint32_t qn = 0;
+        uint32_t cm[PS_ROWS];
+        ps_u4 l1[PS_ROWS];      // (only the non-STASH push loop reads it back)
+#pragma unroll
+        for (uint32_t rr = 0; rr < PS_ROWS; rr++) {
+            uint8_t *win = rowbuf + rr * PS_WSTRIDE;
+            const uint32_t site = a.site_offset + min(r0 + rr, a.rows - 1u);
+            uint32_t w[4] = { 0u, 0u, 0u, 0u };
+            if (!WIDE) {
+#pragma unroll
+                for (int j = 0; j < 4; j++)
+                    w[j] = ps_pack4(win[pidx[4 * j]], win[pidx[4 * j + 1]], win[pidx[4 * j + 2]], win[pidx[4 * j + 3]]);
+            } else {
+                const uint8_t *src = a.state + (size_t)min(r0 + rr, a.rows - 1u) * a.pitch + w_lo;
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    uint32_t bsel[4];
+#pragma unroll
+                    for (int b = 0; b < 4; b++) bsel[b] = ((uint32_t)(4 * j + b) < nvalid) ? (uint32_t)src[pidx[4 * j + b]] : 0u;
+                    w[j] = ps_pack4(bsel[0], bsel[1], bsel[2], bsel[3]);
+                }
+            }
+            uint4 d = make_uint4(w[0], w[1], w[2], w[3]);
+            l1[rr] = ps_philox(site, chunk, a.gen, PS_STREAM_CORE_L1, a.k0, a.k1);
+            cm[rr] = ps_candidates_swar(l1[rr], c4) & vperm;
+            if (STASH) {
+                d.x = ps_stash(d.x, l1[rr].x); d.y = ps_stash(d.y, l1[rr].y);
+                d.z = ps_stash(d.z, l1[rr].z); d.w = ps_stash(d.w, l1[rr].w);
+            }
+            ps_wave_sync();                                     // the row buffer becomes the child row: every gather read precedes
+            *(uint4 *)(win + i0) = d;
+            __builtin_amdgcn_sched_barrier(0);      // keep the rows apart (see the wave sweep)
+        }
+        // ONE push loop for all rows of the batch (the wave sweep's)
+        for (;;) {
+            uint32_t any = cm[0];
+#pragma unroll
+            for (uint32_t rr = 1; rr < PS_ROWS; rr++) any |= cm[rr];
+            if (__ballot(any != 0u) == 0ull) break;
+#pragma unroll
+            for (uint32_t rr = 0; rr < PS_ROWS; rr++) {
+                const bool act = cm[rr] != 0u;
+                const uint64_t bal = __ballot(act);
+                if (act) {
+                    const uint32_t p = __builtin_ctz(cm[rr]);
+                    cm[rr] &= cm[rr] - 1u;
+                    const uint32_t pos = qn + ps_lane_prefix(bal);
+                    if (STASH) {
+                        if (pos < PS_QCAP) q[pos] = (lane << 5) | (rr << 11) | p;
+                    } else {
+                        const uint32_t b = p >> 3, j = 7u - (p & 7u);
+                        const uint32_t sel = ((j & 1u) * 4u + b) | 0x0c0c0c00u;
+                        const uint32_t byte = (j & 2u) ? __builtin_amdgcn_perm(l1[rr].w, l1[rr].z, sel)
+                                                       : __builtin_amdgcn_perm(l1[rr].y, l1[rr].x, sel);
+                        if (pos < PS_QCAP) q[pos] = (i0 + 4u * j + b) | (rr << 10) | (byte << 12);
+                    }
+                }
+                qn += (uint32_t)__popcll(bal);
+            }
+        }
+        ps_wave_sync();
+
+        const uint32_t qcap = a.qcap_limit ? min(PS_QCAP, a.qcap_limit) : PS_QCAP;
+        if (qn > qcap) {
+            // full queue: the batch is redone by the queue-free method (see the wave sweep), donors recomputed
+#pragma unroll 1
+            for (uint32_t rr = 0; rr < PS_ROWS; rr++) {
+                uint8_t *row = rowbuf + rr * PS_WSTRIDE;
+                const uint32_t rg = min(r0 + rr, a.rows - 1u), site = a.site_offset + rg;
+                const uint8_t *old_row = a.state + (size_t)rg * a.pitch;
+                const ps_u4 l1r = ps_philox(site, chunk, a.gen, PS_STREAM_CORE_L1, a.k0, a.k1);
+                uint32_t cmr = ps_candidates_swar(l1r, c4) & vperm;
+                while (cmr) {
+                    const uint32_t p = __builtin_ctz(cmr);
+                    cmr &= cmr - 1u;
+                    const uint32_t k = 4u * (7u - (p & 7u)) + (p >> 3), cell = c0 + k;
+                    const ps_u4 l2 = ps_philox(site, cell, a.gen, PS_STREAM_CORE_L2, a.k0, a.k1);
+                    const ps_cell cl = ps_classify((ps_l1_byte(l1r, k) << 24) | (l2.x >> 8), pl);
+                    if (DO_MUT && cl.mut) row[i0 + k] = (uint8_t)cl.mut;
+                    if (DO_HR && cl.hr) {
+                        uint32_t donor = ps_mulhi(l2.y, a.N - 1u);
+                        donor += (donor >= cell) ? 1u : 0u;                      // population.rs:618
+                        row[i0 + k] = (uint8_t)ps_donor_value(a, pl, old_row, site, donor, DO_MUT);
+                    }
+                }
+            }
+            ps_wave_sync();
+        } else {
+            // dense pass (the wave sweep's): byte-decided mutations; the others compacted in place
+            uint32_t n2 = 0;
+            for (uint32_t base = 0; base < qn; base += 64u) {
+                const uint32_t e = base + lane;
+                const bool valid = e < qn;
+                uint32_t ent = valid ? q[e] : 0u;
+                if (STASH) {
+                    // (bit position p = 8b + 7 - j of cell 4j + b | lane << 5 | row << 11) -> cell | row << 10 | nibble << 12
+                    const uint32_t p = ent & 31u;
+                    const uint32_t cl = (((ent >> 5) & 63u) << 4) + 4u * (7u - (p & 7u)) + (p >> 3), rr = ent >> 11;
+                    ent = cl | (rr << 10);
+                    ent |= (uint32_t)(rowbuf[cell_addr(ent)] >> 4) << 12;
+                }
+                const uint32_t byte = (ent >> 12) & 0xFFu;
+                uint32_t allele = 0;
+                if (use_lut) {
+                    const uint32_t code = (uint32_t)(lut >> (2u * (byte & 31u))) & 3u;
+                    allele = code ? (1u << code) : 0u;
+                } else {
+                    if (byte < t0b) allele = 2u;
+                    else if (byte > t0b && byte < t1b) allele = 4u;
+                    else if (byte > t1b && byte < t2b) allele = 8u;
+                }
+                const bool amb = valid && allele == 0u;
+                if (DO_MUT && valid && allele) rowbuf[cell_addr(ent)] = (uint8_t)allele;
+                const uint64_t bal = __ballot(amb);
+                if (amb) q[n2 + ps_lane_prefix(bal)] = ent;
+                n2 += (uint32_t)__popcll(bal);
+            }
+            ps_wave_sync();
+            // exact pass: level-2 Philox.  A cell that receives a donor allele is not resolved here (two dependent global
+            // loads): it becomes a record (row, cell, donor, donor's parent) at the tail of the queue, resolved at the top
+            // of the next batch; only when the tail has no room (queue nearly full of undecided cells) inline.
+            const uint32_t rec_cap = (PS_QCAP - n2) >> 2;
+            uint32_t pd0 = 0, slot0 = 0xFFFFFFFFu;           // first-iteration record of this lane: the parent load stays in flight
+            for (uint32_t base = 0; base < n2; base += 64u) {
+                const uint32_t e = base + lane;
+                bool hr_here = false;
+                uint32_t cell = 0, rg = 0, donor = 0;
+                if (e < n2) {
+                    const uint32_t ent = q[e];
+                    const uint32_t rr = (ent >> 10) & 3u, byte = (ent >> 12) & 0xFFu;
+                    cell = c_first + (ent & 1023u);
+                    rg = min(r0 + rr, a.rows - 1u);
+                    const uint32_t site = a.site_offset + rg;
+                    const ps_u4 l2 = ps_philox(site, cell, a.gen, PS_STREAM_CORE_L2, a.k0, a.k1);
+                    const ps_cell cl = ps_classify((byte << 24) | (l2.x >> 8), pl);
+                    if (DO_MUT && cl.mut) rowbuf[cell_addr(ent)] = (uint8_t)cl.mut;
+                    if (DO_HR && cl.hr && rr < nr) {
+                        hr_here = true;
+                        donor = ps_mulhi(l2.y, a.N - 1u);
+                        donor += (donor >= cell) ? 1u : 0u;                      // population.rs:618
+                    }
+                }
+                if (DO_HR) {
+                    const uint64_t balh = __ballot(hr_here);
+                    if (hr_here) {
+                        const uint32_t slot = nrec + ps_lane_prefix(balh);
+                        if (slot < rec_cap) {
+                            uint32_t pdw = 0xFFFFFFFFu;
+                            if (base == 0u) { pd0 = a.idx[donor]; slot0 = slot; }       // (written into the record after the row stores)
+                            *(uint4 *)(q + PS_QCAP - 4u * (slot + 1u)) = make_uint4(rg, cell, donor, pdw);
+                        } else {
+                            const ps_u4 dummy = { 0, 0, 0, 0 };
+                            (void)dummy;
+                            // no room: resolve now and patch the LDS row (nobody else reads it)
+                            // cell_addr needs the entry's row: rebuild it from rg
+                            const uint32_t rr2 = rg - r0;
+                            rowbuf[(cell - c_first) + rr2 * PS_WSTRIDE] =
+                                (uint8_t)ps_donor_value(a, pl, a.state + (size_t)rg * a.pitch, a.site_offset + rg, donor, DO_MUT);
+                        }
+                    }
+                    nrec = min(nrec + (uint32_t)__popcll(balh), rec_cap);
+                }
+            }
+            ps_wave_sync();
+            hr_pd0 = pd0; hr_slot0 = slot0;
+        }
+
+        if (has_chunk) {
+#pragma unroll
+            for (uint32_t rr = 0; rr < PS_ROWS; rr++) {
+                if (rr < nr) {
+                    uint4 o = *(const uint4 *)(rowbuf + rr * PS_WSTRIDE + i0);
+                    if (STASH) { o.x &= 0x0F0F0F0Fu; o.y &= 0x0F0F0F0Fu; o.z &= 0x0F0F0F0Fu; o.w &= 0x0F0F0F0Fu; }
+                    ps_store_row16(a.out + (size_t)(r0 + rr) * a.pitch + c0, o, NT);
+                }
+            }
+        }
+        if (DO_HR && hr_slot0 != 0xFFFFFFFFu) { q[PS_QCAP - 4u * (hr_slot0 + 1u) + 3u] = hr_pd0; hr_slot0 = 0xFFFFFFFFu; }
+        ps_wave_sync();   // the next iteration's DMA overwrites the row buffers
+    }
+    }
+    // the last batch's records
+    if (DO_HR && nrec) {
+        for (uint32_t rix = lane; rix < nrec; rix += 64u) {
+            const uint4 rec = *(const uint4 *)(q + PS_QCAP - 4u * (rix + 1u));
+            a.out[(size_t)rec.x * a.pitch + rec.y] =
+                (uint8_t)ps_donor_value(a, pl, a.state + (size_t)rec.x * a.pitch, a.site_offset + rec.x, rec.z, DO_MUT);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
 // Block sweep for rows wider than one wavefront (pitch > 1024: cfg4/cfg5 populations).
 // A workgroup of nw waves stages R whole site rows in LDS (parent rows and child rows) and
 // splits them into 1024-cell segments.  A wave takes PS_SB consecutive segments per

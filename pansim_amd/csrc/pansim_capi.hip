@@ -221,6 +221,7 @@ struct ps_population {
     uint32_t *d_idxT = nullptr;      // transposed parents for the block sweep (16 x cpr)
     uint32_t *d_work = nullptr;      // wave sweep: chunk counters (2 sets x 8 x 128 bytes)
     uint64_t sweep_launches = 0;     // parity selects the counter set
+    uint64_t window_launches = 0;    // the same for the window sweep's per-segment counters
     double *d_log1p = nullptr;       // G
     int32_t *d_num_genes = nullptr;  // N
     double *d_logw = nullptr;        // N
@@ -246,6 +247,7 @@ struct ps_population {
     bool no_block_preload = false;      // tests: block sweep reads its parent indices per batch
     uint32_t block_batch = 0;           // block sweep: segments per wave batch (0 = 4, falling back to 2; 2 = force 2)
     uint32_t sweep_queue_cap = 0;       // tests: the sweeps treat their candidate queues / HR lists as this short (0 = real size)
+    int window_sweep = -1;              // window sweep for N > 1024 when the parents are sorted: -1 = choose, 0 = never, 1 = whenever possible
     uint32_t *h_flag = nullptr, *d_flag = nullptr;   // host-mapped sticky device error word
     unsigned long long *h_stamps = nullptr, *d_stamps = nullptr;   // diagnostic phase stamps
 };
@@ -294,6 +296,7 @@ static int pop_create_impl(const ps_config *cfg, const uint8_t *init_vec, ps_pop
     }
     if (const char *e = getenv("PANSIM_HGT_MODE")) p->hgt_mode = atoi(e);
     if (const char *e = getenv("PANSIM_SWEEP_OOP")) p->sweep_oop = std::max(-1, std::min(2, atoi(e)));
+    if (const char *e = getenv("PANSIM_WINDOW_SWEEP")) p->window_sweep = std::max(-1, std::min(1, atoi(e)));
     if (const char *e = getenv("PANSIM_BLOCK_BATCH")) p->block_batch = (uint32_t)atoi(e);
     if (const char *e = getenv("PANSIM_BLOCK_WAVES")) p->block_waves = (uint32_t)atoi(e);
     if (const char *e = getenv("PANSIM_HGT_SLICES")) p->hgt_slices = (uint32_t)atoi(e);
@@ -317,8 +320,13 @@ static int pop_create_impl(const ps_config *cfg, const uint8_t *init_vec, ps_pop
         p->cpr = p->pitch / 16;
         HIPCHK(hipMalloc(&p->state, std::max<uint64_t>(C, 1) * p->pitch));
         HIPCHK(hipMalloc(&p->d_idxT, 16ull * p->cpr * sizeof(uint32_t)));
-        HIPCHK(hipMalloc(&p->d_work, 2 * 8 * 128));
-        HIPCHK(hipMemsetAsync(p->d_work, 0, 2 * 8 * 128, p->stream));
+        {
+            // chunk counters of the dynamic row assignment: 2 sets (alternating by launch) x 8 groups (wave sweep) or
+            // x one per 1024-child segment (window sweep), 128 bytes apart
+            const uint64_t nctr = std::max<uint64_t>(8, (N + 1023) / 1024);
+            HIPCHK(hipMalloc(&p->d_work, 2 * nctr * 128));
+            HIPCHK(hipMemsetAsync(p->d_work, 0, 2 * nctr * 128, p->stream));
+        }
         if (C) {
             const uint64_t total = C * p->cpr;
             const uint32_t blocks = (uint32_t)std::min<uint64_t>((total + 255) / 256, 65536);
@@ -451,6 +459,9 @@ extern "C" int ps_set_tuning(ps_population *p, const char *key, int64_t value)
     } else if (k == "hgt_bin_cap") {
         if (value < 0 || value > (1 << 30)) return ps_fail(PS_ERR_INVALID, "hgt_bin_cap must be 0 (sized by the rates)..2^30");
         p->hgt_bin_cap = (uint32_t)value;
+    } else if (k == "window_sweep") {
+        if (value < -1 || value > 1) return ps_fail(PS_ERR_INVALID, "window_sweep must be -1 (choose), 0 (block sweep) or 1 (window sweep where the parents are sorted)");
+        p->window_sweep = (int)value;
     } else if (k == "sweep_queue_cap") {
         if (value < 0 || value > 65536) return ps_fail(PS_ERR_INVALID, "sweep_queue_cap must be 0 (real size)..65536");
         p->sweep_queue_cap = (uint32_t)value;
@@ -747,8 +758,36 @@ static int launch_core_sweep_block(ps_population *p, const core_sweep_args &a, c
     return PS_OK;
 }
 
+// window sweep (core_kernels.h): N > 1024, fused gather + mutate (+ HR), parents in ascending order, out of place
+template <bool HR>
+static int launch_core_sweep_window(ps_population *p, const core_sweep_args &a, hipStream_t st)
+{
+    constexpr uint32_t ROWS = 3;
+    const uint32_t lds = 4u * (ROWS * PS_WSTRIDE + ps_qcap(ROWS) * 4u);
+    const uint32_t bpc = std::max(1u, std::min(6u, p->lds_limit / lds));
+    const uint32_t segs = (a.N + 1023u) / 1024u;
+    const uint32_t grid = std::max((segs + 3u) / 4u, 256u * bpc);       // at least one wave per segment
+    const bool stash = a.plan.bC <= 15u && p->nibble_safe;
+    // two launches: the segments whose parent window fits the row buffer, then the others (usually none: its waves
+    // leave at once); they alternate the counter sets like any two consecutive launches
+    // (the counter sets alternate among the launches that use them: a parity of their own)
+    core_sweep_args a0 = a, b = a;
+    a0.launch_parity = (uint32_t)(p->window_launches++ & 1u);
+    b.launch_parity = (uint32_t)(p->window_launches++ & 1u);
+#define PS_WLAUNCH(ST_, NT_)                                                                                                           \
+    {                                                                                                                                 \
+        hipLaunchKernelGGL((core_sweep_window_kernel<ROWS, true, HR, ST_, NT_, false>), dim3(grid), dim3(256), lds, st, a0);          \
+        hipLaunchKernelGGL((core_sweep_window_kernel<ROWS, true, HR, ST_, NT_, true>), dim3(grid), dim3(256), lds, st, b);            \
+    }
+    if (a.nt) { if (stash) PS_WLAUNCH(true, true) else PS_WLAUNCH(false, true) }
+    else { if (stash) PS_WLAUNCH(true, false) else PS_WLAUNCH(false, false) }
+#undef PS_WLAUNCH
+    HIPCHK(hipGetLastError());
+    return PS_OK;
+}
+
 static int launch_core_sweep(ps_population *p, const uint32_t *d_idx, uint32_t gen, bool ga, bool mu,
-                             bool hr, hipStream_t st)
+                             bool hr, hipStream_t st, bool parents_sorted = false)
 {
     if (p->cfg.ncols == 0) return PS_OK;
     core_sweep_args a;
@@ -776,8 +815,27 @@ static int launch_core_sweep(ps_population *p, const uint32_t *d_idx, uint32_t g
     core_block_geom g_probe{};
     uint32_t lds_probe = 0, nw_probe = 0;
     const bool inline_form = !wave && (p->force_inline_sweep || !block_sweep_geometry(p, ga, mu, hr, &g_probe, &lds_probe, &nw_probe));
-    const int oop = p->sweep_oop < 0 ? (wave ? 2 : 0) : p->sweep_oop;
-    if (oop && !inline_form) {
+    // window sweep: the wave-per-row design for N > 1024 -- needs the children in ascending parent order (ps_sim's
+    // generations), the fused gather + mutate (+ HR) step with events, its queue sized like the wave sweep's, a second
+    // buffer (it is out of place by construction) and 4 x 6.5 KB of LDS
+    bool window = !wave && parents_sorted && ga && mu && a.plan.has_events && p->window_sweep != 0 && p->pitch > 1024
+                  && a.plan.bC <= 126u && !p->force_inline_sweep && !p->force_block_sweep
+                  && 4u * (3u * PS_WSTRIDE + ps_qcap(3) * 4u) <= p->lds_limit;
+    if (window) {
+        const double m = 3.0 * 1024.0 * (double)(a.plan.bC + 1u) / 256.0;
+        window = m + 10.0 * std::sqrt(m) + 16.0 <= (double)ps_qcap(3);
+    }
+    if (window && !p->state2 && hipMalloc(&p->state2, (uint64_t)p->cfg.ncols * p->pitch) != hipSuccess) {
+        (void)hipGetLastError();
+        p->state2 = nullptr;
+        window = false;          // no room for the second buffer (cfg4 on a full GPU): the in-place block sweep
+    }
+    // (window sweep: nontemporal row traffic only without HR -- the donors' bytes are read from the old rows the other waves
+    // have just streamed, and the patched bytes land in lines this wave has just stored: both want the rows kept in L2 /
+    // Infinity Cache; N = 65536, 150 000 sites: 4.61 ms against 5.09 with nt, 3.94 / 3.75 ms without HR)
+    const int oop = window ? (p->sweep_oop == 1 || p->sweep_oop == 2 ? p->sweep_oop : (hr ? 1 : 2))
+                           : p->sweep_oop < 0 ? (wave ? 2 : 0) : p->sweep_oop;
+    if (oop && (!inline_form || window)) {
         if (!p->state2 && hipMalloc(&p->state2, (uint64_t)p->cfg.ncols * p->pitch) != hipSuccess) {
             (void)hipGetLastError();
             p->state2 = nullptr;
@@ -795,6 +853,7 @@ static int launch_core_sweep(ps_population *p, const uint32_t *d_idx, uint32_t g
     a.work_ctr = p->d_work;
     a.launch_parity = (uint32_t)(p->sweep_launches++ & 1u);
     a.idxT = p->d_idxT;
+    if (window) return hr ? launch_core_sweep_window<true>(p, a, st) : launch_core_sweep_window<false>(p, a, st);
 #define PS_DISPATCH(G_, M_, H_)                                              \
     if (ga == G_ && mu == M_ && hr == H_)                                    \
         return wave ? launch_core_sweep_wave<G_, M_, H_>(p, a, st)           \
@@ -1062,9 +1121,9 @@ static int upload_idx(ps_population *p, const uint32_t *sample)
 }
 
 static int step_device(ps_population *p, const uint32_t *d_idx, uint32_t gen, bool ga, bool mu, bool hr,
-                       hipStream_t st, uint32_t *idx_out = nullptr)
+                       hipStream_t st, uint32_t *idx_out = nullptr, bool parents_sorted = false)
 {
-    if (p->cfg.core) return launch_core_sweep(p, d_idx, gen, ga, mu, hr, st);
+    if (p->cfg.core) return launch_core_sweep(p, d_idx, gen, ga, mu, hr, st, parents_sorted);
     if (ga || mu) PSCHK(launch_acc_step(p, d_idx, gen, ga, mu, st, idx_out));
     if (hr) PSCHK(launch_acc_hgt(p, gen, st));
     return PS_OK;
@@ -2194,6 +2253,7 @@ struct ps_sim {
     // largest part of the host half there, and the host half does not shrink with the number of site shards)
     bool device_draw = false;
     double *h_cum = nullptr, *d_cum = nullptr;   // cumulative weights: pinned host copy, device copy
+    uint32_t *d_idx_cnt = nullptr;               // device draw: children per parent, then their inclusive prefix sums (counting sort)
     int last_slot = 0;
     // distance phase (ps_sim_pairwise_distances): pinned numerators, events around the kernels of each matrix
     uint32_t *h_cnt = nullptr;           // 3 x P: core numerators | accessory intersections | unions
@@ -2236,6 +2296,7 @@ extern "C" void ps_sim_destroy(ps_sim *s)
     if (s->h_avg) (void)hipHostFree(s->h_avg);
     if (s->h_cum) (void)hipHostFree(s->h_cum);
     if (s->d_cum) (void)hipFree(s->d_cum);
+    if (s->d_idx_cnt) (void)hipFree(s->d_idx_cnt);
     if (s->h_cnt) (void)hipHostFree(s->h_cnt);
     for (auto e : s->ev_dist) if (e) (void)hipEventDestroy(e);
     if (s->d_avg) (void)hipFree(s->d_avg);
@@ -2364,6 +2425,7 @@ static int sim_create_impl(const ps_sim_params *p, ps_sim *s)
     if (const char *e = getenv("PANSIM_DEVICE_DRAW")) s->device_draw = atoi(e) != 0;
     HIPCHK(hipHostMalloc(&s->h_cum, N * sizeof(double)));
     HIPCHK(hipMalloc(&s->d_cum, N * sizeof(double)));
+    HIPCHK(hipMalloc(&s->d_idx_cnt, N * sizeof(uint32_t)));
     HIPCHK(hipMalloc(&s->d_avg, N * sizeof(double)));
     if (G) {
         std::vector<double> l1p(G);
@@ -2450,15 +2512,19 @@ static int sim_one_generation(ps_sim *s, uint32_t gen)
         double total = w[0];
         for (uint64_t i = 1; i < N; i++) { s->h_cum[i - 1] = total; total += w[i]; }
         HIPCHK(hipMemcpyAsync(s->d_cum, s->h_cum, (N - 1) * sizeof(double), hipMemcpyHostToDevice, sa));
+        // the N draws, then a counting sort: children are stored in ascending parent order
+        HIPCHK(hipMemsetAsync(s->d_idx_cnt, 0, N * sizeof(uint32_t), sa));
         acc_draw_parents_kernel<<<(uint32_t)((N + 255) / 256), 256, 0, sa>>>(s->d_cum, total, (uint32_t)N, (uint32_t)p.seed,
-                                                                         (uint32_t)(p.seed >> 32), gen, s->d_idx[slot],
-                                                                         s->m_idx[slot]);
+                                                                         (uint32_t)(p.seed >> 32), gen, s->d_idx_cnt);
+        idx_scan_kernel<<<1, 1024, 0, sa>>>(s->d_idx_cnt, (uint32_t)N);
+        idx_fill_kernel<<<(uint32_t)((N + 255) / 256), 256, 0, sa>>>(s->d_idx_cnt, (uint32_t)N, s->d_idx[slot], s->m_idx[slot]);
         HIPCHK(hipGetLastError());
         s->host_draw_ms += ms_since(th0);
         s->host_calls++;
         PSCHK(launch_acc_step(acc, s->d_idx[slot], gen, true, true, sa, nullptr));
     } else {
     PSCHK(ps_draw_parents(w.data(), N, p.seed, gen, s->h_idx[slot]));
+    std::sort(s->h_idx[slot], s->h_idx[slot] + N);      // children in ascending parent order
     s->host_draw_ms += ms_since(th0);
     s->host_calls++;
     // main.rs:447, :455, :462-464 on the accessory stream.  The gather kernel reads the parents
@@ -2505,7 +2571,7 @@ static int sim_one_generation(ps_sim *s, uint32_t gen)
         }
         HIPCHK(hipEventRecord(s->ev_gap[slot][0], sc));
     }
-    PSCHK(step_device(core, s->d_idx[slot], gen, true, true, p.HR_rate > 0.0, sc));
+    PSCHK(step_device(core, s->d_idx[slot], gen, true, true, p.HR_rate > 0.0, sc, nullptr, true));
     if (s->timing) {
         HIPCHK(hipEventRecord(t1, sc));
         s->tev.emplace_back(t0, t1);

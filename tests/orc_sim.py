@@ -39,6 +39,10 @@ class OracleSim:
         rc, idx = o.sample_indices(self.acc, self.seed, gen, self.d.avg_gene_num, avg, self.sel,
                                    self.no_control, self.penalty, self.competition)
         assert rc == 0
+        # the build's generation loop stores the children in ascending parent order (a relabeling of
+        # exchangeable individuals that lets the gather of wide populations work from a window of the parent row);
+        # Population::sample_indices itself (orc.sample_indices) returns the draws in draw order, as the reference does
+        idx = np.sort(idx)
         self.last_idx = idx
         self.core = o.next_generation(self.core, idx)
         self.acc = o.next_generation(self.acc, idx)

@@ -172,3 +172,44 @@ def test_parent_draw_on_host_and_device_agree(pa, orc, monkeypatch, device_draw)
     assert np.array_equal(sim.core_genome.read_matrix(), ref.core)
     assert np.array_equal(sim.pan_genome.read_matrix(), ref.acc)
     sim.close()
+
+
+def _max_window(idx):
+    """widest parent window of a 1024-child segment (core_sweep_window_kernel: > 1536 bytes goes to the wide launch)"""
+    n = len(idx)
+    return max(int(idx[min(c + 1023, n - 1)]) - (int(idx[c]) & ~15) + 1 for c in range(0, n, 1024))
+
+
+@pytest.mark.parametrize("kw,extra,window", [
+    (dict(pop_size=5000, core_size=240, pan_genes=300, core_genes=40, HR_rate=0.3, HGT_rate=0.05), dict(prop_positive=0.5, pos_lambda=0.4), 1),
+    (dict(pop_size=5000, core_size=240, pan_genes=300, core_genes=40, HR_rate=0.3, HGT_rate=0.05), dict(prop_positive=0.5, pos_lambda=0.4), 0),
+    (dict(pop_size=3100, core_size=500, pan_genes=200, core_genes=100, HR_rate=0.6, HGT_rate=0.0), dict(), 1),
+    (dict(pop_size=9000, core_size=100, pan_genes=120, core_genes=20, HR_rate=0.0, HGT_rate=0.1), dict(prop_positive=0.3, pos_lambda=0.3), 1),
+])
+def test_window_sweep_of_wide_populations(pa, orc, kw, extra, window):
+    # The generation loop stores the children in ascending parent order, and populations wider than one wavefront take
+    # the window sweep (a wave gathers from a ~1.1 KB window of the parent row; HR donors recomputed from the old
+    # generation and patched in): with and without selection strong enough that some windows exceed the row buffer (the
+    # second, "wide" launch), with HR off, and against the block sweep (window_sweep = 0) -- always the oracle's run
+    from orc_sim import OracleSim
+    os.environ["PANSIM_WINDOW_SWEEP"] = str(window)
+    try:
+        sim = pa.Simulation(pa.make_params(seed=13, n_gen=5, max_distances=300, **kw, **extra))
+    finally:
+        os.environ.pop("PANSIM_WINDOW_SWEEP", None)
+    ref = OracleSim(seed=13, **kw, **extra)
+    widest = 0
+    for g in range(5):
+        sim.run(1)
+        sim.sync()
+        ref.generation(g)
+        idx = sim.last_parents()
+        assert np.array_equal(idx, ref.last_idx) and (np.diff(idx.astype(np.int64)) >= 0).all()
+        widest = max(widest, _max_window(idx))
+        assert np.array_equal(sim.core_genome.read_matrix(), ref.core), "generation %d" % g
+    assert np.array_equal(sim.pan_genome.read_matrix(), ref.acc)
+    if extra:
+        assert widest > 1536, "the selection of this test no longer produces a wide window (%d)" % widest
+    core_d, acc_d = sim.final_distances()
+    assert np.array_equal(core_d, orc.pairwise_distances(ref.core, True, kw["core_genes"], sim.range1, sim.range2))
+    sim.close()
