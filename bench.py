@@ -318,7 +318,8 @@ def sweep_roofline(r, with_traffic):
     return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
             "kernel": ("core_sweep_wave_kernel<gather,mutate,HR>" if kern == "wave" else
-                       "core_sweep_block_kernel<gather,mutate,HR>"), "avg_launch_ms": r["sweep_avg_ms"],
+                       "core_sweep_window_kernel<gather,mutate,HR> (children in ascending parent order; PANSIM_WINDOW_SWEEP=0: "
+                       "core_sweep_block_kernel)"), "avg_launch_ms": r["sweep_avg_ms"],
             "algorithmic_bytes_per_launch": r["bytes_per_launch"]}
 
 

@@ -594,18 +594,6 @@ __device__ __forceinline__ void ps_dma16(const uint8_t *gsrc, uint8_t *lds_base,
                                           (__attribute__((address_space(3))) void *)lds_base, 16, 0, 0);
 }
 
-// the donor's own mutation of this generation (0: none): level-1 byte of its block, level-2 word if that is a candidate
-__device__ __forceinline__ uint32_t ps_donor_mutation(const core_sweep_args &a, const ps_core_plan &pl, uint32_t site, uint32_t donor,
-                                                      bool do_mut)
-{
-    if (!do_mut) return 0u;
-    const ps_u4 l1 = ps_philox(site, donor >> 4, a.gen, PS_STREAM_CORE_L1, a.k0, a.k1);
-    const uint32_t byte = ps_l1_byte(l1, donor & 15u);
-    if (byte > pl.bC) return 0u;
-    const ps_u4 l2 = ps_philox(site, donor, a.gen, PS_STREAM_CORE_L2, a.k0, a.k1);
-    return ps_classify((byte << 24) | (l2.x >> 8), pl).mut;
-}
-
 // WIDE = false: the segments whose window fits the row buffer (all of them under drift); WIDE = true: a second launch for
 // the others (parents far apart: strong selection against a stretch of the population) -- same code, the bytes gathered
 // straight from the old row in global memory; ascending parents keep every load instruction's 64 addresses in one compact
@@ -624,7 +612,12 @@ __global__ void __launch_bounds__(256, 6) core_sweep_window_kernel(core_sweep_ar
     const ps_core_plan pl = a.plan;
     // the wave's segment, fixed for the launch
     const uint32_t segs = (a.N + 1023u) >> 10;
-    const uint32_t wg = __builtin_amdgcn_readfirstlane(blockIdx.x * 4u + wave);
+    // Workgroups with equal blockIdx.x % 8 share an XCD (observed; affinity only) and with it an L2: group g takes the
+    // rows [rows g / 8, rows (g + 1) / 8) and ALL segments of them, so that a whole row passes through one L2 at about the
+    // same time -- the donors' bytes of HR (anywhere in the row), the overlap of neighbouring windows and the patched
+    // bytes then hit it.
+    const uint32_t grp = blockIdx.x & 7u;
+    const uint32_t wg = __builtin_amdgcn_readfirstlane((blockIdx.x >> 3) * 4u + wave);     // wave index inside its group
     const uint32_t sg = wg % segs;
     const uint32_t c_first = sg * 1024u, c_last = min(c_first + 1023u, a.N - 1u);
     const uint32_t chunk = sg * 64u + lane;                 // the lane's 16-cell chunk of the row (Philox counter word)
@@ -659,20 +652,19 @@ __global__ void __launch_bounds__(256, 6) core_sweep_window_kernel(core_sweep_ar
     // launch zeroes the next one's)
     constexpr uint32_t PS_CHUNK = 4u;
     const uint32_t batches = (a.rows + PS_ROWS - 1u) / PS_ROWS;
-    uint32_t *ctr = a.work_ctr + (a.launch_parity * segs + sg) * 32u;
-    if (wg < segs && lane == 0) a.work_ctr[((a.launch_parity ^ 1u) * segs + wg) * 32u] = 0u;
+    const uint32_t b_lo = (uint32_t)((uint64_t)batches * grp / 8u), b_hi = (uint32_t)((uint64_t)batches * (grp + 1u) / 8u);
+    uint32_t *ctr = a.work_ctr + ((a.launch_parity * 8u + grp) * segs + sg) * 32u;
+    if (wg < segs && lane == 0) a.work_ctr[(((a.launch_parity ^ 1u) * 8u + grp) * segs + wg) * 32u] = 0u;
     if (wide != WIDE) return;                               // the segment belongs to the other launch (no workgroup barriers here)
-    uint32_t nrec = 0;                                   // wave-uniform: HR records waiting at the tail of the queue
-    uint32_t hr_pd0 = 0, hr_slot0 = 0xFFFFFFFFu;
     uint32_t next_chunk = 0;
     if (lane == 0) next_chunk = __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     for (;;) {
         const uint32_t chk = __builtin_amdgcn_readfirstlane(next_chunk);
-        if (chk * PS_CHUNK >= batches) break;
+        if (b_lo + chk * PS_CHUNK >= b_hi) break;
         if (lane == 0) next_chunk = __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     for (uint32_t cb = 0; cb < PS_CHUNK; cb++) {
-        const uint32_t batch = chk * PS_CHUNK + cb;
-        if (batch >= batches) break;
+        const uint32_t batch = b_lo + chk * PS_CHUNK + cb;
+        if (batch >= b_hi) break;
         const uint32_t r0 = batch * PS_ROWS;
         const uint32_t nr = min(PS_ROWS, a.rows - r0);
         // the first window piece of every row of the batch by LDS-DMA: two 16-byte pieces per lane, the second only where
@@ -683,32 +675,8 @@ __global__ void __launch_bounds__(256, 6) core_sweep_window_kernel(core_sweep_ar
             if (ld0) ps_dma16(src + i0, rowbuf + rr * PS_WSTRIDE, NT);
             if (ld1) ps_dma16(src + 1024u + i0, rowbuf + rr * PS_WSTRIDE + 1024u, NT);
         }
-        // HR cells of the PREVIOUS batch (records at the tail of the queue, see the exact pass): their donors' bytes are
-        // fetched from the old generation while this batch's windows are in flight, the donors' own mutation words are
-        // recomputed meanwhile, and the values patch the child rows already stored (same wave, same address, later store)
-        uint32_t h_row = 0, h_cell = 0, h_mut = 0, h_b0 = 0;
-        const bool h_have = DO_HR && lane < nrec;
-        if (DO_HR && nrec) {
-            if (h_have) {
-                const uint4 rec = *(const uint4 *)(q + PS_QCAP - 4u * (lane + 1u));
-                h_row = rec.x; h_cell = rec.y;
-                const uint32_t pd = (rec.w != 0xFFFFFFFFu) ? rec.w : a.idx[rec.z];
-                h_b0 = a.state[(size_t)h_row * a.pitch + pd];
-                h_mut = ps_donor_mutation(a, pl, a.site_offset + h_row, rec.z, DO_MUT);
-            }
-        }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // (the compiler does not track LDS-DMA)
         ps_wave_sync();
-        if (DO_HR && nrec) {
-            if (h_have) a.out[(size_t)h_row * a.pitch + h_cell] = (uint8_t)(h_mut ? h_mut : h_b0);
-            for (uint32_t rix = 64u + lane; rix < nrec; rix += 64u) {          // (more than 64 records: high HR rates)
-                const uint4 rec = *(const uint4 *)(q + PS_QCAP - 4u * (rix + 1u));
-                a.out[(size_t)rec.x * a.pitch + rec.y] =
-                    (uint8_t)ps_donor_value(a, pl, a.state + (size_t)rec.x * a.pitch, a.site_offset + rec.x, rec.z, DO_MUT);
-            }
-            ps_wave_sync();                                  // the records are consumed before the queue is reused
-            nrec = 0;
-        }
         uint32_t qn = 0;
         uint32_t cm[PS_ROWS];
         ps_u4 l1[PS_ROWS];      // (only the non-STASH push loop reads it back)
@@ -827,53 +795,29 @@ __global__ void __launch_bounds__(256, 6) core_sweep_window_kernel(core_sweep_ar
                 n2 += (uint32_t)__popcll(bal);
             }
             ps_wave_sync();
-            // exact pass: level-2 Philox.  A cell that receives a donor allele is not resolved here (two dependent global
-            // loads): it becomes a record (row, cell, donor, donor's parent) at the tail of the queue, resolved at the top
-            // of the next batch; only when the tail has no room (queue nearly full of undecided cells) inline.
-            const uint32_t rec_cap = (PS_QCAP - n2) >> 2;
-            uint32_t pd0 = 0, slot0 = 0xFFFFFFFFu;           // first-iteration record of this lane: the parent load stays in flight
+            // exact pass: level-2 Philox; a cell that receives a donor allele recomputes the donor's post-mutation value
+            // from the old generation (two dependent global loads and the donor's own level-1 / level-2 words).  Measured
+            // against parking such cells in records and patching the stored rows a batch later (donor loads in flight during
+            // the next batch's window DMA): 4.28 against 4.54 ms per 9.8e9 cells -- the patch stores and the later,
+            // cache-cold donor reads cost more than the latency they hide at 24 waves per CU.
             for (uint32_t base = 0; base < n2; base += 64u) {
                 const uint32_t e = base + lane;
-                bool hr_here = false;
-                uint32_t cell = 0, rg = 0, donor = 0;
                 if (e < n2) {
                     const uint32_t ent = q[e];
                     const uint32_t rr = (ent >> 10) & 3u, byte = (ent >> 12) & 0xFFu;
-                    cell = c_first + (ent & 1023u);
-                    rg = min(r0 + rr, a.rows - 1u);
-                    const uint32_t site = a.site_offset + rg;
+                    const uint32_t cell = c_first + (ent & 1023u);
+                    const uint32_t rg = min(r0 + rr, a.rows - 1u), site = a.site_offset + rg;
                     const ps_u4 l2 = ps_philox(site, cell, a.gen, PS_STREAM_CORE_L2, a.k0, a.k1);
                     const ps_cell cl = ps_classify((byte << 24) | (l2.x >> 8), pl);
                     if (DO_MUT && cl.mut) rowbuf[cell_addr(ent)] = (uint8_t)cl.mut;
-                    if (DO_HR && cl.hr && rr < nr) {
-                        hr_here = true;
-                        donor = ps_mulhi(l2.y, a.N - 1u);
+                    if (DO_HR && cl.hr) {
+                        uint32_t donor = ps_mulhi(l2.y, a.N - 1u);
                         donor += (donor >= cell) ? 1u : 0u;                      // population.rs:618
+                        rowbuf[cell_addr(ent)] = (uint8_t)ps_donor_value(a, pl, a.state + (size_t)rg * a.pitch, site, donor, DO_MUT);
                     }
-                }
-                if (DO_HR) {
-                    const uint64_t balh = __ballot(hr_here);
-                    if (hr_here) {
-                        const uint32_t slot = nrec + ps_lane_prefix(balh);
-                        if (slot < rec_cap) {
-                            uint32_t pdw = 0xFFFFFFFFu;
-                            if (base == 0u) { pd0 = a.idx[donor]; slot0 = slot; }       // (written into the record after the row stores)
-                            *(uint4 *)(q + PS_QCAP - 4u * (slot + 1u)) = make_uint4(rg, cell, donor, pdw);
-                        } else {
-                            const ps_u4 dummy = { 0, 0, 0, 0 };
-                            (void)dummy;
-                            // no room: resolve now and patch the LDS row (nobody else reads it)
-                            // cell_addr needs the entry's row: rebuild it from rg
-                            const uint32_t rr2 = rg - r0;
-                            rowbuf[(cell - c_first) + rr2 * PS_WSTRIDE] =
-                                (uint8_t)ps_donor_value(a, pl, a.state + (size_t)rg * a.pitch, a.site_offset + rg, donor, DO_MUT);
-                        }
-                    }
-                    nrec = min(nrec + (uint32_t)__popcll(balh), rec_cap);
                 }
             }
             ps_wave_sync();
-            hr_pd0 = pd0; hr_slot0 = slot0;
         }
 
         if (has_chunk) {
@@ -886,17 +830,8 @@ __global__ void __launch_bounds__(256, 6) core_sweep_window_kernel(core_sweep_ar
                 }
             }
         }
-        if (DO_HR && hr_slot0 != 0xFFFFFFFFu) { q[PS_QCAP - 4u * (hr_slot0 + 1u) + 3u] = hr_pd0; hr_slot0 = 0xFFFFFFFFu; }
         ps_wave_sync();   // the next iteration's DMA overwrites the row buffers
     }
-    }
-    // the last batch's records
-    if (DO_HR && nrec) {
-        for (uint32_t rix = lane; rix < nrec; rix += 64u) {
-            const uint4 rec = *(const uint4 *)(q + PS_QCAP - 4u * (rix + 1u));
-            a.out[(size_t)rec.x * a.pitch + rec.y] =
-                (uint8_t)ps_donor_value(a, pl, a.state + (size_t)rec.x * a.pitch, a.site_offset + rec.x, rec.z, DO_MUT);
-        }
     }
 }
 

@@ -323,7 +323,7 @@ static int pop_create_impl(const ps_config *cfg, const uint8_t *init_vec, ps_pop
         {
             // chunk counters of the dynamic row assignment: 2 sets (alternating by launch) x 8 groups (wave sweep) or
             // x one per 1024-child segment (window sweep), 128 bytes apart
-            const uint64_t nctr = std::max<uint64_t>(8, (N + 1023) / 1024);
+            const uint64_t nctr = 8 * std::max<uint64_t>(1, (N + 1023) / 1024);
             HIPCHK(hipMalloc(&p->d_work, 2 * nctr * 128));
             HIPCHK(hipMemsetAsync(p->d_work, 0, 2 * nctr * 128, p->stream));
         }
@@ -766,7 +766,8 @@ static int launch_core_sweep_window(ps_population *p, const core_sweep_args &a, 
     const uint32_t lds = 4u * (ROWS * PS_WSTRIDE + ps_qcap(ROWS) * 4u);
     const uint32_t bpc = std::max(1u, std::min(6u, p->lds_limit / lds));
     const uint32_t segs = (a.N + 1023u) / 1024u;
-    const uint32_t grid = std::max((segs + 3u) / 4u, 256u * bpc);       // at least one wave per segment
+    // at least one wave per (XCD group, segment); a multiple of the 8 groups
+    const uint32_t grid = (std::max(8u * ((segs + 3u) / 4u), 256u * bpc) + 7u) & ~7u;
     const bool stash = a.plan.bC <= 15u && p->nibble_safe;
     // two launches: the segments whose parent window fits the row buffer, then the others (usually none: its waves
     // leave at once); they alternate the counter sets like any two consecutive launches
@@ -822,6 +823,7 @@ static int launch_core_sweep(ps_population *p, const uint32_t *d_idx, uint32_t g
                   && a.plan.bC <= 126u && !p->force_inline_sweep && !p->force_block_sweep
                   && 4u * (3u * PS_WSTRIDE + ps_qcap(3) * 4u) <= p->lds_limit;
     if (window) {
+        // (a full queue only sends the batch to the queue-free redo; 10 sigma of room as for the wave sweep)
         const double m = 3.0 * 1024.0 * (double)(a.plan.bC + 1u) / 256.0;
         window = m + 10.0 * std::sqrt(m) + 16.0 <= (double)ps_qcap(3);
     }
@@ -830,11 +832,7 @@ static int launch_core_sweep(ps_population *p, const uint32_t *d_idx, uint32_t g
         p->state2 = nullptr;
         window = false;          // no room for the second buffer (cfg4 on a full GPU): the in-place block sweep
     }
-    // (window sweep: nontemporal row traffic only without HR -- the donors' bytes are read from the old rows the other waves
-    // have just streamed, and the patched bytes land in lines this wave has just stored: both want the rows kept in L2 /
-    // Infinity Cache; N = 65536, 150 000 sites: 4.61 ms against 5.09 with nt, 3.94 / 3.75 ms without HR)
-    const int oop = window ? (p->sweep_oop == 1 || p->sweep_oop == 2 ? p->sweep_oop : (hr ? 1 : 2))
-                           : p->sweep_oop < 0 ? (wave ? 2 : 0) : p->sweep_oop;
+    const int oop = window ? (p->sweep_oop == 1 ? 1 : 2) : p->sweep_oop < 0 ? (wave ? 2 : 0) : p->sweep_oop;
     if (oop && (!inline_form || window)) {
         if (!p->state2 && hipMalloc(&p->state2, (uint64_t)p->cfg.ncols * p->pitch) != hipSuccess) {
             (void)hipGetLastError();
