@@ -59,6 +59,19 @@ __device__ __forceinline__ void ps_set_byte(uint32_t (&w)[4], uint32_t k, uint32
     for (uint32_t jj = 0; jj < 4; jj++) w[jj] = (jj == j) ? ((w[jj] & m) | val) : w[jj];
 }
 
+#ifndef PS_WAVE_DMA
+#define PS_WAVE_DMA 0      // wave sweep: 1 = parent rows by LDS-DMA; measured no faster than through registers (profiles/r03_sweep_experiments.md)
+#endif
+// one 16-byte piece per lane straight into LDS (global_load_lds_dwordx4: no VGPR, asynchronous; the LDS destination is
+// the wave-uniform base + lane * 16)
+__device__ __forceinline__ void ps_dma16(const uint8_t *gsrc, uint8_t *lds_base, bool nt)
+{
+    if (nt) __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)gsrc,
+                                             (__attribute__((address_space(3))) void *)lds_base, 16, 0, 2);
+    else __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)gsrc,
+                                          (__attribute__((address_space(3))) void *)lds_base, 16, 0, 0);
+}
+
 // 16-bit mask of the level-1 bytes that may hold an event (byte <= bC)
 __device__ __forceinline__ uint32_t ps_candidate_mask(const ps_u4 &l1, uint32_t bC)
 {
@@ -326,13 +339,24 @@ __global__ void __launch_bounds__(256, PS_ROWS >= 4 ? 6 : 8) core_sweep_wave_ker
         const uint32_t nr = min(PS_ROWS, a.rows - r0);
         // rows past the end of the last batch are processed as copies of the last row and never stored
         uint4 v[PS_ROWS];
+        if (DO_GATHER && PS_WAVE_DMA) {
+            // the parent rows straight into LDS (global_load_lds_dwordx4: no VGPRs, no ds_write; 1 KiB per instruction)
 #pragma unroll
-        for (uint32_t rr = 0; rr < PS_ROWS; rr++)
-            v[rr] = ps_load_row16(a.state + (size_t)min(r0 + rr, a.rows - 1u) * a.pitch + ld_off, NT);
-        if (DO_GATHER) {
-#pragma unroll
-            for (uint32_t rr = 0; rr < PS_ROWS; rr++) *(uint4 *)(rowbuf + rr * 1024u + i0) = v[rr];
+            for (uint32_t rr = 0; rr < PS_ROWS; rr++) {
+                v[rr] = make_uint4(0, 0, 0, 0);
+                ps_dma16(a.state + (size_t)min(r0 + rr, a.rows - 1u) * a.pitch + ld_off, rowbuf + rr * 1024u, NT);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // (the compiler does not track LDS-DMA)
             ps_wave_sync();
+        } else {
+#pragma unroll
+            for (uint32_t rr = 0; rr < PS_ROWS; rr++)
+                v[rr] = ps_load_row16(a.state + (size_t)min(r0 + rr, a.rows - 1u) * a.pitch + ld_off, NT);
+            if (DO_GATHER) {
+#pragma unroll
+                for (uint32_t rr = 0; rr < PS_ROWS; rr++) *(uint4 *)(rowbuf + rr * 1024u + i0) = v[rr];
+                ps_wave_sync();
+            }
         }
         PS_T(0);   // global load + LDS stage
 
@@ -584,15 +608,6 @@ __device__ __forceinline__ uint32_t ps_donor_value(const core_sweep_args &a, con
     return val;
 }
 
-// one 16-byte piece per lane straight into LDS (global_load_lds_dwordx4: no VGPR, asynchronous; the LDS destination is
-// the wave-uniform base + lane * 16)
-__device__ __forceinline__ void ps_dma16(const uint8_t *gsrc, uint8_t *lds_base, bool nt)
-{
-    if (nt) __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)gsrc,
-                                             (__attribute__((address_space(3))) void *)lds_base, 16, 0, 2);
-    else __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)gsrc,
-                                          (__attribute__((address_space(3))) void *)lds_base, 16, 0, 0);
-}
 
 // WIDE = false: the segments whose window fits the row buffer (all of them under drift); WIDE = true: a second launch for
 // the others (parents far apart: strong selection against a stretch of the population) -- same code, the bytes gathered
