@@ -122,7 +122,7 @@ def run(trials, seed=1, log=print):
         # ---- whole generation loop (every 5th trial): random parameters, 4 generations without host sync
         if t % 5 == 0:
             from orc_sim import OracleSim
-            N = int(rng.choice([2, 9, 64, 200, 1030, 2100]))
+            N = int(rng.choice([2, 9, 64, 200, 1030, 2100, 3300, 5000]))
             L = int(rng.choice([1, 17, 300, 1500]))
             cg = int(rng.choice([0, 5, 40]))
             pg = cg + int(rng.choice([0, 1, 64, 500]))
@@ -138,8 +138,12 @@ def run(trials, seed=1, log=print):
             if rng.random() < 0.3:
                 extra["no_control_genome_size"] = True
             seed = int(rng.integers(0, 2**40))
-            for k in ("PANSIM_HEAVY_HGT", "PANSIM_HGT_MODE"):
+            for k in ("PANSIM_HEAVY_HGT", "PANSIM_HGT_MODE", "PANSIM_WINDOW_SWEEP", "PANSIM_SWEEP_OOP"):
                 os.environ.pop(k, None)
+            if rng.random() < 0.5:
+                os.environ["PANSIM_WINDOW_SWEEP"] = str(int(rng.integers(0, 2)))       # window sweep / block sweep for N > 1024
+            if rng.random() < 0.3:
+                os.environ["PANSIM_SWEEP_OOP"] = str(int(rng.integers(0, 3)))
             if rng.random() < 0.4:
                 os.environ["PANSIM_HEAVY_HGT"] = "1"
                 os.environ["PANSIM_HGT_MODE"] = str(int(rng.integers(0, 3)))
@@ -159,6 +163,6 @@ def run(trials, seed=1, log=print):
                     sim.close()
             except (pa.PansimError, AssertionError) as e:
                 log("LOOP skipped", t, kw, extra, str(e)[:80])
-            for k in ("PANSIM_HEAVY_HGT", "PANSIM_HGT_MODE"):
+            for k in ("PANSIM_HEAVY_HGT", "PANSIM_HGT_MODE", "PANSIM_WINDOW_SWEEP", "PANSIM_SWEEP_OOP"):
                 os.environ.pop(k, None)
     return bad
