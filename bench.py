@@ -43,6 +43,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s
 MFMA_I8_PEAK_TOPS = 5000.0   # MI355X_MICROARCH.md, Matrix cores: I8 = 2x BF16 per clock, BF16 ~2.5 PFLOP/s dense
+MFMA_FP4_PEAK_TOPS = 10000.0  # the same table: FP4 (block-scaled) = 4x BF16 per clock, ~10 PFLOP/s dense
 
 CONFIGS = {
     # name: (simulation parameters, P, shard emulation, default steps, default warmup, BASELINE label)
@@ -196,12 +197,14 @@ def distance_roofline(form, N, L_local, G_acc, P, core_ms, acc_ms):
         out.update({"regime": "i (matrix transposed once to 2-bit strings, two strings streamed per pair)", "bound": "hbm",
                     "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                     "algorithmic_bytes": alg})
-    elif form == 6:
+    elif form in (6, 7):
         # all pairs on the matrix cores: N (N - 1) / 2 pairs x L sites x 4 one-hot products, 2 operations each
         ops = float(N) * (N - 1) / 2.0 * L_local * 4.0 * 2.0
         ach = ops / kms / 1e12
-        out.update({"regime": "all pairs, one-hot X X^T on v_mfma_i32_32x32x32_i8 (exact i32 counts), then lookup",
-                    "bound": "mfma-i8", "achieved": ach, "peak": MFMA_I8_PEAK_TOPS, "unit": "TOP/s", "frac": ach / MFMA_I8_PEAK_TOPS,
+        peak = MFMA_I8_PEAK_TOPS if form == 6 else MFMA_FP4_PEAK_TOPS
+        out.update({"regime": ("all pairs, one-hot X X^T on v_mfma_i32_32x32x32_i8 (exact i32 counts), then lookup" if form == 6 else
+                               "all pairs, one-hot X X^T on v_mfma_scale_f32_32x32x64_f8f6f4 (E2M1 {0, 1}, scales 2^0; exact f32 counts), then lookup"),
+                    "bound": "mfma-i8" if form == 6 else "mfma-fp4", "achieved": ach, "peak": peak, "unit": "TOP/s", "frac": ach / peak,
                     "pair_sites_per_s": float(N) * (N - 1) / 2.0 * L_local / kms})
     elif form == 2:
         # all pairs, xor + popcount on nibble strings: 2 VALU wave-instructions per 8 sites of a pair

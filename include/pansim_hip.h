@@ -155,7 +155,8 @@ enum {
     PS_PAIR_FORM_TILED4 = 3,     /* sampled pairs from LDS tiles of nibble strings */
     PS_PAIR_FORM_ROWS = 4,       /* matrix transposed once to bit strings, two strings streamed per pair (HBM bound) */
     PS_PAIR_FORM_SIMPLE = 5,     /* one thread per pair on the byte matrix (matrices with bytes above 15) */
-    PS_PAIR_FORM_ALLPAIRS_MFMA = 6 /* all-pairs one-hot X X^T on the i8 matrix cores (exact i32 counts), then lookup */
+    PS_PAIR_FORM_ALLPAIRS_MFMA = 6, /* all-pairs one-hot X X^T on the i8 matrix cores (exact i32 counts), then lookup */
+    PS_PAIR_FORM_ALLPAIRS_MFMA_FP4 = 7 /* the same on the block-scaled FP4 path (E2M1 {0, 1}, scales 2^0; exact f32 counts) */
 };
 int ps_last_pair_form(ps_population *p);
 /* Population::gene_frequencies (population.rs:840-863): ncols + core_genes values */
@@ -174,7 +175,7 @@ int ps_sync(ps_population *p);
  * distances: 0 = choose by cost, 1 = sampled-pair kernel, 2 = all-pairs tiles + lookup, 3 = sampled-pair
  * kernel in its nibble form even for one-hot matrices, 4 = transposed bit strings streamed per pair -- the
  * sampled form of populations too wide for an LDS tile, 5 = all-pairs xor + popcount tiles even for one-hot matrices,
- * 6 = all pairs; one-hot matrices go to the i8 matrix cores in modes 0, 2 and 6), "pair_ranges" (site ranges of the tiled
+ * 6 = all pairs on the i8 matrix cores; one-hot matrices go to the matrix cores in modes 0 and 2 (FP4 form) and 6 (i8 form)), "pair_ranges" (site ranges of the tiled
  * sampled-pair kernels, 0 = choose; the 16-bit counter cap still applies),
  * "hgt_mode" (accessory recombination: 0 = choose, 1 = one atomic per event, 2 = two passes: bin
  * by recipient partition, OR in LDS images), "hgt_slices" (binned HGT: event slices, 0 = choose), "hgt_list_in_global" (0/1: donor gene lists in

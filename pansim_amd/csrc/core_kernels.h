@@ -2057,6 +2057,118 @@ __global__ void __launch_bounds__(512) core_allpairs_mfma_kernel(const uint32_t 
         }
 }
 
+// The same contraction on the block-scaled FP4 path of the matrix cores (v_mfma_scale_f32_32x32x64_f8f6f4, both operands
+// E2M1, both block scales 2^0): a one-hot allele is the FP4 value 1.0 (0b0010) in one of a site's four nibbles, so a K = 64
+// instruction covers 8 sites per lane half where the i8 form covers 4, at the same cycles (FP4 runs at 4x the bf16 rate,
+// i8 at 2x).  {0, 1} products and f32 sums of at most 2^24 matches are exact, so the integers equal the i8 form's.
+// Table: byte (4 sites) -> 8 bytes (4 sites x 4 nibbles), stored 32 times (64 KB): a lane reads copy (lane & 31), and the
+// 32 lanes a ds_read_b64 serves together cover all 64 banks exactly once.  Two table reads per operand fragment and step.
+typedef int ps_v8i __attribute__((ext_vector_type(8)));
+typedef float ps_v16f __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ uint2 ps_mf_lut_read64(uint32_t raw, uint32_t colofs, uint32_t b)
+{
+    uint32_t addr;      // (byte b of raw) << 8 | colofs  (colofs = copy * 8 < 256); the table sits at LDS offset 0
+    switch (b) {
+    case 0: addr = __builtin_amdgcn_perm(raw, colofs, 0x0c0c0400u); break;
+    case 1: addr = __builtin_amdgcn_perm(raw, colofs, 0x0c0c0500u); break;
+    case 2: addr = __builtin_amdgcn_perm(raw, colofs, 0x0c0c0600u); break;
+    default: addr = __builtin_amdgcn_perm(raw, colofs, 0x0c0c0700u); break;
+    }
+    typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+    const u32x2 v = *(const __attribute__((address_space(3))) u32x2 *)(uintptr_t)addr;
+    return make_uint2(v.x, v.y);
+}
+
+__global__ void __launch_bounds__(512) core_allpairs_mfma_fp4_kernel(const uint32_t *packT, uint32_t WT, uint32_t N, uint32_t *H,
+                                                                     uint32_t chunks_per_range, uint32_t n_chunks, uint32_t ntile)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t lut[];      // 256 entries x 32 copies x 8 bytes = 64 KB, at LDS offset 0
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    for (uint32_t x = tid; x < 256u * 32u; x += 512u) {
+        const uint32_t e = x >> 5;
+        uint2 v;      // site k: 16 bits, nibble ck = 0x2 (E2M1 1.0)
+        v.x = (2u << (4u * (e & 3u))) | (2u << (16u + 4u * ((e >> 2) & 3u)));
+        v.y = (2u << (4u * ((e >> 4) & 3u))) | (2u << (16u + 4u * ((e >> 6) & 3u)));
+        *(uint2 *)(lut + (size_t)x * 8u) = v;        // x = e * 32 + copy
+    }
+    const uint32_t colofs = (lane & 31u) << 3;
+    uint32_t ti = 0, rem = blockIdx.x;
+    while (rem >= ntile - ti) { rem -= ntile - ti; ti++; }
+    const uint32_t tj = ti + rem;
+    const uint32_t wi = wave >> 2, wj = wave & 3u;
+    const uint32_t r = lane & 31u, h = lane >> 5;
+    const uint32_t *src[6];
+#pragma unroll
+    for (uint32_t f = 0; f < 6u; f++) {
+        const uint32_t ind = f < 4u ? ti * PS_MF_TILE + wi * 128u + f * 32u + r : tj * PS_MF_TILE + wj * 64u + (f - 4u) * 32u + r;
+        src[f] = packT + (size_t)min(ind, N - 1u) * WT + h * 4u;
+    }
+    ps_v16f acc[4][2];
+#pragma unroll
+    for (int a = 0; a < 4; a++)
+#pragma unroll
+        for (int b = 0; b < 2; b++)
+#pragma unroll
+            for (int v = 0; v < 16; v++) acc[a][b][v] = 0.0f;
+    const uint32_t c_lo = blockIdx.y * chunks_per_range, c_hi = min(n_chunks, c_lo + chunks_per_range);
+    if (c_lo >= c_hi) return;
+    uint4 cur[6], nxt[6];
+#pragma unroll
+    for (uint32_t f = 0; f < 6u; f++) cur[f] = *(const uint4 *)(src[f] + (size_t)c_lo * PS_MF_CHUNK_DW);
+    __syncthreads();
+    // 8 K-steps per chunk: step t takes bytes 2t, 2t+1 of the lane's 16 (= dword t >> 1, byte pair t & 1)
+    uint2 opA[6][2], opB[6][2];
+    auto fetch = [&](const uint4 &w, uint32_t t, uint2 (&op)[2]) {
+        const uint32_t raw = (t >> 1) == 0u ? w.x : (t >> 1) == 1u ? w.y : (t >> 1) == 2u ? w.z : w.w;
+        op[0] = ps_mf_lut_read64(raw, colofs, 2u * (t & 1u));
+        op[1] = ps_mf_lut_read64(raw, colofs, 2u * (t & 1u) + 1u);
+    };
+#pragma unroll
+    for (uint32_t f = 0; f < 6u; f++) fetch(cur[f], 0u, opA[f]);
+    const int one = 0x7f7f7f7f;          // E8M0 block scale 2^0 in every byte
+    for (uint32_t c = c_lo; c < c_hi; c++) {
+        const uint32_t cn = min(c + 1u, c_hi - 1u);
+#pragma unroll
+        for (uint32_t f = 0; f < 6u; f++) nxt[f] = *(const uint4 *)(src[f] + (size_t)cn * PS_MF_CHUNK_DW);
+#pragma unroll
+        for (uint32_t t = 0; t < 8u; t++) {
+            const uint32_t tn = (t + 1u) & 7u;
+#pragma unroll
+            for (uint32_t f = 0; f < 6u; f++) {
+                if (t & 1u) fetch((t == 7u) ? nxt[f] : cur[f], tn, opA[f]);
+                else fetch((t == 7u) ? nxt[f] : cur[f], tn, opB[f]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int a = 0; a < 4; a++)
+#pragma unroll
+                for (int b = 0; b < 2; b++) {
+                    const uint2 *xa = (t & 1u) ? opB[a] : opA[a], *xb = (t & 1u) ? opB[4 + b] : opA[4 + b];
+                    const ps_v8i va = { (int)xa[0].x, (int)xa[0].y, (int)xa[1].x, (int)xa[1].y, 0, 0, 0, 0 };
+                    const ps_v8i vb = { (int)xb[0].x, (int)xb[0].y, (int)xb[1].x, (int)xb[1].y, 0, 0, 0, 0 };
+                    acc[a][b] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(va, vb, acc[a][b], 4, 4, 0, one, 0, one);
+                }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (uint32_t f = 0; f < 6u; f++) cur[f] = nxt[f];
+    }
+    const uint32_t sites = (c_hi - c_lo) * PS_MF_CHUNK_DW * 16u;
+#pragma unroll
+    for (int a = 0; a < 4; a++)
+#pragma unroll
+        for (int b = 0; b < 2; b++) {
+            const uint32_t j = tj * PS_MF_TILE + wj * 64u + (uint32_t)b * 32u + r;
+#pragma unroll
+            for (int v = 0; v < 16; v++) {
+                const uint32_t i = ti * PS_MF_TILE + wi * 128u + (uint32_t)a * 32u + (uint32_t)((v & 3) + 8 * (v >> 2)) + 4u * h;
+                const uint32_t mism = sites - (uint32_t)acc[a][b][v];
+                if (i < N && j < N && mism) atomicAdd(&H[(size_t)i * N + j], 2u * mism);
+            }
+        }
+}
+
 // out[slot] = H[i][j] for the 256-tiles of core_allpairs_mfma_kernel (tiles ti <= tj were computed; a diagonal
 // tile holds both orders)
 __global__ void core_pair_lookup256_kernel(const uint32_t *H, uint32_t N, const uint32_t *r1, const uint32_t *r2,

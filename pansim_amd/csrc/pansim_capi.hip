@@ -441,7 +441,7 @@ extern "C" int ps_set_tuning(ps_population *p, const char *key, int64_t value)
         if (value < 0 || value > 2) return ps_fail(PS_ERR_INVALID, "hgt_mode must be 0 (auto), 1 (one atomic per event) or 2 (binned by recipient partition, two passes)");
         p->hgt_mode = (int)value;
     } else if (k == "pair_mode") {
-        if (value < 0 || value > 6) return ps_fail(PS_ERR_INVALID, "pair_mode must be 0 (auto), 1 (sampled), 2 (all pairs), 3 (sampled, nibble form even for one-hot matrices), 4 (transposed bit strings, streamed per pair), 5 (all pairs, xor + popcount tiles even for one-hot matrices) or 6 (all pairs, matrix cores when the matrix is one-hot)");
+        if (value < 0 || value > 6) return ps_fail(PS_ERR_INVALID, "pair_mode must be 0 (auto), 1 (sampled), 2 (all pairs), 3 (sampled, nibble form even for one-hot matrices), 4 (transposed bit strings, streamed per pair), 5 (all pairs, xor + popcount tiles even for one-hot matrices) or 6 (all pairs, i8 matrix cores when the matrix is one-hot; mode 2 takes the FP4 form)");
         p->pair_mode = (int)value;
     } else if (k == "pair_ranges") {
         if (value < 0 || value > 65535) return ps_fail(PS_ERR_INVALID, "pair_ranges must be 0 (choose)..65535");
@@ -1572,8 +1572,17 @@ static int pair_counts_device(ps_population *p, uint64_t P, const uint32_t *d_r1
             const uint32_t cpr = (n_chunks + ranges - 1u) / ranges;
             ranges = (n_chunks + cpr - 1u) / cpr;
             const uint32_t lds = 256u * 16u * 16u;
+            // i8 (pair_mode 6) or the block-scaled FP4 form (default: twice the sites per instruction at the same cycles;
+            // a range must stay below 2^24 sites for the f32 sums to be exact)
+            const bool fp4 = p->pair_mode != 6 && (uint64_t)cpr * PS_MF_CHUNK_DW * 16u < (1u << 24);
+            if (fp4) {
+                HIPCHK(hipFuncSetAttribute((const void *)core_allpairs_mfma_fp4_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                hipLaunchKernelGGL(core_allpairs_mfma_fp4_kernel, dim3(tile_pairs, ranges), dim3(512), lds, st, p->d_pack2, WT, N, p->d_H, cpr, n_chunks, ntile);
+                p->last_pair_form = PS_PAIR_FORM_ALLPAIRS_MFMA_FP4;
+            } else {
             HIPCHK(hipFuncSetAttribute((const void *)core_allpairs_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             hipLaunchKernelGGL(core_allpairs_mfma_kernel, dim3(tile_pairs, ranges), dim3(512), lds, st, p->d_pack2, WT, N, p->d_H, cpr, n_chunks, ntile);
+            }
             core_pair_lookup256_kernel<<<(uint32_t)((P + 255) / 256), 256, 0, st>>>(p->d_H, N, d_r1, d_r2, d_perm, P, d_a);
         } else
         if (use_all) {

@@ -284,7 +284,7 @@ def test_pairwise_core_kernels_agree(pa, orc, N, L, P):
         pop.set_tuning("pair_mode", mode)
         pop.load_matrix(m)
         assert np.array_equal(pop.pairwise_counts(r1, r2)[0], want)
-        assert pop.last_pair_form() == {1: 1, 2: 6, 3: 3, 5: 2, 6: 6}[mode]
+        assert pop.last_pair_form() == {1: 1, 2: 7, 3: 3, 5: 2, 6: 6}[mode]
         pop.close()
 
 
@@ -306,11 +306,12 @@ def test_allpairs_matrix_core_form(pa, orc, N, L):
         r1, r2 = r1[sel], r2[sel]
     want = orc.pairwise_hamming_counts(m, 0, L, r1, r2)
     pop = pa.Population(N, L, 4, True, 0.0, 0, 0)
-    pop.set_tuning("pair_mode", 6)
     pop.load_matrix(m)
-    (got,) = pop.pairwise_counts(np.ascontiguousarray(r1), np.ascontiguousarray(r2))
-    assert pop.last_pair_form() == 6
-    assert np.array_equal(got, want)
+    for mode, form in ((6, 6), (2, 7)):          # i8, then the block-scaled FP4 form
+        pop.set_tuning("pair_mode", mode)
+        (got,) = pop.pairwise_counts(np.ascontiguousarray(r1), np.ascontiguousarray(r2))
+        assert pop.last_pair_form() == form
+        assert np.array_equal(got, want), "pair form %d" % form
     # a matrix that is not one-hot falls back to the xor + popcount tiles
     m[0, 0] = 3
     pop.load_matrix(m)
