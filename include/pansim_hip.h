@@ -269,7 +269,12 @@ typedef struct ps_sim ps_sim;
 int ps_sim_create(const ps_sim_params *p, ps_sim **out);
 void ps_sim_destroy(ps_sim *s);
 /* main.rs:429-464 for generations [first, first+count): select, gather x2,
- * mutate x2, HR, HGT.  Asynchronous on the device; ps_sim_sync() waits. */
+ * mutate x2, HR, HGT.  Asynchronous on the device; ps_sim_sync() waits.
+ * The loop stores the children of a generation in ASCENDING PARENT ORDER: the N draws of sample_indices
+ * (population.rs:440-443) are sorted before both gathers.  The individuals of a Wright-Fisher generation
+ * are exchangeable, so this is a relabeling no output statistic of the reference can see; it is what lets populations wider
+ * than one wavefront gather from a ~1 KB window of the parent row.  The Population-level calls (ps_sample_indices,
+ * ps_next_generation, ps_step) take and return any order, like the reference's methods. */
 int ps_sim_run(ps_sim *s, uint32_t first_generation, uint32_t count);
 int ps_sim_sync(ps_sim *s);
 /* Shard the HGT donors over the site shards of this run (shard_rank / shard_count of the parameters) and exchange the
@@ -285,7 +290,7 @@ ps_population *ps_sim_acc(ps_sim *s);
 const double *ps_sim_selection(ps_sim *s);                     /* pan_size values */
 const uint32_t *ps_sim_range1(ps_sim *s);
 const uint32_t *ps_sim_range2(ps_sim *s);
-/* parent indices drawn for the most recent generation (N values) */
+/* parent indices of the most recent generation (N values, ascending: see ps_sim_run) */
 int ps_sim_last_parents(ps_sim *s, uint32_t *out_idx);
 /* Device timing of the core sweep kernel, measured with HIP events on the
  * stream it is launched on, accumulated since the last reset: launches, total

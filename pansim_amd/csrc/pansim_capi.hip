@@ -323,7 +323,7 @@ static int pop_create_impl(const ps_config *cfg, const uint8_t *init_vec, ps_pop
         {
             // chunk counters of the dynamic row assignment: 2 sets (alternating by launch) x 8 groups (wave sweep) or
             // x one per 1024-child segment (window sweep), 128 bytes apart
-            const uint64_t nctr = 8 * std::max<uint64_t>(1, (N + 1023) / 1024);
+            const uint64_t nctr = 8 * std::max<uint64_t>(1, std::min<uint64_t>((N + 1023) / 1024, 4096));      // (window sweep: N <= 2^22)
             HIPCHK(hipMalloc(&p->d_work, 2 * nctr * 128));
             HIPCHK(hipMemsetAsync(p->d_work, 0, 2 * nctr * 128, p->stream));
         }
@@ -820,6 +820,7 @@ static int launch_core_sweep(ps_population *p, const uint32_t *d_idx, uint32_t g
     // generations), the fused gather + mutate (+ HR) step with events, its queue sized like the wave sweep's, a second
     // buffer (it is out of place by construction) and 4 x 6.5 KB of LDS
     bool window = !wave && parents_sorted && ga && mu && a.plan.has_events && p->window_sweep != 0 && p->pitch > 1024
+                  && a.N <= (1u << 22)
                   && a.plan.bC <= 126u && !p->force_inline_sweep && !p->force_block_sweep
                   && 4u * (3u * PS_WSTRIDE + ps_qcap(3) * 4u) <= p->lds_limit;
     if (window) {
@@ -1160,7 +1161,9 @@ extern "C" int ps_step(ps_population *p, uint32_t generation, const uint32_t *sa
     if (!p->rates_set) return ps_fail(PS_ERR_STATE, "ps_set_rates has not been called");
     PSCHK(use_device(p));
     PSCHK(upload_idx(p, sample));
-    PSCHK(step_device(p, p->d_idx, generation, true, true, do_recombine != 0, p->stream));
+    // an ascending sample lets a wide core population take the window sweep (what ps_sim_run's own generations do)
+    const bool sorted = p->cfg.core && std::is_sorted(sample, sample + p->cfg.pop_size);
+    PSCHK(step_device(p, p->d_idx, generation, true, true, do_recombine != 0, p->stream, nullptr, sorted));
     return sync_checked(p);
 }
 

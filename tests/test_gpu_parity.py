@@ -724,6 +724,44 @@ def test_pairwise_accessory_all_pairs_form(pa, orc, N, G, mode):
     pop.close()
 
 
+@pytest.mark.parametrize("N,L,lh,tune", [(1030, 40, 0.02, {}), (3000, 33, 0.02, {}), (9000, 20, 0.0, {}), (20000, 7, 0.1, {}),
+                                         (5000, 30, 0.02, {"sweep_queue_cap": 8}), (4097, 25, 0.02, {"window_sweep": 0}),
+                                         (65536, 3, 0.02, {}), (3000, 20, 0.02, {"sweep_out_of_place": 1})])
+def test_step_with_ascending_parents_takes_the_window_sweep(pa, orc, N, L, lh, tune):
+    # ps_step on a wide population with an ASCENDING sample: the window sweep (a wave gathers its 1024-child segment from a
+    # window of the parent row, HR donors recomputed from the old generation), incl. a skewed sample whose windows exceed the
+    # row buffer (second launch), a full queue (redo path) and the block sweep for comparison -- always the oracle's result
+    rng = np.random.default_rng(N * 3 + L)
+    m0 = _rand_core(rng, N, L)
+    LG = 1200000
+    lm = 0.05 * LG
+    lhr = lh * LG
+    plan = orc.core_plan(lm, lhr, LG)
+    for skew in (False, True):
+        if skew:       # most children from the first tenth of the parents, the rest spread thin: wide windows at the end
+            sample = np.sort(np.concatenate([rng.integers(0, max(1, N // 10), N - N // 20), rng.integers(0, N, N // 20)])).astype(np.uint32)
+        else:
+            sample = np.sort(rng.integers(0, N, N)).astype(np.uint32)
+        want = orc.next_generation(m0, sample)
+        orc.mutate_core(want, 11, 5, 2, plan)
+        if lhr > 0:
+            orc.recombine_core(want, 11, 5, 2, plan)
+        pop = pa.Population(N, L, 4, True, 0.0, 5, 0, col_offset=11, global_cols=LG)
+        for k, v in tune.items():
+            pop.set_tuning(k, v)
+        pop.set_rates([lm], [lhr])
+        pop.load_matrix(m0)
+        pop.step(2, sample, lhr > 0)
+        assert np.array_equal(pop.read_matrix(), want), "skew %s" % skew
+        pop.step(3, sample, lhr > 0)           # a second generation on top (the buffers have swapped)
+        want2 = orc.next_generation(want, sample)
+        orc.mutate_core(want2, 11, 5, 3, plan)
+        if lhr > 0:
+            orc.recombine_core(want2, 11, 5, 3, plan)
+        assert np.array_equal(pop.read_matrix(), want2)
+        pop.close()
+
+
 # ----------------------------------------------------------------------------- BASELINE full sizes
 def _crc(a):
     import zlib
