@@ -180,6 +180,8 @@ int ps_sync(ps_population *p);
  * "hgt_mode" (accessory recombination: 0 = choose, 1 = one atomic per event, 2 = two passes: bin
  * by recipient partition, OR in LDS images), "hgt_slices" (binned HGT: event slices, 0 = choose), "hgt_list_in_global" (0/1: donor gene lists in
  * global scratch instead of LDS; "hgt_bin_list_in_global": the same for the bin pass of the binned form),
+ * "hgt_events_per_thread" (light HGT kernel inside the generation loop: events a thread handles in sequence -- the launch is that
+ * narrow; 0 = whole chip; ps_sim sets it from the estimated sweep time),
  * "hgt_bin_cap" (tests: the bins of the binned HGT hold at most this many events; the rest take the overflow image),
  * "sweep_queue_cap" (tests: the sweeps treat their candidate queues and HR lists as this short, so that the queue-free
  * redo of a batch / row group -- what a full queue falls back to -- runs; 0 = real size),

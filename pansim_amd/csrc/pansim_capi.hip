@@ -300,6 +300,7 @@ static int pop_create_impl(const ps_config *cfg, const uint8_t *init_vec, ps_pop
     if (const char *e = getenv("PANSIM_BLOCK_BATCH")) p->block_batch = (uint32_t)atoi(e);
     if (const char *e = getenv("PANSIM_BLOCK_WAVES")) p->block_waves = (uint32_t)atoi(e);
     if (const char *e = getenv("PANSIM_HGT_SLICES")) p->hgt_slices = (uint32_t)atoi(e);
+    if (const char *e = getenv("PANSIM_HGT_BIN_LIST_GLOBAL")) p->hgt_bin_list_in_global = atoi(e) != 0;
     if (const char *e = getenv("PANSIM_SWEEP_ROWS")) {
         const int v = atoi(e);
         if (v >= 2 && v <= 4) p->sweep_rows = (uint32_t)v;
@@ -459,6 +460,9 @@ extern "C" int ps_set_tuning(ps_population *p, const char *key, int64_t value)
     } else if (k == "hgt_bin_cap") {
         if (value < 0 || value > (1 << 30)) return ps_fail(PS_ERR_INVALID, "hgt_bin_cap must be 0 (sized by the rates)..2^30");
         p->hgt_bin_cap = (uint32_t)value;
+    } else if (k == "hgt_events_per_thread") {
+        if (value < 0 || value > 100000) return ps_fail(PS_ERR_INVALID, "hgt_events_per_thread must be 0 (whole chip)..100000");
+        p->hgt_events_per_thread = (uint32_t)value;
     } else if (k == "window_sweep") {
         if (value < -1 || value > 1) return ps_fail(PS_ERR_INVALID, "window_sweep must be -1 (choose), 0 (block sweep) or 1 (window sweep where the parents are sorted)");
         p->window_sweep = (int)value;

@@ -31,7 +31,7 @@ import time
 wall = {v: [] for v in vals}
 for r in range(rounds):
     for v in (vals if r % 2 == 0 else vals[::-1]):
-        sim.core_genome.set_tuning(key, v)
+        (sim.pan_genome if key.startswith("hgt_") else sim.core_genome).set_tuning(key, v)
         sim.run(8)
         sim.sync()
         sim.sweep_timing(reset=True)
