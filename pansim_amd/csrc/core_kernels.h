@@ -589,6 +589,9 @@ __global__ void __launch_bounds__(256, PS_ROWS >= 4 ? 6 : 8) core_sweep_wave_ker
 // stride in LDS, the window buffer beside them).
 // ---------------------------------------------------------------------------
 #define PS_WCAP 1536u     // bytes of parent window staged at a time (per row)
+#ifndef PS_WINDOW_NT_LOADS
+#define PS_WINDOW_NT_LOADS 0   // window sweep: 1 = the window loads nt as well; 0 = default cache policy (neighbouring windows share lines, HR donors read the rows), stores nt: 4.107 vs 4.142 ms
+#endif
 #define PS_WSTRIDE (PS_WCAP + 16u)   // row buffer stride in LDS: 16 zero bytes behind the window (what cells past N gather)
 
 // post-mutation, pre-recombination value of cell (site row, individual donor), from the old generation
@@ -687,8 +690,8 @@ __global__ void __launch_bounds__(256, 6) core_sweep_window_kernel(core_sweep_ar
 #pragma unroll
         for (uint32_t rr = 0; rr < PS_ROWS; rr++) {
             const uint8_t *src = a.state + (size_t)min(r0 + rr, a.rows - 1u) * a.pitch + w_lo;
-            if (ld0) ps_dma16(src + i0, rowbuf + rr * PS_WSTRIDE, NT);
-            if (ld1) ps_dma16(src + 1024u + i0, rowbuf + rr * PS_WSTRIDE + 1024u, NT);
+            if (ld0) ps_dma16(src + i0, rowbuf + rr * PS_WSTRIDE, NT && PS_WINDOW_NT_LOADS);
+            if (ld1) ps_dma16(src + 1024u + i0, rowbuf + rr * PS_WSTRIDE + 1024u, NT && PS_WINDOW_NT_LOADS);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // (the compiler does not track LDS-DMA)
         ps_wave_sync();
