@@ -767,8 +767,8 @@ template <bool HR>
 static int launch_core_sweep_window(ps_population *p, const core_sweep_args &a, hipStream_t st)
 {
     constexpr uint32_t ROWS = 3;
-    const uint32_t lds = 4u * (ROWS * PS_WSTRIDE + ps_qcap(ROWS) * 4u);
-    const uint32_t bpc = std::max(1u, std::min(6u, p->lds_limit / lds));
+    const uint32_t lds = 4u * (ROWS * PS_WSTRIDE + PS_WQCAP * 4u);
+    const uint32_t bpc = std::max(1u, std::min((uint32_t)PS_WBPC, p->lds_limit / lds));
     const uint32_t segs = (a.N + 1023u) / 1024u;
     // at least one wave per (XCD group, segment); a multiple of the 8 groups
     const uint32_t grid = (std::max(8u * ((segs + 3u) / 4u), 256u * bpc) + 7u) & ~7u;
@@ -822,15 +822,15 @@ static int launch_core_sweep(ps_population *p, const uint32_t *d_idx, uint32_t g
     const bool inline_form = !wave && (p->force_inline_sweep || !block_sweep_geometry(p, ga, mu, hr, &g_probe, &lds_probe, &nw_probe));
     // window sweep: the wave-per-row design for N > 1024 -- needs the children in ascending parent order (ps_sim's
     // generations), the fused gather + mutate (+ HR) step with events, its queue sized like the wave sweep's, a second
-    // buffer (it is out of place by construction) and 4 x 6.5 KB of LDS
+    // buffer (it is out of place by construction) and 4 x 5.6 KB of LDS
     bool window = !wave && parents_sorted && ga && mu && a.plan.has_events && p->window_sweep != 0 && p->pitch > 1024
                   && a.N <= (1u << 22)
                   && a.plan.bC <= 126u && !p->force_inline_sweep && !p->force_block_sweep
-                  && 4u * (3u * PS_WSTRIDE + ps_qcap(3) * 4u) <= p->lds_limit;
+                  && 4u * (3u * PS_WSTRIDE + PS_WQCAP * 4u) <= p->lds_limit;
     if (window) {
         // (a full queue only sends the batch to the queue-free redo; 10 sigma of room as for the wave sweep)
         const double m = 3.0 * 1024.0 * (double)(a.plan.bC + 1u) / 256.0;
-        window = m + 10.0 * std::sqrt(m) + 16.0 <= (double)ps_qcap(3);
+        window = m + 10.0 * std::sqrt(m) + 16.0 <= (double)PS_WQCAP;
     }
     if (window && !p->state2 && hipMalloc(&p->state2, (uint64_t)p->cfg.ncols * p->pitch) != hipSuccess) {
         (void)hipGetLastError();
