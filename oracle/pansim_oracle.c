@@ -329,10 +329,11 @@ uint32_t orc_poisson_from_table(uint32_t u, uint32_t kmin, const uint32_t *thr, 
 
 /* population.rs:544-751, accessory path (HGT), keyed per donor like the reference draws it:
  * donor d of compartment c sends k_d ~ Poisson(lambda_c) events (:599; here the threshold table
- * above on word 0 of Philox(d, 0, gen, HGT_COUNT | c << 8)).  Event j of donor d:
- * Philox(j, d, gen, HGT | c << 8) -> recipient uniform over the others (:584, :616-619; word 1),
+ * above on word 0 of Philox(d, 0, gen, HGT_COUNT | c << 8)).  Events 2m and 2m + 1 of donor d share the
+ * block Philox(m, d, gen, HGT | c << 8): words 0, 1 serve event 2m, words 2, 3 event 2m + 1 ->
+ * recipient uniform over the others (:584, :616-619; the first word of the pair),
  * locus uniform among the donor's present genes of the compartment in the pre-recombination
- * snapshot (:636-680; word 2), value always 1 (:632).  A donor without genes in the compartment
+ * snapshot (:636-680; the second word), value always 1 (:632).  A donor without genes in the compartment
  * sends nothing (:672, :740).  Returns the number of events drawn (donors without genes included). */
 uint64_t orc_recombine_acc(uint8_t *pop, uint64_t N, uint64_t G, uint64_t seed, uint32_t gen,
                            int n_comp, const uint64_t *comp_begin, const uint64_t *comp_end,
@@ -364,11 +365,15 @@ uint64_t orc_recombine_acc(uint8_t *pop, uint64_t N, uint64_t G, uint64_t seed, 
                 if (snap[d * G + g] != 0) list[n++] = (uint32_t)g;
             if (n == 0) continue;                        /* population.rs:672 */
             for (uint32_t j = 0; j < k; j++) {
-                uint32_t ce[4] = { j, (uint32_t)d, gen, stream_e };
-                orc_philox4x32_10(ce, key, w);
-                uint32_t r = mulhi32(w[1], (uint32_t)(N - 1));
+                /* one block per two events: words 0, 1 = (recipient, gene) of event 2m, words 2, 3 of event 2m + 1 */
+                if ((j & 1u) == 0u) {
+                    uint32_t ce[4] = { j >> 1, (uint32_t)d, gen, stream_e };
+                    orc_philox4x32_10(ce, key, w);
+                }
+                const uint32_t h = (j & 1u) * 2u;
+                uint32_t r = mulhi32(w[h], (uint32_t)(N - 1));
                 if (r >= d) r++;                         /* population.rs:618 */
-                pop[(uint64_t)r * G + list[mulhi32(w[2], n)]] = 1;
+                pop[(uint64_t)r * G + list[mulhi32(w[h + 1u], n)]] = 1;
             }
         }
         free(thr);

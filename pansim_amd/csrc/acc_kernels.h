@@ -259,12 +259,17 @@ __global__ void __launch_bounds__(64) acc_hgt_donor_wave_kernel(acc_hgt_args a)
         __threadfence_block();                             // the list is written (it may live in global memory)
         if (n == 0u) continue;                             // population.rs:672
         const uint32_t stream = PS_STREAM_HGT | (c << 8);
-        for (uint32_t j = lane; j < k; j += 64u) {
-            const ps_u4 r = ps_philox(j, dn, a.gen, stream, a.k0, a.k1);
-            uint32_t rc = ps_mulhi(r.y, d.N - 1u);
-            rc += (rc >= dn) ? 1u : 0u;                                 // population.rs:618
-            const uint32_t gene = glist[ps_mulhi(r.z, n)];
-            atomicOr((unsigned long long *)&a.dstI[(uint64_t)rc * d.GW + (gene >> 6)], 1ull << (gene & 63u));
+        // one Philox block serves two events: (x, y) = (recipient, gene) words of event 2 jp, (z, w) of event 2 jp + 1
+        for (uint32_t jp = lane; 2u * jp < k; jp += 64u) {
+            const ps_u4 r = ps_philox(jp, dn, a.gen, stream, a.k0, a.k1);
+#pragma unroll
+            for (uint32_t h = 0; h < 2u; h++) {
+                if (2u * jp + h >= k) break;
+                uint32_t rc = ps_mulhi(h ? r.z : r.x, d.N - 1u);
+                rc += (rc >= dn) ? 1u : 0u;                             // population.rs:618
+                const uint32_t gene = glist[ps_mulhi(h ? r.w : r.y, n)];
+                atomicOr((unsigned long long *)&a.dstI[(uint64_t)rc * d.GW + (gene >> 6)], 1ull << (gene & 63u));
+            }
         }
     }
 }
@@ -305,17 +310,22 @@ __global__ void __launch_bounds__(256) acc_hgt_donor_bin_kernel(acc_hgt_args a)
         const uint32_t n = sh_n;
         if (n == 0u) continue;                             // population.rs:672
         const uint32_t stream = PS_STREAM_HGT | (c << 8);
-        for (uint32_t j = tid; j < k; j += blockDim.x) {
-            const ps_u4 r = ps_philox(j, dn, a.gen, stream, a.k0, a.k1);
-            uint32_t rc = ps_mulhi(r.y, d.N - 1u);
-            rc += (rc >= dn) ? 1u : 0u;                                 // population.rs:618
-            const uint32_t gene = glist[ps_mulhi(r.z, n)];
-            const uint32_t part = ps_mulhi(rc, a.part_magic);           // rc / rows_per_part
-            const uint32_t pos = atomicAdd(&fill[part], 1u);
-            if (pos < cap) mybins[(uint64_t)part * cap + pos] = ((rc - part * a.rows_per_part) << 16) | gene;
-            // a full bin (sized for mean + 10 sigma) drops nothing: the event goes to the overflow image, which the reduce
-            // pass ORs in like one more slice image and clears again
-            else atomicOr(&a.ovf_img[(uint64_t)rc * d.GW + (gene >> 6)], 1ull << (gene & 63u));
+        // one Philox block serves two events: (x, y) = (recipient, gene) words of event 2 jp, (z, w) of event 2 jp + 1
+        for (uint32_t jp = tid; 2u * jp < k; jp += blockDim.x) {
+            const ps_u4 r = ps_philox(jp, dn, a.gen, stream, a.k0, a.k1);
+#pragma unroll
+            for (uint32_t h = 0; h < 2u; h++) {
+                if (2u * jp + h >= k) break;
+                uint32_t rc = ps_mulhi(h ? r.z : r.x, d.N - 1u);
+                rc += (rc >= dn) ? 1u : 0u;                             // population.rs:618
+                const uint32_t gene = glist[ps_mulhi(h ? r.w : r.y, n)];
+                const uint32_t part = ps_mulhi(rc, a.part_magic);       // rc / rows_per_part
+                const uint32_t pos = atomicAdd(&fill[part], 1u);
+                if (pos < cap) mybins[(uint64_t)part * cap + pos] = ((rc - part * a.rows_per_part) << 16) | gene;
+                // a full bin (sized for mean + 10 sigma) drops nothing: the event goes to the overflow image, which the
+                // reduce pass ORs in like one more slice image and clears again
+                else atomicOr(&a.ovf_img[(uint64_t)rc * d.GW + (gene >> 6)], 1ull << (gene & 63u));
+            }
         }
     }
     __syncthreads();

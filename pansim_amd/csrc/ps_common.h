@@ -12,7 +12,7 @@ enum : uint32_t {
     PS_STREAM_CORE_L1 = 1,    // ctr = (site, individual/16, gen): 16 level-1 bytes
     PS_STREAM_CORE_L2 = 2,    // ctr = (site, individual, gen): refine bits + donor
     PS_STREAM_ACC_MUT = 3,    // ctr = (gene/4, individual, gen): 4 flip words
-    PS_STREAM_HGT = 4,        // ctr = (event lo, event hi, gen), | compartment << 8
+    PS_STREAM_HGT = 4,        // ctr = (event / 2, donor, gen), | compartment << 8: (x, y) event 2m, (z, w) event 2m + 1
     PS_STREAM_INIT_CORE = 16, // host sequential streams: ctr = (n lo, n hi, gen)
     PS_STREAM_INIT_ACC = 17,
     PS_STREAM_SELECTION = 18,
