@@ -1521,8 +1521,13 @@ static int pair_counts_device(ps_population *p, uint64_t P, const uint32_t *d_r1
         const bool force_all = p->pair_mode == 2 || p->pair_mode == 5 || p->pair_mode == 6;
         const bool use_rows = p->nibble_safe && !force_all
                               && (p->pair_mode == 4 || (!W && (p->pair_mode == 1 || p->pair_mode == 3 || !all_fits || t_rows < t_all)));
+        // against the sampled LDS-tile kernels (one-hot: ~6.4e13 pair-sites/s): the xor + popcount all-pairs tiles from
+        // P > N^2 / 4 on; the matrix-core form (FP4: ~5.5e14 pair-sites/s over whole 256 x 256 tiles) by the time model --
+        // cfg2 (N = 1000, P = 100 k): 1.53 ms against 2.0 ms
+        const double mf_tiles = std::ceil(N / 256.0) * (std::ceil(N / 256.0) + 1.0) * 0.5 * 65536.0;
+        const bool all_wins = mfma_ok ? mf_tiles / 5.5e14 < (double)P / 6.4e13 : (double)P * 2.0 > all_pairs;
         const bool use_all = !use_rows && all_fits && p->pair_mode != 1 && p->pair_mode != 3
-                             && (force_all || (double)P * 2.0 > all_pairs || !W);
+                             && (force_all || all_wins || !W);
         if (use_rows) {
             p->last_pair_form = PS_PAIR_FORM_ROWS;
             const bool nib = !p->onehot_safe;
