@@ -1579,8 +1579,22 @@ static int pair_counts_device(ps_population *p, uint64_t P, const uint32_t *d_r1
             const uint32_t ntile = (N + PS_MF_TILE - 1u) / PS_MF_TILE;
             const uint32_t tile_pairs = ntile * (ntile + 1u) / 2u;
             const uint32_t n_chunks = WT / PS_MF_CHUNK_DW;
-            // enough (tile, chunk range) workgroups to fill the chip several times over: one 8-wave workgroup per CU
-            uint32_t ranges = std::max(1u, std::min(n_chunks, (256u * 6u + tile_pairs - 1u) / tile_pairs));
+            // (tile, chunk range) workgroups, one 8-wave workgroup per CU at a time (242 VGPRs): the number of ranges that
+            // minimises rounds x (time of a workgroup + its fixed cost) -- whole rounds of 256 workgroups, e.g. N = 8192:
+            // 528 tiles x 16 ranges = 33 rounds exactly, where 3 ranges left the 7th round 19 % full
+            uint32_t ranges = 1;
+            {
+                const double cu_rate = 7.0e14 / 256.0, fixed = 15.0e-6;
+                double best = 1.0e300;
+                const uint32_t r_hi = std::min(n_chunks, std::max(1u, (256u * 64u) / tile_pairs));
+                const uint32_t r_lo = std::min(r_hi, (256u * 4u + tile_pairs - 1u) / tile_pairs);      // >= 4 rounds: edge tiles are lighter
+                for (uint32_t r = r_lo; r <= r_hi; r++) {
+                    const uint32_t c = (n_chunks + r - 1u) / r, rr = (n_chunks + c - 1u) / c;     // ranges actually launched
+                    const double blocks = (double)tile_pairs * rr;
+                    const double t = std::ceil(blocks / 256.0) * (65536.0 * (double)c * PS_MF_CHUNK_DW * 16.0 / cu_rate + fixed);
+                    if (t < best) { best = t; ranges = rr; }
+                }
+            }
             const uint32_t cpr = (n_chunks + ranges - 1u) / ranges;
             ranges = (n_chunks + cpr - 1u) / cpr;
             const uint32_t lds = 256u * 16u * 16u;
