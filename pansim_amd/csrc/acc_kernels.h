@@ -501,23 +501,34 @@ __global__ void acc_gene_counts_kernel(const uint64_t *accG, uint32_t *counts, a
     counts[g] = n;
 }
 
-// distances.rs:55-77 numerators for sampled pairs
-__global__ void acc_pair_counts_kernel(const uint64_t *accI, const uint32_t *r1, const uint32_t *r2,
-                                       const uint32_t *perm, uint64_t P, uint32_t *inter, uint32_t *uni,
-                                       acc_dims d)
+// distances.rs:55-77 numerators for sampled pairs: 8 lanes per pair, each reading every 8th word of the two rows (the 8
+// lanes of a pair read 64 contiguous bytes per load -- one line instead of eight), partial counts summed across the group
+__global__ void __launch_bounds__(256) acc_pair_counts_kernel(const uint64_t *accI, const uint32_t *r1, const uint32_t *r2,
+                                                              const uint32_t *perm, uint64_t P, uint32_t *inter, uint32_t *uni,
+                                                              acc_dims d)
 {
-    const uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= P) return;
-    const uint64_t *x = accI + (uint64_t)r1[k] * d.GW, *y = accI + (uint64_t)r2[k] * d.GW;
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t k = t >> 3;
+    const uint32_t sub = (uint32_t)t & 7u;
     uint32_t in = 0, un = 0;
-    for (uint32_t gw = 0; gw < d.GW; gw++) {
-        const uint64_t a = x[gw], b = y[gw];
-        in += __popcll(a & b);
-        un += __popcll(a | b);
+    if (k < P) {
+        const uint64_t *x = accI + (uint64_t)r1[k] * d.GW, *y = accI + (uint64_t)r2[k] * d.GW;
+        for (uint32_t gw = sub; gw < d.GW; gw += 8u) {
+            const uint64_t a = x[gw], b = y[gw];
+            in += __popcll(a & b);
+            un += __popcll(a | b);
+        }
     }
-    const uint64_t o = perm ? perm[k] : k;
-    inter[o] = in;
-    uni[o] = un;
+#pragma unroll
+    for (int off = 4; off >= 1; off >>= 1) {        // (whole waves take part: k >= P lanes carry zeros)
+        in += __shfl_xor(in, off);
+        un += __shfl_xor(un, off);
+    }
+    if (k < P && sub == 0u) {
+        const uint64_t o = perm ? perm[k] : k;
+        inter[o] = in;
+        uni[o] = un;
+    }
 }
 
 // D-avg, population.rs:753-784 on the accessory matrix: mean Jaccard distance of i to all others, summed in ascending j

@@ -1714,7 +1714,7 @@ static int pair_counts_device(ps_population *p, uint64_t P, const uint32_t *d_r1
             acc_pair_inter_tiled_kernel<<<dim3(nt, nt), 256, 0, st>>>(p->I[p->cur], p->d_H, rowcnt, p->d);
             acc_pair_lookup_kernel<<<(uint32_t)((P + 255) / 256), 256, 0, st>>>(p->d_H, rowcnt, N, d_r1, d_r2, d_perm, P, d_a, d_b);
         } else {
-            acc_pair_counts_kernel<<<(uint32_t)((P + 255) / 256), 256, 0, st>>>(p->I[p->cur], d_r1, d_r2, d_perm, P,
+            acc_pair_counts_kernel<<<(uint32_t)((P * 8 + 255) / 256), 256, 0, st>>>(p->I[p->cur], d_r1, d_r2, d_perm, P,
                                                                              d_a, d_b, p->d);
         }
     }
