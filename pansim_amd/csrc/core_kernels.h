@@ -1840,8 +1840,12 @@ __global__ void core_pair_lookup_kernel(const uint32_t *H, uint32_t N, const uin
 // the four dwords of an item go to LDS as one 16-byte store (word-major tile T[word][individual]), and
 // the tile leaves as 128 contiguous bytes per individual.
 // ---------------------------------------------------------------------------
+#ifndef PS_PT_IB
 #define PS_PT_IB 256u   // individuals per tile
+#endif
+#ifndef PS_PT_WB
 #define PS_PT_WB 32u    // dwords per individual per tile
+#endif
 template <bool NIB>
 __global__ void __launch_bounds__(256) core_packT_kernel(const uint8_t *state, uint32_t N, uint32_t pitch, uint32_t rows,
                                                          uint32_t *packT, uint32_t WT)
@@ -1855,7 +1859,7 @@ __global__ void __launch_bounds__(256) core_packT_kernel(const uint8_t *state, u
     const uint32_t i0 = (blockIdx.x % nib) * PS_PT_IB, w0 = (blockIdx.x / nib) * PS_PT_WB;
     // 64 quads x 32 words = 2048 items, 8 per thread; consecutive lanes take consecutive quads
     for (uint32_t it = tid; it < (PS_PT_IB / 4u) * PS_PT_WB; it += 256u) {
-        const uint32_t qd = it & 63u, w = it >> 6;
+        const uint32_t qd = it % (PS_PT_IB / 4u), w = it / (PS_PT_IB / 4u);
         const uint32_t s_first = (w0 + w) * SPW;
         const bool item_valid = s_first < rows;
         const uint32_t sb = min(s_first, rows - 1u);
@@ -1889,8 +1893,9 @@ __global__ void __launch_bounds__(256) core_packT_kernel(const uint8_t *state, u
     }
     __syncthreads();
     // 8 lanes write the 128 bytes of one individual; 32 individuals per pass of the workgroup
-    const uint32_t k4 = tid & 7u;
-    for (uint32_t ind = tid >> 3; ind < PS_PT_IB; ind += 32u) {
+    constexpr uint32_t LPI = PS_PT_WB / 4u;             // lanes per individual (16 bytes each)
+    const uint32_t k4 = tid % LPI;
+    for (uint32_t ind = tid / LPI; ind < PS_PT_IB; ind += 256u / LPI) {
         if (i0 + ind >= N) break;
         const uint32_t *src = T + (4u * k4) * RS + ind;
         const uint4 o = make_uint4(src[0], src[RS], src[2u * RS], src[3u * RS]);
