@@ -1325,12 +1325,48 @@ extern "C" int ps_draw_parents(const double *weights, uint64_t n, uint64_t seed,
                                uint32_t *out_idx)
 {
     if (!weights || !out_idx || n == 0) return ps_fail(PS_ERR_INVALID, "null argument");
-    std::vector<double> cum(n);
+    static thread_local std::vector<double> cum;
+    cum.resize(n);
     double total = weights[0];
     for (uint64_t i = 1; i < n; i++) { cum[i - 1] = total; total += weights[i]; }
-    for (uint64_t k = 0; k < n; k++) {
-        const double x = hs_f64(seed, PS_STREAM_PARENTS, generation, k) * total;
-        out_idx[k] = (uint32_t)(std::upper_bound(cum.begin(), cum.begin() + (n - 1), x) - cum.begin());
+    // number of cumulative weights <= x among the first m = n - 1 (WeightedIndex::sample): fixed power-of-two steps, the
+    // same for every draw, so that 8 draws advance in lockstep (independent dependency chains; the loop over the lanes
+    // is what the host compiler unrolls / vectorises)
+    const double *A = cum.data();
+    const uint64_t m = n - 1;
+    uint32_t top = 1;
+    while ((uint64_t)top * 2 <= m) top *= 2;
+    constexpr uint32_t LN = 8;
+    auto batch = [&](uint64_t k0, uint32_t *dst) {        // draws k0 .. k0 + 7 (k0 a multiple of 8)
+        // draws 2b and 2b + 1 are the two f64 of block b of the PARENTS stream (hs_f64): one Philox call serves both
+        double x[LN];
+        uint32_t pos[LN];
+        for (uint32_t b = 0; b < LN / 2; b++) {
+            const ps_u4 w = hs_block(seed, PS_STREAM_PARENTS, generation, k0 / 2 + b);
+            const uint64_t x0 = ((uint64_t)w.y << 32) | w.x, x1 = ((uint64_t)w.w << 32) | w.z;
+            x[2 * b] = (double)(x0 >> 11) * (1.0 / 9007199254740992.0) * total;
+            x[2 * b + 1] = (double)(x1 >> 11) * (1.0 / 9007199254740992.0) * total;
+            pos[2 * b] = pos[2 * b + 1] = 0;
+        }
+        for (uint32_t step = top; step; step >>= 1)
+            for (uint32_t l = 0; l < LN; l++) {
+                const uint32_t j = pos[l] + step;
+                const uint32_t jj = j <= m ? j : (uint32_t)m;        // (clamped load, the comparison below rejects j > m)
+                const uint32_t ok = (uint32_t)(j <= m) & (uint32_t)(A[jj - 1] <= x[l]);     // (arithmetic: clang turns a ?: into branches)
+                pos[l] += step & (0u - ok);
+            }
+        for (uint32_t l = 0; l < LN; l++) dst[l] = pos[l];
+    };
+    if (m == 0) {
+        out_idx[0] = 0;
+        return PS_OK;
+    }
+    uint64_t k0 = 0;
+    for (; k0 + LN <= n; k0 += LN) batch(k0, out_idx + k0);
+    if (k0 < n) {
+        uint32_t tail[LN];
+        batch(k0, tail);
+        for (uint64_t k = k0; k < n; k++) out_idx[k] = tail[k - k0];
     }
     return PS_OK;
 }
@@ -2274,6 +2310,7 @@ struct ps_sim {
     hipEvent_t ev_idx[PS_RING] = {}, ev_core[PS_RING] = {};
     hipEvent_t ev_hgt = nullptr;
     hipEvent_t ev_gap[PS_RING][2] = {};   // timestamped events around the sweep when timing is off
+    std::vector<uint32_t> h_kids;       // children per parent (host counting sort of the drawn parents)
     bool heavy_hgt = false;             // expected HGT events per generation >= 1e7: HGT and sweep take turns
     bool slot_used[PS_RING] = {};
     int32_t *h_num_genes = nullptr, *m_num_genes = nullptr;   // pinned + its device alias
@@ -2557,7 +2594,15 @@ static int sim_one_generation(ps_sim *s, uint32_t gen)
         PSCHK(launch_acc_step(acc, s->d_idx[slot], gen, true, true, sa, nullptr));
     } else {
     PSCHK(ps_draw_parents(w.data(), N, p.seed, gen, s->h_idx[slot]));
-    std::sort(s->h_idx[slot], s->h_idx[slot] + N);      // children in ascending parent order
+    {
+        // children in ascending parent order: a counting sort, as on the device
+        s->h_kids.assign(N, 0u);
+        uint32_t *ix = s->h_idx[slot];
+        for (uint64_t k = 0; k < N; k++) s->h_kids[ix[k]]++;
+        uint64_t j = 0;
+        for (uint64_t par = 0; par < N; par++)
+            for (uint32_t c = s->h_kids[par]; c; c--) ix[j++] = (uint32_t)par;
+    }
     s->host_draw_ms += ms_since(th0);
     s->host_calls++;
     // main.rs:447, :455, :462-464 on the accessory stream.  The gather kernel reads the parents
