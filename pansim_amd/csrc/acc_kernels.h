@@ -179,6 +179,20 @@ struct acc_hgt_args {
 // k_d for every (compartment, donor): kmin + number of thresholds <= u (ps_poisson_table).
 // The light form also takes its snapshot copy of the matrix here (copy_src -> copy_dst, grid-stride)
 // instead of a separate blit beside the sweep.
+// k_d of one (compartment, donor): the threshold table searched with word 0 of Philox(d, 0, gen, HGT_COUNT | c << 8)
+__device__ __forceinline__ uint32_t ps_hgt_count(const acc_hgt_args &a, uint32_t c, uint32_t dn)
+{
+    if (!a.ptab[c]) return 0u;
+    const ps_u4 r = ps_philox(dn, 0u, a.gen, PS_STREAM_HGT_COUNT | (c << 8), a.k0, a.k1);
+    uint32_t lo = 0, hi = a.plen[c];
+    while (lo < hi) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (a.ptab[c][mid] <= r.x) lo = mid + 1u; else hi = mid;
+    }
+    if (lo >= a.plen[c]) lo = a.plen[c] - 1u;
+    return a.kmin[c] + lo;
+}
+
 __global__ void __launch_bounds__(256) acc_hgt_counts_kernel(acc_hgt_args a, const uint64_t *copy_src, uint64_t *copy_dst)
 {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -188,18 +202,7 @@ __global__ void __launch_bounds__(256) acc_hgt_counts_kernel(acc_hgt_args a, con
     }
     if (t >= a.n_comp * a.d.N) return;
     const uint32_t c = t / a.d.N, dn = t % a.d.N;
-    uint32_t k = 0;
-    if (a.ptab[c]) {
-        const ps_u4 r = ps_philox(dn, 0u, a.gen, PS_STREAM_HGT_COUNT | (c << 8), a.k0, a.k1);
-        uint32_t lo = 0, hi = a.plen[c];
-        while (lo < hi) {
-            const uint32_t mid = (lo + hi) >> 1;
-            if (a.ptab[c][mid] <= r.x) lo = mid + 1u; else hi = mid;
-        }
-        if (lo >= a.plen[c]) lo = a.plen[c] - 1u;
-        k = a.kmin[c] + lo;
-    }
-    a.kcnt[t] = k;
+    a.kcnt[t] = ps_hgt_count(a, c, dn);
 }
 
 // the present genes of row `row` inside [gb, ge), ascending, into list[]; returns their number
@@ -299,7 +302,7 @@ __global__ void __launch_bounds__(256) acc_hgt_donor_bin_kernel(acc_hgt_args a)
     for (uint32_t item = blockIdx.x; item < items; item += gridDim.x) {
         __syncthreads();                                   // previous list is no longer read; fill[] is zeroed
         const uint32_t c = item / a.dn_cnt, dn = a.dn_lo + item % a.dn_cnt;
-        const uint32_t k = a.kcnt[c * d.N + dn];
+        const uint32_t k = ps_hgt_count(a, c, dn);      // (every thread draws the same count: no separate counts kernel on the chain)
         if (k == 0u) continue;
         if (tid < 64u) {
             const uint32_t m = ps_wave_gene_list(a.srcI + (uint64_t)dn * d.GW, d.GW, a.gb[c], a.ge[c], glist, lane);

@@ -958,7 +958,6 @@ static int launch_acc_hgt(ps_population *p, uint32_t gen, hipStream_t st, hipEve
     const uint32_t list_lds = ((max_comp * 2u + 15u) & ~15u);
     if (list_lds > p->lds_limit)
         return ps_fail(PS_ERR_INVALID, "a compartment of %u genes needs %u bytes of LDS (limit %u)", max_comp, list_lds, p->lds_limit);
-    HIPCHK(hipMemsetAsync(a.work_ctr, 0, sizeof(uint32_t), st));
 
     // Heavy HGT (>= 1e7 expected events per generation: cfg3, and every generation at the cfg4 / cfg5
     // populations): two passes without global atomics -- the donors' events are binned by recipient
@@ -972,9 +971,11 @@ static int launch_acc_hgt(ps_population *p, uint32_t gen, hipStream_t st, hipEve
                         && list_lds + parts * 4u + 64u <= p->lds_limit;
     // event counts per donor; the light form's snapshot copy rides along (donors read the
     // pre-recombination matrix, population.rs:693-695, while recipients are edited in place)
-    {
-        const uint32_t blocks = std::max((items_all + 255) / 256, binned ? 1u : 64u);
-        acc_hgt_counts_kernel<<<blocks, 256, 0, st>>>(a, binned ? nullptr : p->I[p->cur], binned ? nullptr : p->I[1 - p->cur]);
+    // (the binned form draws the count of an item where it serves the item: two launches fewer on the chain)
+    if (!binned) {
+        HIPCHK(hipMemsetAsync(a.work_ctr, 0, sizeof(uint32_t), st));
+        const uint32_t blocks = std::max((items_all + 255) / 256, 64u);
+        acc_hgt_counts_kernel<<<blocks, 256, 0, st>>>(a, p->I[p->cur], p->I[1 - p->cur]);
     }
     if (binned) {
         const uint32_t rows_per_part = (p->d.N + parts - 1) / parts;
