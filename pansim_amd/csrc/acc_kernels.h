@@ -78,6 +78,8 @@ struct acc_step_args {
     uint64_t *dstI;           // rows of the children
     const uint32_t *idx;      // parents; may alias host-mapped pinned memory (one broadcast read per wave)
     uint32_t *idx_out;        // if set, the word-0 threads publish the parents in device memory
+    uint64_t *snapI;          // if set, a second copy of the children: the pre-recombination snapshot of the light HGT form
+    uint32_t *zero_word;      // if set, thread 0 zeroes this word (the HGT kernel's work counter: no memset on the chain)
     acc_dims d;
     uint32_t gen, k0, k1;
     ps_acc_plan plan;
@@ -108,6 +110,7 @@ __global__ void __launch_bounds__(256) acc_step_rows_kernel(acc_step_args a)
 {
     const acc_dims d = a.d;
     const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t == 0 && a.zero_word) *a.zero_word = 0u;
     if (t >= (uint64_t)d.N * d.GW) return;
     const uint32_t i = (uint32_t)(t / d.GW), gw = (uint32_t)(t % d.GW);
     const uint32_t p = DO_GATHER ? a.idx[i] : i;
@@ -134,6 +137,7 @@ __global__ void __launch_bounds__(256) acc_step_rows_kernel(acc_step_args a)
         word ^= (f1 & m1) | (f0 & m0 & ~m1);
     }
     a.dstI[t] = word;
+    if (a.snapI) a.snapI[t] = word;
 }
 
 // ---------------------------------------------------------------------------
@@ -158,7 +162,6 @@ struct acc_hgt_args {
     uint32_t gb[PS_MAX_COMP], ge[PS_MAX_COMP];
     const uint32_t *ptab[PS_MAX_COMP];   // Poisson thresholds of the compartment (null: no events)
     uint32_t kmin[PS_MAX_COMP], plen[PS_MAX_COMP];
-    uint32_t *kcnt;                // events per item, [c * N + d]
     uint32_t *work_ctr;            // dynamic item counter (zeroed before the launch)
     uint32_t gen, k0, k1;
     // binned form (heavy HGT)
@@ -193,16 +196,11 @@ __device__ __forceinline__ uint32_t ps_hgt_count(const acc_hgt_args &a, uint32_t
     return a.kmin[c] + lo;
 }
 
-__global__ void __launch_bounds__(256) acc_hgt_counts_kernel(acc_hgt_args a, const uint64_t *copy_src, uint64_t *copy_dst)
+// the light form's snapshot copy of the matrix when the step before it did not leave one (stand-alone ps_recombine calls)
+__global__ void __launch_bounds__(256) acc_snapshot_kernel(const uint64_t *copy_src, uint64_t *copy_dst, uint64_t words)
 {
-    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (copy_dst) {
-        const uint64_t words = (uint64_t)a.d.N * a.d.GW;
-        for (uint64_t w = t; w < words; w += (uint64_t)gridDim.x * blockDim.x) copy_dst[w] = copy_src[w];
-    }
-    if (t >= a.n_comp * a.d.N) return;
-    const uint32_t c = t / a.d.N, dn = t % a.d.N;
-    a.kcnt[t] = ps_hgt_count(a, c, dn);
+    for (uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; w < words; w += (uint64_t)gridDim.x * blockDim.x)
+        copy_dst[w] = copy_src[w];
 }
 
 // the present genes of row `row` inside [gb, ge), ascending, into list[]; returns their number
@@ -255,7 +253,7 @@ __global__ void __launch_bounds__(64) acc_hgt_donor_wave_kernel(acc_hgt_args a)
         item = __builtin_amdgcn_readfirstlane(item);
         if (item >= items) break;
         const uint32_t c = item / a.dn_cnt, dn = a.dn_lo + item % a.dn_cnt;
-        const uint32_t k = a.kcnt[c * d.N + dn];
+        const uint32_t k = ps_hgt_count(a, c, dn);
         if (k == 0u) continue;
         __threadfence_block();                             // the previous item's list reads are done
         const uint32_t n = ps_wave_gene_list(a.srcI + (uint64_t)dn * d.GW, d.GW, a.gb[c], a.ge[c], glist, lane);
@@ -545,14 +543,22 @@ __global__ void __launch_bounds__(256) acc_pair_counts_kernel(const uint64_t *ac
 // of the 64 + 64 individuals at a time, and every thread counts its 4 x 4 pairs from 4 + 4 LDS reads per word
 // (the plain kernel re-reads a 504-byte row per pair from L2: 0.15 ms alone, 0.31 ms beside the sweep at N = 1000).
 #define PS_PM_CH 16u
-__global__ void __launch_bounds__(256) acc_pair_matrix_tiled_kernel(const uint64_t *accI, double *Dt, acc_dims d,
-                                                                    double core_genes)
+// T = 64: 256 threads per workgroup; T = 32: one wave per workgroup -- four times the workgroups, for populations whose 64 x 64
+// tiles are fewer than the CUs (N = 1000: 136 tiles; beside the sweep a workgroup gets an eighth of its SIMDs' issue slots, so
+// the kernel's time is set by how many CUs it is spread over: 183 us on 136 CUs)
+template <uint32_t T>
+__global__ void __launch_bounds__((T / 4u) * (T / 4u)) acc_pair_matrix_tiled_kernel(const uint64_t *accI, double *Dt, acc_dims d,
+                                                                                   double core_genes)
 {
-    __shared__ uint64_t TA[64u * (PS_PM_CH + 1u)], TB[64u * (PS_PM_CH + 1u)];
+    constexpr uint32_t Q = T / 4u, NT = Q * Q;
+    // D-avg sits on the critical chain of a --competition_strength generation (HGT -> D-avg -> host half -> parents): its waves
+    // take VALU issue before the sweep's on their SIMD (N = 1000 beside the sweep: 225 -> 39 us)
+    __builtin_amdgcn_s_setprio(3);
+    __shared__ uint64_t TA[T * (PS_PM_CH + 1u)], TB[T * (PS_PM_CH + 1u)];
     const uint32_t bi = blockIdx.y, bj = blockIdx.x;
     if (bj < bi) return;
-    const uint32_t tid = threadIdx.x, tx = tid & 15u, ty = tid >> 4;
-    const uint32_t i0 = bi * 64u, j0 = bj * 64u;
+    const uint32_t tid = threadIdx.x, tx = tid % Q, ty = tid / Q;
+    const uint32_t i0 = bi * T, j0 = bj * T;
     uint32_t in[4][4], cx[4] = { 0, 0, 0, 0 }, cy[4] = { 0, 0, 0, 0 };
 #pragma unroll
     for (int a = 0; a < 4; a++)
@@ -560,7 +566,7 @@ __global__ void __launch_bounds__(256) acc_pair_matrix_tiled_kernel(const uint64
         for (int b = 0; b < 4; b++) in[a][b] = 0;
     for (uint32_t g0 = 0; g0 < d.GW; g0 += PS_PM_CH) {
         __syncthreads();
-        for (uint32_t t = tid; t < 64u * PS_PM_CH; t += 256u) {
+        for (uint32_t t = tid; t < T * PS_PM_CH; t += NT) {
             const uint32_t r = t / PS_PM_CH, c = t % PS_PM_CH;
             const bool okc = g0 + c < d.GW;
             TA[r * (PS_PM_CH + 1u) + c] = (okc && i0 + r < d.N) ? accI[(uint64_t)(i0 + r) * d.GW + g0 + c] : 0ull;
@@ -571,9 +577,9 @@ __global__ void __launch_bounds__(256) acc_pair_matrix_tiled_kernel(const uint64
         for (uint32_t c = 0; c < PS_PM_CH; c++) {
             uint64_t x[4], y[4];
 #pragma unroll
-            for (int a = 0; a < 4; a++) x[a] = TA[(ty + 16u * a) * (PS_PM_CH + 1u) + c];
+            for (int a = 0; a < 4; a++) x[a] = TA[(ty + Q * a) * (PS_PM_CH + 1u) + c];
 #pragma unroll
-            for (int b = 0; b < 4; b++) y[b] = TB[(tx + 16u * b) * (PS_PM_CH + 1u) + c];
+            for (int b = 0; b < 4; b++) y[b] = TB[(tx + Q * b) * (PS_PM_CH + 1u) + c];
             // |x u y| = |x| + |y| - |x n y|: only the intersections are counted per pair
 #pragma unroll
             for (int a = 0; a < 4; a++) cx[a] += __popcll(x[a]);
@@ -589,7 +595,7 @@ __global__ void __launch_bounds__(256) acc_pair_matrix_tiled_kernel(const uint64
     for (int a = 0; a < 4; a++)
 #pragma unroll
         for (int b = 0; b < 4; b++) {
-            const uint32_t i = i0 + ty + 16u * a, j = j0 + tx + 16u * b;
+            const uint32_t i = i0 + ty + Q * a, j = j0 + tx + Q * b;
             if (i < d.N && j < d.N) {
                 const double pd = 1.0 - (((double)in[a][b] + 0.0 + core_genes) / ((double)(cx[a] + cy[b] - in[a][b]) + 0.0 + core_genes));
                 Dt[(uint64_t)i * d.N + j] = pd;
@@ -732,25 +738,60 @@ __global__ void __launch_bounds__(256) acc_average_distance_tiled_kernel(const u
     }
 }
 
-__global__ void __launch_bounds__(64) acc_average_from_matrix_kernel(const double *Dt, double *out, acc_dims d)
+// Workgroup = 16 individuals.  The fold of an individual is sequential (f64 addition in ascending j, population.rs:770), the
+// loads are not: all 256 threads stage 64 rows x 16 columns of Dt in LDS (2 x 8.5 KB: it fits beside the sweep) (the next chunk's loads are in flight while 16
+// threads add the current one), so a thread's chain of additions never waits for memory.  (One thread per individual
+// reading its own column, 16 loads in flight: a thousand rows = 62 memory latencies in a row, 43 us at N = 1000 whether
+// beside the sweep or not; deeper register prefetch changed nothing.)
+#define PS_AV_IB 16u
+#define PS_AV_JB 64u
+__global__ void __launch_bounds__(256) acc_average_from_matrix_kernel(const double *Dt, double *out, acc_dims d)
 {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= d.N) return;
-    // the fold is sequential (f64 addition in ascending j), the loads are not: 16 of them in flight per thread
-    // (one dependent load per addition made this kernel 0.27 ms at N = 1000: a thousand L2 latencies in a row)
+    __shared__ double S[2][PS_AV_JB * (PS_AV_IB + 1u)];
+    __builtin_amdgcn_s_setprio(3);          // (on the critical chain of a --competition_strength generation, see the pair matrix)
+    const uint32_t tid = threadIdx.x, i0 = blockIdx.x * PS_AV_IB;
+    const uint32_t row = tid >> 2, quarter = tid & 3u;         // this thread stages 4 doubles of chunk row `row`
+    const uint32_t nch = (d.N + PS_AV_JB - 1u) / PS_AV_JB;
+    double v[4];
+    auto load = [&](uint32_t c) {
+        const uint32_t j = c * PS_AV_JB + row;
+#pragma unroll
+        for (uint32_t u = 0; u < 4u; u++) {
+            const uint32_t ii = i0 + quarter * 4u + u;
+            v[u] = (j < d.N && ii < d.N) ? Dt[(uint64_t)j * d.N + ii] : 0.0;      // = distance(ii, j)
+        }
+    };
+    auto park = [&](uint32_t buf) {
+#pragma unroll
+        for (uint32_t u = 0; u < 4u; u++) S[buf][row * (PS_AV_IB + 1u) + quarter * 4u + u] = v[u];
+    };
+    load(0u);
+    park(0u);
+    __syncthreads();
     double sum = 0.0;
-    uint32_t j = 0;
-    for (; j + 16u <= d.N; j += 16u) {
-        double v[16];
+    const uint32_t i = i0 + tid;             // (threads 0..15 fold)
+    for (uint32_t c = 0; c < nch; c++) {
+        const uint32_t buf = c & 1u;
+        if (c + 1u < nch) load(c + 1u);
+        if (tid < PS_AV_IB) {
+            // 16 LDS reads ahead of their 16 dependent additions (rows past N hold zeros and are skipped like j == i)
+            for (uint32_t jj = 0; jj < PS_AV_JB; jj += 16u) {
+                double w[16];
 #pragma unroll
-        for (uint32_t u = 0; u < 16u; u++) v[u] = Dt[(uint64_t)(j + u) * d.N + i];      // = distance(i, j + u)
+                for (uint32_t u = 0; u < 16u; u++) w[u] = S[buf][(jj + u) * (PS_AV_IB + 1u) + tid];
 #pragma unroll
-        for (uint32_t u = 0; u < 16u; u++)
-            if (j + u != i) sum = sum + v[u];
+                for (uint32_t u = 0; u < 16u; u++) {
+                    const uint32_t j = c * PS_AV_JB + jj + u;
+                    if (j < d.N && j != i) sum = sum + w[u];
+                }
+            }
+        }
+        if (c + 1u < nch) park(buf ^ 1u);
+        __syncthreads();
     }
-    for (; j < d.N; j++)
-        if (j != i) sum = sum + Dt[(uint64_t)j * d.N + i];
-    double fd = sum / (double)(d.N - 1u);
-    if (fd == 0.0) fd = 2.2250738585072014e-308;    // f64::MIN_POSITIVE, population.rs:774-776
-    out[i] = fd;
+    if (tid < PS_AV_IB && i < d.N) {
+        double fd = sum / (double)(d.N - 1u);
+        if (fd == 0.0) fd = 2.2250738585072014e-308;    // f64::MIN_POSITIVE, population.rs:774-776
+        out[i] = fd;
+    }
 }

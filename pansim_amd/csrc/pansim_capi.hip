@@ -201,6 +201,8 @@ struct ps_population {
     uint32_t hgt_bin_cap = 0;            // tests: bins of the binned HGT hold at most this many events (0 = sized for mean + 10 sigma)
     void *hgt_scratch = nullptr;         // slice images of the LDS-partitioned HGT kernel
     uint64_t hgt_scratch_cap = 0;
+    uint64_t *I_snap = nullptr;          // light HGT: the pre-recombination snapshot written by the step before it (ps_sim)
+    bool snap_valid = false;
     uint32_t hgt_slices = 0;             // tuning: event slices of the LDS-partitioned HGT kernel (0 = choose)
     uint32_t hgt_events_per_thread = 0;  // light HGT kernel: 0 = whole chip, else narrow launch (set by ps_sim)
     bool hgt_list_in_global = false;     // light HGT kernel: donor lists in global scratch (no LDS beside the block sweep)
@@ -263,7 +265,7 @@ extern "C" void ps_population_destroy(ps_population *p)
     if (!p) return;
     (void)hipSetDevice(p->device);
     if (p->stream) (void)hipStreamSynchronize(p->stream);
-    void *ptrs[] = { p->state, p->state2, p->d_delta, p->hgt_ovf_img, p->G[0], p->G[1], p->I[0], p->I[1], p->d_ptab[0], p->d_ptab[1], p->hgt_scratch, p->cnt, p->d_idx, p->d_idxT, p->d_work,
+    void *ptrs[] = { p->state, p->state2, p->d_delta, p->hgt_ovf_img, p->G[0], p->G[1], p->I[0], p->I[1], p->I_snap, p->d_ptab[0], p->d_ptab[1], p->hgt_scratch, p->cnt, p->d_idx, p->d_idxT, p->d_work,
                      p->d_log1p, p->d_num_genes, p->d_logw, p->d_pairs, p->d_H, p->d_Dt, p->d_pack2, p->d_pair_part };
     for (void *q : ptrs)
         if (q) (void)hipFree(q);
@@ -515,6 +517,7 @@ extern "C" int ps_load_matrix(ps_population *p, const uint8_t *rows)
                                                                  p->pitch, C);
     } else {
         const uint64_t nI = (uint64_t)p->d.N * p->d.GW;
+        p->snap_valid = false;
         acc_pack_rows_kernel<<<(uint32_t)((nI + 255) / 256), 256, 0, p->stream>>>(d_rows, p->I[p->cur],
                                                                               p->d);
         p->g_valid = false;
@@ -873,8 +876,10 @@ static int launch_core_sweep(ps_population *p, const uint32_t *d_idx, uint32_t g
 // ---------------------------------------------------------------------------
 // accessory step launches
 // ---------------------------------------------------------------------------
+// want_snapshot: the step also leaves the pre-recombination snapshot (and the zeroed work counter) of a light-form HGT that
+// follows on the same stream -- ps_sim's generations: no copy kernel and no memset between the two
 static int launch_acc_step(ps_population *p, const uint32_t *d_idx, uint32_t gen, bool ga, bool mu,
-                           hipStream_t st, uint32_t *idx_out = nullptr)
+                           hipStream_t st, uint32_t *idx_out = nullptr, bool want_snapshot = false)
 {
     if (p->d.G == 0) return PS_OK;
     acc_step_args a;
@@ -882,6 +887,20 @@ static int launch_acc_step(ps_population *p, const uint32_t *d_idx, uint32_t gen
     a.dstI = p->I[1 - p->cur];
     a.idx = d_idx;
     a.idx_out = idx_out;
+    a.snapI = nullptr;
+    a.zero_word = nullptr;
+    p->snap_valid = false;
+    if (want_snapshot) {
+        if (!p->I_snap && hipMalloc(&p->I_snap, (uint64_t)p->d.N * p->d.GW * 8) != hipSuccess) {
+            (void)hipGetLastError();
+            p->I_snap = nullptr;
+        }
+        if (p->I_snap) {
+            a.snapI = p->I_snap;
+            a.zero_word = p->cnt + (uint64_t)PS_MAX_COMP * p->d.N;
+            p->snap_valid = true;
+        }
+    }
     a.d = p->d;
     a.gen = gen;
     a.k0 = (uint32_t)p->cfg.seed;
@@ -941,14 +960,12 @@ static int launch_acc_hgt(ps_population *p, uint32_t gen, hipStream_t st, hipEve
     a.gen = gen;
     a.k0 = (uint32_t)p->cfg.seed;
     a.k1 = (uint32_t)(p->cfg.seed >> 32);
-    a.kcnt = p->cnt;
     a.work_ctr = p->cnt + (uint64_t)PS_MAX_COMP * p->d.N;
     a.overflow_flag = p->d_flag;
     const bool sharded = p->donor_cnt != 0;
     a.dn_lo = sharded ? p->donor_lo : 0u;
     a.dn_cnt = sharded ? p->donor_cnt : p->d.N;
     const uint32_t items = a.n_comp * a.dn_cnt;           // work items of THIS launch: (compartment, own donor)
-    const uint32_t items_all = a.n_comp * p->d.N;
     const uint64_t mat_words = (uint64_t)p->d.N * p->d.GW;
     if (sharded && !p->d_delta) {
         p->delta_words = (mat_words + 4095) & ~4095ull;
@@ -971,11 +988,13 @@ static int launch_acc_hgt(ps_population *p, uint32_t gen, hipStream_t st, hipEve
                         && list_lds + parts * 4u + 64u <= p->lds_limit;
     // event counts per donor; the light form's snapshot copy rides along (donors read the
     // pre-recombination matrix, population.rs:693-695, while recipients are edited in place)
-    // (the binned form draws the count of an item where it serves the item: two launches fewer on the chain)
-    if (!binned) {
+    // (both forms draw the count of an item where they serve the item; the light form's snapshot and zeroed work counter
+    // come from the step before it when ps_sim asked for them, else from a copy kernel and a memset here)
+    const bool have_snapshot = p->snap_valid;
+    p->snap_valid = false;                      // (the matrix is about to change)
+    if (!binned && !have_snapshot) {
         HIPCHK(hipMemsetAsync(a.work_ctr, 0, sizeof(uint32_t), st));
-        const uint32_t blocks = std::max((items_all + 255) / 256, 64u);
-        acc_hgt_counts_kernel<<<blocks, 256, 0, st>>>(a, p->I[p->cur], p->I[1 - p->cur]);
+        acc_snapshot_kernel<<<64, 256, 0, st>>>(p->I[p->cur], p->I[1 - p->cur], mat_words);
     }
     if (binned) {
         const uint32_t rows_per_part = (p->d.N + parts - 1) / parts;
@@ -1040,7 +1059,7 @@ static int launch_acc_hgt(ps_population *p, uint32_t gen, hipStream_t st, hipEve
                                                                               sharded ? p->d_delta : p->I[p->cur], words, n_slices,
                                                                               sharded ? 1 : 0, (unsigned long long *)p->hgt_ovf_img);
     } else {
-        a.srcI = p->I[1 - p->cur];          // the snapshot written by acc_hgt_counts_kernel
+        a.srcI = have_snapshot ? p->I_snap : p->I[1 - p->cur];          // the snapshot (left by the step, or copied above)
         a.dstI = sharded ? p->d_delta : p->I[p->cur];
         if (sharded) HIPCHK(hipMemsetAsync(p->d_delta, 0, mat_words * 8, st));
         // beside a long core sweep (ps_sim sets hgt_events_per_thread) the kernel is launched narrow --
@@ -1398,8 +1417,13 @@ static int average_distance_device(ps_population *p, double *d_out, hipStream_t 
     if (N <= 8192) {
         if (!p->d_Dt) HIPCHK(hipMalloc(&p->d_Dt, N * N * sizeof(double)));
         const uint32_t nt = (uint32_t)((N + 63) / 64);
-        acc_pair_matrix_tiled_kernel<<<dim3(nt, nt), 256, 0, st>>>(p->I[p->cur], p->d_Dt, p->d, (double)p->cfg.core_genes);
-        acc_average_from_matrix_kernel<<<(uint32_t)((N + 63) / 64), 64, 0, st>>>(p->d_Dt, d_out, p->d);
+        if (nt * (nt + 1u) / 2u < 512u) {
+            // few 64 x 64 tiles: 32 x 32 tiles in one-wave workgroups spread over the whole chip
+            const uint32_t nt32 = (uint32_t)((N + 31) / 32);
+            acc_pair_matrix_tiled_kernel<32u><<<dim3(nt32, nt32), 64, 0, st>>>(p->I[p->cur], p->d_Dt, p->d, (double)p->cfg.core_genes);
+        } else
+        acc_pair_matrix_tiled_kernel<64u><<<dim3(nt, nt), 256, 0, st>>>(p->I[p->cur], p->d_Dt, p->d, (double)p->cfg.core_genes);
+        acc_average_from_matrix_kernel<<<(uint32_t)((N + PS_AV_IB - 1) / PS_AV_IB), 256, 0, st>>>(p->d_Dt, d_out, p->d);
     } else {
         acc_average_distance_tiled_kernel<<<(uint32_t)((N + 63) / 64), 256, 0, st>>>(p->I[p->cur], d_out, p->d,
                                                                                 (double)p->cfg.core_genes);
@@ -2592,7 +2616,7 @@ static int sim_one_generation(ps_sim *s, uint32_t gen)
         HIPCHK(hipGetLastError());
         s->host_draw_ms += ms_since(th0);
         s->host_calls++;
-        PSCHK(launch_acc_step(acc, s->d_idx[slot], gen, true, true, sa, nullptr));
+        PSCHK(launch_acc_step(acc, s->d_idx[slot], gen, true, true, sa, nullptr, p.HGT_rate > 0.0));
     } else {
     PSCHK(ps_draw_parents(w.data(), N, p.seed, gen, s->h_idx[slot]));
     {
@@ -2610,7 +2634,7 @@ static int sim_one_generation(ps_sim *s, uint32_t gen)
     // straight from the host-mapped slot (4*N bytes over PCIe) and publishes the device copy the
     // core sweep uses: no copy kernel has to fight the sweep for a CU.
     if (G == 0) HIPCHK(hipMemcpyAsync(s->d_idx[slot], s->h_idx[slot], N * sizeof(uint32_t), hipMemcpyHostToDevice, sa));
-    PSCHK(launch_acc_step(acc, s->m_idx[slot], gen, true, true, sa, s->d_idx[slot]));
+    PSCHK(launch_acc_step(acc, s->m_idx[slot], gen, true, true, sa, s->d_idx[slot], p.HGT_rate > 0.0));
     }
     HIPCHK(hipEventRecord(s->ev_idx[slot], sa));
     // Heavy HGT (cfg3-like rates, >= 1e7 expected events): its scattered loads and the streaming
