@@ -543,27 +543,30 @@ __global__ void __launch_bounds__(256) acc_pair_counts_kernel(const uint64_t *ac
 // of the 64 + 64 individuals at a time, and every thread counts its 4 x 4 pairs from 4 + 4 LDS reads per word
 // (the plain kernel re-reads a 504-byte row per pair from L2: 0.15 ms alone, 0.31 ms beside the sweep at N = 1000).
 #define PS_PM_CH 16u
-// T = 64: 256 threads per workgroup; T = 32: one wave per workgroup -- four times the workgroups, for populations whose 64 x 64
-// tiles are fewer than the CUs (N = 1000: 136 tiles; beside the sweep a workgroup gets an eighth of its SIMDs' issue slots, so
-// the kernel's time is set by how many CUs it is spread over: 183 us on 136 CUs)
-template <uint32_t T>
-__global__ void __launch_bounds__((T / 4u) * (T / 4u)) acc_pair_matrix_tiled_kernel(const uint64_t *accI, double *Dt, acc_dims d,
-                                                                                   double core_genes)
+// T x T pairs per 256-thread workgroup, R x R per thread: 64 / 4, or 32 / 2 -- four times the workgroups -- for populations
+// whose 64 x 64 tiles are fewer than the CUs (N = 1000: 136 tiles)
+template <uint32_t T, uint32_t R>
+__global__ void __launch_bounds__(256, 8) acc_pair_matrix_tiled_kernel(const uint64_t *accI, double *Dt, acc_dims d, double core_genes)
 {
-    constexpr uint32_t Q = T / 4u, NT = Q * Q;
+    constexpr uint32_t Q = T / R, NT = Q * Q;
+    static_assert(NT == 256u, "256 threads: (T / R)^2");
+    // (at most 64 VGPRs -- launch bounds -- because 7 sweep waves of 64 VGPRs leave a SIMD exactly that: with 90 the kernel
+    // could not start before the sweep's waves retired, whatever its priority)
     // D-avg sits on the critical chain of a --competition_strength generation (HGT -> D-avg -> host half -> parents): its waves
-    // take VALU issue before the sweep's on their SIMD (N = 1000 beside the sweep: 225 -> 39 us)
+    // take VALU issue before the sweep's on their SIMD
     __builtin_amdgcn_s_setprio(3);
     __shared__ uint64_t TA[T * (PS_PM_CH + 1u)], TB[T * (PS_PM_CH + 1u)];
     const uint32_t bi = blockIdx.y, bj = blockIdx.x;
     if (bj < bi) return;
     const uint32_t tid = threadIdx.x, tx = tid % Q, ty = tid / Q;
     const uint32_t i0 = bi * T, j0 = bj * T;
-    uint32_t in[4][4], cx[4] = { 0, 0, 0, 0 }, cy[4] = { 0, 0, 0, 0 };
+    uint32_t in[R][R], cx[R], cy[R];
 #pragma unroll
-    for (int a = 0; a < 4; a++)
+    for (uint32_t a = 0; a < R; a++) {
+        cx[a] = cy[a] = 0;
 #pragma unroll
-        for (int b = 0; b < 4; b++) in[a][b] = 0;
+        for (uint32_t b = 0; b < R; b++) in[a][b] = 0;
+    }
     for (uint32_t g0 = 0; g0 < d.GW; g0 += PS_PM_CH) {
         __syncthreads();
         for (uint32_t t = tid; t < T * PS_PM_CH; t += NT) {
@@ -573,28 +576,28 @@ __global__ void __launch_bounds__((T / 4u) * (T / 4u)) acc_pair_matrix_tiled_ker
             TB[r * (PS_PM_CH + 1u) + c] = (okc && j0 + r < d.N) ? accI[(uint64_t)(j0 + r) * d.GW + g0 + c] : 0ull;
         }
         __syncthreads();
-#pragma unroll 4
+#pragma unroll 2
         for (uint32_t c = 0; c < PS_PM_CH; c++) {
-            uint64_t x[4], y[4];
+            uint64_t x[R], y[R];
 #pragma unroll
-            for (int a = 0; a < 4; a++) x[a] = TA[(ty + Q * a) * (PS_PM_CH + 1u) + c];
+            for (uint32_t a = 0; a < R; a++) x[a] = TA[(ty + Q * a) * (PS_PM_CH + 1u) + c];
 #pragma unroll
-            for (int b = 0; b < 4; b++) y[b] = TB[(tx + Q * b) * (PS_PM_CH + 1u) + c];
+            for (uint32_t b = 0; b < R; b++) y[b] = TB[(tx + Q * b) * (PS_PM_CH + 1u) + c];
             // |x u y| = |x| + |y| - |x n y|: only the intersections are counted per pair
 #pragma unroll
-            for (int a = 0; a < 4; a++) cx[a] += __popcll(x[a]);
+            for (uint32_t a = 0; a < R; a++) cx[a] += __popcll(x[a]);
 #pragma unroll
-            for (int b = 0; b < 4; b++) cy[b] += __popcll(y[b]);
+            for (uint32_t b = 0; b < R; b++) cy[b] += __popcll(y[b]);
 #pragma unroll
-            for (int a = 0; a < 4; a++)
+            for (uint32_t a = 0; a < R; a++)
 #pragma unroll
-                for (int b = 0; b < 4; b++) in[a][b] += __popcll(x[a] & y[b]);
+                for (uint32_t b = 0; b < R; b++) in[a][b] += __popcll(x[a] & y[b]);
         }
     }
 #pragma unroll
-    for (int a = 0; a < 4; a++)
+    for (uint32_t a = 0; a < R; a++)
 #pragma unroll
-        for (int b = 0; b < 4; b++) {
+        for (uint32_t b = 0; b < R; b++) {
             const uint32_t i = i0 + ty + Q * a, j = j0 + tx + Q * b;
             if (i < d.N && j < d.N) {
                 const double pd = 1.0 - (((double)in[a][b] + 0.0 + core_genes) / ((double)(cx[a] + cy[b] - in[a][b]) + 0.0 + core_genes));
@@ -745,7 +748,7 @@ __global__ void __launch_bounds__(256) acc_average_distance_tiled_kernel(const u
 // beside the sweep or not; deeper register prefetch changed nothing.)
 #define PS_AV_IB 16u
 #define PS_AV_JB 64u
-__global__ void __launch_bounds__(256) acc_average_from_matrix_kernel(const double *Dt, double *out, acc_dims d)
+__global__ void __launch_bounds__(256, 8) acc_average_from_matrix_kernel(const double *Dt, double *out, acc_dims d)
 {
     __shared__ double S[2][PS_AV_JB * (PS_AV_IB + 1u)];
     __builtin_amdgcn_s_setprio(3);          // (on the critical chain of a --competition_strength generation, see the pair matrix)

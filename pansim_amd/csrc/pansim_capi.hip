@@ -1418,11 +1418,11 @@ static int average_distance_device(ps_population *p, double *d_out, hipStream_t 
         if (!p->d_Dt) HIPCHK(hipMalloc(&p->d_Dt, N * N * sizeof(double)));
         const uint32_t nt = (uint32_t)((N + 63) / 64);
         if (nt * (nt + 1u) / 2u < 512u) {
-            // few 64 x 64 tiles: 32 x 32 tiles in one-wave workgroups spread over the whole chip
+            // few 64 x 64 tiles: 32 x 32 tiles (2 x 2 pairs per thread), four times the workgroups
             const uint32_t nt32 = (uint32_t)((N + 31) / 32);
-            acc_pair_matrix_tiled_kernel<32u><<<dim3(nt32, nt32), 64, 0, st>>>(p->I[p->cur], p->d_Dt, p->d, (double)p->cfg.core_genes);
+            acc_pair_matrix_tiled_kernel<32u, 2u><<<dim3(nt32, nt32), 256, 0, st>>>(p->I[p->cur], p->d_Dt, p->d, (double)p->cfg.core_genes);
         } else
-        acc_pair_matrix_tiled_kernel<64u><<<dim3(nt, nt), 256, 0, st>>>(p->I[p->cur], p->d_Dt, p->d, (double)p->cfg.core_genes);
+        acc_pair_matrix_tiled_kernel<64u, 4u><<<dim3(nt, nt), 256, 0, st>>>(p->I[p->cur], p->d_Dt, p->d, (double)p->cfg.core_genes);
         acc_average_from_matrix_kernel<<<(uint32_t)((N + PS_AV_IB - 1) / PS_AV_IB), 256, 0, st>>>(p->d_Dt, d_out, p->d);
     } else {
         acc_average_distance_tiled_kernel<<<(uint32_t)((N + 63) / 64), 256, 0, st>>>(p->I[p->cur], d_out, p->d,
