@@ -443,25 +443,46 @@ __global__ void __launch_bounds__(256) acc_draw_parents_kernel(const double *cum
     atomicAdd(&cnt[lo], 1u);
 }
 
-// cnt[p] (children of parent p) -> inclusive prefix sums, in place; one workgroup: thread t owns the E consecutive
-// parents t*E .. t*E+E-1, the 1024 partial sums are scanned through LDS
-__global__ void __launch_bounds__(1024) idx_scan_kernel(uint32_t *cnt, uint32_t N)
+// cnt[p] (children of parent p) -> inclusive prefix sums, in place.  One workgroup of 256 threads -- 4 waves: it fits the one
+// wave slot per SIMD the sweeps leave, where a 1024-thread workgroup waited for the sweep to end -- walks tiles of 1024
+// parents: 4 consecutive counts per thread (16-byte accesses), wave prefix sums, the 4 wave totals through LDS, a running carry.
+__global__ void __launch_bounds__(256) idx_scan_kernel(uint32_t *cnt, uint32_t N)
 {
-    __shared__ uint32_t part[1024];
-    const uint32_t t = threadIdx.x, E = (N + 1023u) / 1024u;
-    const uint32_t b = t * E, e = min(N, b + E);
-    uint32_t sum = 0;
-    for (uint32_t p = b; p < e; p++) sum += cnt[p];
-    part[t] = sum;
-    __syncthreads();
-    for (uint32_t off = 1; off < 1024u; off <<= 1) {          // Hillis-Steele inclusive scan of the partial sums
-        const uint32_t v = (t >= off) ? part[t - off] : 0u;
+    __shared__ uint32_t wtot[4];
+    const uint32_t t = threadIdx.x, lane = t & 63u, wave = t >> 6;
+    uint32_t carry = 0;
+    for (uint32_t base = 0; base < N; base += 1024u) {
+        const uint32_t p0 = base + 4u * t;
+        uint32_t v[4];
+#pragma unroll
+        for (uint32_t u = 0; u < 4u; u++) v[u] = (p0 + u < N) ? cnt[p0 + u] : 0u;
+        v[1] += v[0];
+        v[2] += v[1];
+        v[3] += v[2];
+        uint32_t incl = v[3];                     // inclusive wave prefix sum of the threads' totals
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t o = __shfl_up(incl, off, 64);
+            if ((int)lane >= off) incl += o;
+        }
+        if (lane == 63u) wtot[wave] = incl;
         __syncthreads();
-        part[t] += v;
-        __syncthreads();
+        uint32_t before = carry + incl - v[3];
+        for (uint32_t w = 0; w < wave; w++) before += wtot[w];
+        const uint32_t tile_total = wtot[0] + wtot[1] + wtot[2] + wtot[3];
+#pragma unroll
+        for (uint32_t u = 0; u < 4u; u++)
+            if (p0 + u < N) cnt[p0 + u] = before + v[u];
+        carry += tile_total;
+        __syncthreads();                          // wtot is rewritten by the next tile
     }
-    uint32_t run = part[t] - sum;                             // children of all parents before this thread's range
-    for (uint32_t p = b; p < e; p++) { run += cnt[p]; cnt[p] = run; }
+}
+
+// zeroes the counts for the next generation's draws (instead of a memset: the runtime's fill kernel did not fit beside the
+// window sweep and waited 2.8 ms for it to end, with the whole chain of the next generation behind it)
+__global__ void __launch_bounds__(256) idx_zero_kernel(uint32_t *cnt, uint32_t N)
+{
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < N) cnt[k] = 0u;
 }
 
 // child k belongs to the first parent whose inclusive prefix exceeds k; written to device memory (the gather kernels)

@@ -589,14 +589,20 @@ __global__ void __launch_bounds__(256, PS_ROWS >= 4 ? 6 : 8) core_sweep_wave_ker
 // stride in LDS, the window buffer beside them).
 // ---------------------------------------------------------------------------
 #ifndef PS_WCAP
-#define PS_WCAP 1280u     // bytes of parent window staged per row (under drift a window spans 1024 + 15 +- 32 parents)
+#define PS_WCAP 1216u     // bytes of parent window staged per row (under drift a window spans 1024 + 15 +- 32 parents: 5.5 sigma)
 #endif
 #ifndef PS_WQCAP
-#define PS_WQCAP 448u     // candidate queue entries per wave
+#define PS_WQCAP 384u     // candidate queue entries per wave
 #endif
 #ifndef PS_WBPC
-#define PS_WBPC 7         // workgroups per CU the kernel is built for (<= 72 VGPRs) and launched at (7 x 22.2 KB of LDS);
+#define PS_WBPC 7         // workgroups per CU the kernel is launched at (7 x 20.9 KB of LDS);
                           // measured in the loop at N = 65536 / 8: 6 per CU (1536 / 512) 4.055 ms, 7 (1280 / 448) 3.949, 8 (1152 / 384) = 7
+#endif
+#ifndef PS_WLB
+#define PS_WLB 8          // ... and the waves per SIMD it is BUILT for: 64 VGPRs, so that 7 resident waves leave a SIMD 64 VGPRs and
+                          // a wave slot (and the CU 13 KB of LDS) for the accessory chain of the next generation.  At 72 VGPRs
+                          // nothing else fitted: every chain kernel -- even the runtime's memset -- waited for the sweep to end
+                          // (2.8 ms at N = 65536 / 8), and the whole chain ran exposed behind it
 #endif
 #ifndef PS_WINDOW_NT_LOADS
 #define PS_WINDOW_NT_LOADS 0   // window sweep: 1 = the window loads nt as well; 0 = default cache policy (neighbouring windows share lines, HR donors read the rows), stores nt: 4.107 vs 4.142 ms
@@ -626,7 +632,7 @@ __device__ __forceinline__ uint32_t ps_donor_value(const core_sweep_args &a, con
 // straight from the old row in global memory; ascending parents keep every load instruction's 64 addresses in one compact
 // range.  A wave whose segment belongs to the other launch leaves at once.
 template <uint32_t PS_ROWS, bool DO_MUT, bool DO_HR, bool STASH, bool NT, bool WIDE>
-__global__ void __launch_bounds__(256, PS_WBPC) core_sweep_window_kernel(core_sweep_args a)
+__global__ void __launch_bounds__(256, PS_WLB) core_sweep_window_kernel(core_sweep_args a)
 {
     constexpr uint32_t PS_QCAP = PS_WQCAP;
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];

@@ -2521,6 +2521,7 @@ static int sim_create_impl(const ps_sim_params *p, ps_sim *s)
     HIPCHK(hipHostMalloc(&s->h_cum, N * sizeof(double)));
     HIPCHK(hipMalloc(&s->d_cum, N * sizeof(double)));
     HIPCHK(hipMalloc(&s->d_idx_cnt, N * sizeof(uint32_t)));
+    HIPCHK(hipMemset(s->d_idx_cnt, 0, N * sizeof(uint32_t)));
     HIPCHK(hipMalloc(&s->d_avg, N * sizeof(double)));
     if (G) {
         std::vector<double> l1p(G);
@@ -2608,11 +2609,12 @@ static int sim_one_generation(ps_sim *s, uint32_t gen)
         for (uint64_t i = 1; i < N; i++) { s->h_cum[i - 1] = total; total += w[i]; }
         HIPCHK(hipMemcpyAsync(s->d_cum, s->h_cum, (N - 1) * sizeof(double), hipMemcpyHostToDevice, sa));
         // the N draws, then a counting sort: children are stored in ascending parent order
-        HIPCHK(hipMemsetAsync(s->d_idx_cnt, 0, N * sizeof(uint32_t), sa));
+        // (the counts are zero: zeroed at creation, and by idx_zero_kernel after every use)
         acc_draw_parents_kernel<<<(uint32_t)((N + 255) / 256), 256, 0, sa>>>(s->d_cum, total, (uint32_t)N, (uint32_t)p.seed,
                                                                          (uint32_t)(p.seed >> 32), gen, s->d_idx_cnt);
-        idx_scan_kernel<<<1, 1024, 0, sa>>>(s->d_idx_cnt, (uint32_t)N);
+        idx_scan_kernel<<<1, 256, 0, sa>>>(s->d_idx_cnt, (uint32_t)N);
         idx_fill_kernel<<<(uint32_t)((N + 255) / 256), 256, 0, sa>>>(s->d_idx_cnt, (uint32_t)N, s->d_idx[slot], s->m_idx[slot]);
+        idx_zero_kernel<<<(uint32_t)((N + 255) / 256), 256, 0, sa>>>(s->d_idx_cnt, (uint32_t)N);
         HIPCHK(hipGetLastError());
         s->host_draw_ms += ms_since(th0);
         s->host_calls++;
