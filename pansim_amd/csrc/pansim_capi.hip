@@ -999,7 +999,11 @@ static int launch_acc_hgt(ps_population *p, uint32_t gen, hipStream_t st, hipEve
     if (binned) {
         const uint32_t rows_per_part = (p->d.N + parts - 1) / parts;
         const uint32_t lds = (uint32_t)(rows_per_part * row_bytes);
-        const uint32_t donor_blocks = std::min(items, 2048u);
+        // (the apply pass reads one bin per (donor workgroup, partition): with 2048 donor workgroups the bins of a donor shard
+        // held ~60 events and the pass was a chain of small dependent reads -- one rank of 8 at cfg4: 4.78 -> 4.63 ms per
+        // generation at 1024, cfg5pop 4.22 -> 4.13, cfg4 33.66 -> 33.45, cfg3 unchanged; 512: cfg3 0.68 against 0.64)
+        uint32_t donor_blocks = std::min(items, 1024u);
+        if (const char *e = getenv("PANSIM_HGT_DONOR_BLOCKS")) donor_blocks = std::max(1u, std::min(items, (uint32_t)atoi(e)));
         // ~1024 apply workgroups, at most 64 slice images (measured: cfg3 64 of 32/64/128, cfg4 5 of 2/3/5)
         const uint32_t n_slices = std::max(1u, p->hgt_slices ? p->hgt_slices : std::min(64u, (1024u + parts - 1) / parts));
         const uint64_t words = (uint64_t)p->d.N * p->d.GW;
