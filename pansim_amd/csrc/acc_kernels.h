@@ -443,38 +443,67 @@ __global__ void __launch_bounds__(256) acc_draw_parents_kernel(const double *cum
     atomicAdd(&cnt[lo], 1u);
 }
 
-// cnt[p] (children of parent p) -> inclusive prefix sums, in place.  One workgroup of 256 threads -- 4 waves: it fits the one
-// wave slot per SIMD the sweeps leave, where a 1024-thread workgroup waited for the sweep to end -- walks tiles of 1024
-// parents: 4 consecutive counts per thread (16-byte accesses), wave prefix sums, the 4 wave totals through LDS, a running carry.
-__global__ void __launch_bounds__(256) idx_scan_kernel(uint32_t *cnt, uint32_t N)
+// cnt[p] (children of parent p) -> inclusive prefix sums, in place, in three small launches of 256-thread workgroups (4 waves:
+// they fit the one wave slot per SIMD the sweeps leave, where a 1024-thread workgroup waited for the sweep to end; one
+// workgroup walking all tiles took 300 us beside the sweep at N = 65536): the totals of the 1024-parent tiles, their
+// exclusive prefix sums (one workgroup), and the scan of every tile started from its prefix.
+__global__ void __launch_bounds__(256) idx_tile_sums_kernel(const uint32_t *cnt, uint32_t N, uint32_t *tsum)
 {
     __shared__ uint32_t wtot[4];
     const uint32_t t = threadIdx.x, lane = t & 63u, wave = t >> 6;
-    uint32_t carry = 0;
-    for (uint32_t base = 0; base < N; base += 1024u) {
-        const uint32_t p0 = base + 4u * t;
-        uint32_t v[4];
+    const uint32_t p0 = blockIdx.x * 1024u + 4u * t;
+    uint32_t v = 0;
 #pragma unroll
-        for (uint32_t u = 0; u < 4u; u++) v[u] = (p0 + u < N) ? cnt[p0 + u] : 0u;
-        v[1] += v[0];
-        v[2] += v[1];
-        v[3] += v[2];
-        uint32_t incl = v[3];                     // inclusive wave prefix sum of the threads' totals
-        for (int off = 1; off < 64; off <<= 1) {
-            const uint32_t o = __shfl_up(incl, off, 64);
-            if ((int)lane >= off) incl += o;
-        }
-        if (lane == 63u) wtot[wave] = incl;
+    for (uint32_t u = 0; u < 4u; u++) v += (p0 + u < N) ? cnt[p0 + u] : 0u;
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+    if (lane == 0) wtot[wave] = v;
+    __syncthreads();
+    if (t == 0) tsum[blockIdx.x] = wtot[0] + wtot[1] + wtot[2] + wtot[3];
+}
+
+// tsum[0 .. n) -> exclusive prefix sums, in place; one workgroup, n <= 256 * 64
+__global__ void __launch_bounds__(256) idx_tile_prefix_kernel(uint32_t *tsum, uint32_t n)
+{
+    __shared__ uint32_t part[256];
+    const uint32_t t = threadIdx.x, E = (n + 255u) / 256u;
+    const uint32_t b = t * E, e = min(n, b + E);
+    uint32_t sum = 0;
+    for (uint32_t k = b; k < e; k++) sum += tsum[k];
+    part[t] = sum;
+    __syncthreads();
+    for (uint32_t off = 1; off < 256u; off <<= 1) {
+        const uint32_t v = (t >= off) ? part[t - off] : 0u;
         __syncthreads();
-        uint32_t before = carry + incl - v[3];
-        for (uint32_t w = 0; w < wave; w++) before += wtot[w];
-        const uint32_t tile_total = wtot[0] + wtot[1] + wtot[2] + wtot[3];
-#pragma unroll
-        for (uint32_t u = 0; u < 4u; u++)
-            if (p0 + u < N) cnt[p0 + u] = before + v[u];
-        carry += tile_total;
-        __syncthreads();                          // wtot is rewritten by the next tile
+        part[t] += v;
+        __syncthreads();
     }
+    uint32_t run = part[t] - sum;
+    for (uint32_t k = b; k < e; k++) { const uint32_t x = tsum[k]; tsum[k] = run; run += x; }
+}
+
+__global__ void __launch_bounds__(256) idx_scan_kernel(uint32_t *cnt, uint32_t N, const uint32_t *tprefix)
+{
+    __shared__ uint32_t wtot[4];
+    const uint32_t t = threadIdx.x, lane = t & 63u, wave = t >> 6;
+    const uint32_t p0 = blockIdx.x * 1024u + 4u * t;
+    uint32_t v[4];
+#pragma unroll
+    for (uint32_t u = 0; u < 4u; u++) v[u] = (p0 + u < N) ? cnt[p0 + u] : 0u;
+    v[1] += v[0];
+    v[2] += v[1];
+    v[3] += v[2];
+    uint32_t incl = v[3];                     // inclusive wave prefix sum of the threads' totals
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t o = __shfl_up(incl, off, 64);
+        if ((int)lane >= off) incl += o;
+    }
+    if (lane == 63u) wtot[wave] = incl;
+    __syncthreads();
+    uint32_t before = tprefix[blockIdx.x] + incl - v[3];
+    for (uint32_t w = 0; w < wave; w++) before += wtot[w];
+#pragma unroll
+    for (uint32_t u = 0; u < 4u; u++)
+        if (p0 + u < N) cnt[p0 + u] = before + v[u];
 }
 
 // zeroes the counts for the next generation's draws (instead of a memset: the runtime's fill kernel did not fit beside the

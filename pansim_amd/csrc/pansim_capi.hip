@@ -2352,6 +2352,7 @@ struct ps_sim {
     // largest part of the host half there, and the host half does not shrink with the number of site shards)
     bool device_draw = false;
     double *h_cum = nullptr, *d_cum = nullptr;   // cumulative weights: pinned host copy, device copy
+    uint32_t *d_idx_tsum = nullptr;              // ... and the totals / prefixes of its 1024-parent tiles
     uint32_t *d_idx_cnt = nullptr;               // device draw: children per parent, then their inclusive prefix sums (counting sort)
     int last_slot = 0;
     // distance phase (ps_sim_pairwise_distances): pinned numerators, events around the kernels of each matrix
@@ -2396,6 +2397,7 @@ extern "C" void ps_sim_destroy(ps_sim *s)
     if (s->h_cum) (void)hipHostFree(s->h_cum);
     if (s->d_cum) (void)hipFree(s->d_cum);
     if (s->d_idx_cnt) (void)hipFree(s->d_idx_cnt);
+    if (s->d_idx_tsum) (void)hipFree(s->d_idx_tsum);
     if (s->h_cnt) (void)hipHostFree(s->h_cnt);
     for (auto e : s->ev_dist) if (e) (void)hipEventDestroy(e);
     if (s->d_avg) (void)hipFree(s->d_avg);
@@ -2524,6 +2526,7 @@ static int sim_create_impl(const ps_sim_params *p, ps_sim *s)
     if (const char *e = getenv("PANSIM_DEVICE_DRAW")) s->device_draw = atoi(e) != 0;
     HIPCHK(hipHostMalloc(&s->h_cum, N * sizeof(double)));
     HIPCHK(hipMalloc(&s->d_cum, N * sizeof(double)));
+    HIPCHK(hipMalloc(&s->d_idx_tsum, ((N + 1023) / 1024 + 1) * sizeof(uint32_t)));
     HIPCHK(hipMalloc(&s->d_idx_cnt, N * sizeof(uint32_t)));
     HIPCHK(hipMemset(s->d_idx_cnt, 0, N * sizeof(uint32_t)));
     HIPCHK(hipMalloc(&s->d_avg, N * sizeof(double)));
@@ -2616,7 +2619,12 @@ static int sim_one_generation(ps_sim *s, uint32_t gen)
         // (the counts are zero: zeroed at creation, and by idx_zero_kernel after every use)
         acc_draw_parents_kernel<<<(uint32_t)((N + 255) / 256), 256, 0, sa>>>(s->d_cum, total, (uint32_t)N, (uint32_t)p.seed,
                                                                          (uint32_t)(p.seed >> 32), gen, s->d_idx_cnt);
-        idx_scan_kernel<<<1, 256, 0, sa>>>(s->d_idx_cnt, (uint32_t)N);
+        {
+            const uint32_t tiles = (uint32_t)((N + 1023) / 1024);
+            idx_tile_sums_kernel<<<tiles, 256, 0, sa>>>(s->d_idx_cnt, (uint32_t)N, s->d_idx_tsum);
+            idx_tile_prefix_kernel<<<1, 256, 0, sa>>>(s->d_idx_tsum, tiles);
+            idx_scan_kernel<<<tiles, 256, 0, sa>>>(s->d_idx_cnt, (uint32_t)N, s->d_idx_tsum);
+        }
         idx_fill_kernel<<<(uint32_t)((N + 255) / 256), 256, 0, sa>>>(s->d_idx_cnt, (uint32_t)N, s->d_idx[slot], s->m_idx[slot]);
         idx_zero_kernel<<<(uint32_t)((N + 255) / 256), 256, 0, sa>>>(s->d_idx_cnt, (uint32_t)N);
         HIPCHK(hipGetLastError());
