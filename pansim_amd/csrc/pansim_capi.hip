@@ -1251,6 +1251,43 @@ static void par_for(uint64_t n, F fn)      // fn(begin, end) on contiguous slice
     for (auto &x : th) x.join();
 }
 
+// x[i] = exp(x[i] - shift) for all i.  The arguments of the size softmax are (gene count - average) * ln(penalty): a few
+// hundred distinct values among N, so exp is looked up in a small direct-mapped table keyed by the argument's bits (the same
+// bits give the same result: nothing about the output depends on the table's state); vectors without repeats (selection
+// coefficients drawn per gene) keep the threads.
+static void exp_all(double *x, uint64_t n, double shift)
+{
+    constexpr uint32_t TB = 4096;
+    if (n >= 2048) {
+        static thread_local std::vector<uint64_t> key;
+        static thread_local std::vector<double> val;
+        key.assign(TB, ~0ull);           // (~0 is a NaN pattern: its exp is computed, never looked up)
+        val.resize(TB);
+        auto one = [&](double a, uint64_t &miss) -> double {
+            uint64_t bits;
+            memcpy(&bits, &a, 8);
+            const uint32_t h = (uint32_t)((bits * 0x9E3779B97F4A7C15ull) >> 52);
+            if (key[h] == bits && bits != ~0ull) return val[h];
+            miss++;
+            const double e = std::exp(a);
+            key[h] = bits;
+            val[h] = e;
+            return e;
+        };
+        // a prefix decides: mostly repeats -> the table for everything
+        const uint64_t probe = 1024;
+        uint64_t miss = 0;
+        for (uint64_t i = 0; i < probe; i++) x[i] = one(x[i] - shift, miss);
+        if (miss * 4 <= probe) {
+            for (uint64_t i = probe; i < n; i++) x[i] = one(x[i] - shift, miss);
+            return;
+        }
+        par_for(n - probe, [&](uint64_t a, uint64_t b) { for (uint64_t i = probe + a; i < probe + b; i++) x[i] = std::exp(x[i] - shift); });
+        return;
+    }
+    par_for(n, [&](uint64_t a, uint64_t b) { for (uint64_t i = a; i < b; i++) x[i] = std::exp(x[i] - shift); });
+}
+
 // softmax as population.rs:325-340 / :356-361 / :377-382 write it: lse = ln_sum_exp(v) (logsumexp 0.1, in
 // its one-pass streaming form: for every x, `if x <= alpha { r += exp(x - alpha) } else { r *= exp(alpha - x);
 // r += 1; alpha = x }`, result ln(r) + alpha), v = exp(v - lse), sum = left-to-right sum of v, v = v / sum
@@ -1281,14 +1318,14 @@ static void softmax_norm(double *v, uint64_t n, std::vector<double> &scratch)
         if (v[i] <= alpha) { arg[i] = v[i] - alpha; upd[i] = 0; }
         else { arg[i] = alpha - v[i]; upd[i] = 1; alpha = v[i]; }
     }
-    par_for(n, [&](uint64_t a, uint64_t b) { for (uint64_t i = a; i < b; i++) arg[i] = std::exp(arg[i]); });
+    exp_all(arg, n, 0.0);
     double r = 0.0;
     for (uint64_t i = 0; i < n; i++) {
         if (upd[i]) { r *= arg[i]; r += 1.0; }
         else r += arg[i];
     }
     const double lse = std::log(r) + alpha;
-    par_for(n, [&](uint64_t a, uint64_t b) { for (uint64_t i = a; i < b; i++) v[i] = std::exp(v[i] - lse); });
+    exp_all(v, n, lse);
     double sum = 0.0;
     for (uint64_t i = 0; i < n; i++) sum += v[i];
     for (uint64_t i = 0; i < n; i++) v[i] = (v[i] != -INFINITY) ? v[i] / sum : 0.0;
