@@ -825,7 +825,7 @@ static int launch_core_sweep(ps_population *p, const uint32_t *d_idx, uint32_t g
     const bool inline_form = !wave && (p->force_inline_sweep || !block_sweep_geometry(p, ga, mu, hr, &g_probe, &lds_probe, &nw_probe));
     // window sweep: the wave-per-row design for N > 1024 -- needs the children in ascending parent order (ps_sim's
     // generations), the fused gather + mutate (+ HR) step with events, its queue sized like the wave sweep's, a second
-    // buffer (it is out of place by construction) and 4 x 5.6 KB of LDS
+    // buffer (it is out of place by construction) and 4 x 5.2 KB of LDS
     bool window = !wave && parents_sorted && ga && mu && a.plan.has_events && p->window_sweep != 0 && p->pitch > 1024
                   && a.N <= (1u << 22)
                   && a.plan.bC <= 126u && !p->force_inline_sweep && !p->force_block_sweep
