@@ -151,6 +151,19 @@ def test_sample_weights_and_draws_match_oracle(pa, orc):
     assert rc == 0 and np.array_equal(w, ow)
 
 
+@pytest.mark.parametrize("N", [1, 2, 7, 8, 9, 63, 1023, 1025, 5001])
+def test_draw_parents_batches_of_eight_match_oracle(pa, orc, N):
+    # the library draws eight parents at a time (one Philox block per two draws, eight binary searches in lockstep
+    # through fixed power-of-two steps); the oracle draws them one by one (population.rs:440-443): sizes around the
+    # batch and the step boundaries, flat / skewed / mostly-zero weights, draws exactly on cumulative boundaries
+    rng = np.random.default_rng(N)
+    for trial, w in enumerate((np.ones(N), rng.random(N) ** 8 + 1e-12, np.where(rng.random(N) < 0.9, 0.0, 1.0) + (np.arange(N) == N - 1),
+                               np.full(N, 0.5 ** 20))):
+        idx = pa.draw_parents(w.astype(np.float64), 5, trial)
+        rc, oidx = orc.draw_parents(w.astype(np.float64), 5, trial)
+        assert rc == 0 and np.array_equal(idx, oidx) and idx.max() < N
+
+
 @pytest.mark.parametrize("N", [40000, 65536])
 def test_sample_weights_large_populations_match_oracle(pa, orc, N):
     # the library takes the independent exp / ln calls of the three softmaxes on several host threads and N
