@@ -133,10 +133,10 @@ def test_config5_cli_print_matrices(pa, orc, tmp_path):
         assert (tmp_path / ("run" + suffix)).read_bytes() == (tmp_path / ("want" + suffix)).read_bytes()
 
 
-@pytest.mark.parametrize("N,G,cg", [(1000, 4000, 2000), (8200, 130, 7), (9000, 64, 0)])
+@pytest.mark.parametrize("N,G,cg", [(1000, 4000, 2000), (2100, 130, 7), (4100, 70, 3), (8200, 130, 7), (9000, 64, 0)])
 def test_average_distance_large_populations(pa, orc, N, G, cg):
-    # D-avg (population.rs:753-784): the N x N matrix form at the cfg2 population and the streaming
-    # kernel that serves N > 8192, both against the oracle's left-to-right fold
+    # D-avg (population.rs:753-784): the N x N matrix form at the cfg2 population (32 x 32 tiles), at populations
+    # with enough 64 x 64 tiles, and the streaming kernel that serves N > 8192, all against the oracle's left-to-right fold
     rng = np.random.default_rng(N + G)
     m = (rng.random((N, G)) < 0.3).astype(np.uint8)
     m[5] = m[6]                                       # a zero distance inside the fold
