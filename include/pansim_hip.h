@@ -283,10 +283,30 @@ int ps_sim_sync(ps_sim *s);
  * deltas through `fn` once per generation (ps_set_donor_shard).  Every shard of the run must do the same. */
 int ps_sim_set_exchange(ps_sim *s, ps_exchange_fn fn, void *ctx);
 /* bench.py --emulate-shard K: play shard 0 of K with the exchange stood in for by device-local copies of the same
- * volume (timing only: the other shards' events never arrive). */
+ * volume plus a kernel that holds the stream for the time the two collectives would take on one xGMI link each
+ * (latency + (K - 1) / K x bytes / link rate per collective; timing only: the other shards' events never arrive). */
 int ps_sim_emulate_exchange(ps_sim *s, int n_shards);
+/* what the emulation charged: modelled link time (microseconds, accumulated since the last reset) and its parameters */
+int ps_sim_emulated_link_time(ps_sim *s, int reset, double *modelled_us, double *link_gbps, double *latency_us);
 /* exchange calls and bytes this shard sent + received in them since the last reset */
 int ps_sim_exchange_stats(ps_sim *s, int reset, uint64_t *calls, uint64_t *bytes);
+/* The native provider of ps_exchange_fn for one process per GPU: the OR over RCCL (all-to-all of the K row slices with
+ * ncclSend / ncclRecv, a local OR, ncclAllGather of the merged slices -- RCCL has no OR reduction).  librccl.so is
+ * opened with dlopen at the first call; without it these calls fail with PS_ERR_NO_DEVICE (ps_rccl_available() = 0)
+ * and nothing else of the library is affected.  Rank 0 draws the id, the host carries its 128 bytes to the other ranks
+ * (MPI, a file, a socket), every rank creates its handle (collective: ncclCommInitRank) and installs
+ *     ps_sim_set_exchange(sim, ps_exchange_rccl, handle).
+ * The reference has no counterpart (one process, rayon threads: main.rs:249-257). */
+#define PS_RCCL_ID_BYTES 128
+typedef struct ps_rccl_exchange ps_rccl_exchange;
+int ps_rccl_available(void);
+int ps_rccl_unique_id(uint8_t *id_out /* PS_RCCL_ID_BYTES */);
+int ps_rccl_exchange_create(const uint8_t *id, int rank, int world, int device, ps_rccl_exchange **out);
+void ps_rccl_exchange_destroy(ps_rccl_exchange *x);
+/* a ps_exchange_fn: ctx = the ps_rccl_exchange of this rank */
+int ps_exchange_rccl(void *ctx, void *d_words, uint64_t n_words, void *hip_stream);
+/* calls and bytes this rank sent + received in them since the last reset */
+int ps_rccl_exchange_stats(ps_rccl_exchange *x, int reset, uint64_t *calls, uint64_t *bytes);
 ps_population *ps_sim_core(ps_sim *s);
 ps_population *ps_sim_acc(ps_sim *s);
 const double *ps_sim_selection(ps_sim *s);                     /* pan_size values */

@@ -107,6 +107,13 @@ SIGNATURES = {
     "ps_sim_set_exchange": (_int, [_vp, _vp, _vp]),
     "ps_sim_emulate_exchange": (_int, [_vp, _int]),
     "ps_sim_exchange_stats": (_int, [_vp, _int, C.POINTER(_u64), C.POINTER(_u64)]),
+    "ps_sim_emulated_link_time": (_int, [_vp, _int, C.POINTER(_f64), C.POINTER(_f64), C.POINTER(_f64)]),
+    "ps_rccl_available": (_int, []),
+    "ps_rccl_unique_id": (_int, [_u8p]),
+    "ps_rccl_exchange_create": (_int, [_u8p, _int, _int, _int, C.POINTER(_vp)]),
+    "ps_rccl_exchange_destroy": (None, [_vp]),
+    "ps_exchange_rccl": (_int, [_vp, _vp, _u64, _vp]),
+    "ps_rccl_exchange_stats": (_int, [_vp, _int, C.POINTER(_u64), C.POINTER(_u64)]),
     "ps_sim_core": (_vp, [_vp]),
     "ps_sim_acc": (_vp, [_vp]),
     "ps_sim_selection": (C.POINTER(_f64), [_vp]),

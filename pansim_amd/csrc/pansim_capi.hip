@@ -58,7 +58,7 @@ static int ps_fail(int code, const char *fmt, ...)
     } while (0)
 
 extern "C" const char *ps_last_error(void) { return g_err.c_str(); }
-extern "C" int ps_abi_version(void) { return 2; }
+extern "C" int ps_abi_version(void) { return 3; }
 extern "C" int ps_device_count(void)
 {
     int n = 0;
@@ -2407,6 +2407,8 @@ struct ps_sim {
     int emu_shards = 0;
     void *emu_buf = nullptr;
     uint64_t emu_cap = 0;
+    uint32_t emu_clock_khz = 0;                        // wall_clock64() rate; 0 = not yet read
+    double emu_link_gbps = 153.0, emu_latency_us = 20.0, emu_modelled_us = 0.0;
     uint64_t exchange_calls = 0, exchange_bytes = 0;   // bytes this rank SENDS + RECEIVES in the exchange (providers add to it)
     // sweep timing
     bool timing = false;
@@ -2748,8 +2750,18 @@ extern "C" int ps_sim_set_exchange(ps_sim *s, ps_exchange_fn fn, void *ctx)
 }
 
 // bench.py --emulate-shard K: this process plays shard 0 of K.  Its HGT serves donors [0, N / K) and the exchange is
-// stood in for by device-local copies of the same volume a K-rank all-to-all + all-gather of the delta moves per rank
-// (2 x (K - 1) / K of the buffer).  A timing stand-in only: the other shards' events never arrive.
+// stood in for by (i) device-local copies of the volume a K-rank all-to-all + all-gather of the delta moves per rank
+// (2 x (K - 1) / K of the buffer: the pack / unpack traffic in HBM) and (ii) a one-wave kernel that holds the stream for
+// the time the two collectives would take on the links: per collective a launch latency + (K - 1) / K x bytes / the
+// rate of ONE xGMI link (the links are point to point, a ring is bound by a single link: 153 GB/s, 20 us; the
+// environment variables PANSIM_EMU_XGMI_GBPS / PANSIM_EMU_COLL_LATENCY_US override).  A timing stand-in only: the
+// other shards' events never arrive.
+__global__ void emu_hold_kernel(unsigned long long ticks)
+{
+    const unsigned long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(64);
+}
+
 static int emulated_exchange(void *ctx, void *d_words, uint64_t n_words, void *hip_stream)
 {
     ps_sim *s = (ps_sim *)ctx;
@@ -2761,13 +2773,29 @@ static int emulated_exchange(void *ctx, void *d_words, uint64_t n_words, void *h
         HIPCHK(hipMalloc(&s->emu_buf, bytes));
         s->emu_cap = bytes;
     }
+    if (s->emu_clock_khz == 0) {
+        int khz = 0, dev = 0;
+        HIPCHK(hipGetDevice(&dev));
+        if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, dev) != hipSuccess || khz <= 0) khz = 100000;
+        s->emu_clock_khz = (uint32_t)khz;
+        const char *e = getenv("PANSIM_EMU_XGMI_GBPS");
+        if (e && atof(e) > 0.0) s->emu_link_gbps = atof(e);
+        e = getenv("PANSIM_EMU_COLL_LATENCY_US");
+        if (e && atof(e) >= 0.0) s->emu_latency_us = atof(e);
+    }
     const uint64_t part = bytes / (uint64_t)s->emu_shards * (uint64_t)(s->emu_shards - 1);
+    const double coll_us = s->emu_latency_us + (double)part / (s->emu_link_gbps * 1e3);     // one collective
+    const unsigned long long ticks = (unsigned long long)(coll_us * 1e-6 * (double)s->emu_clock_khz * 1e3);
     hipStream_t st = (hipStream_t)hip_stream;
     HIPCHK(hipMemcpyAsync(s->emu_buf, d_words, part, hipMemcpyDeviceToDevice, st));                        // "all-to-all"
+    emu_hold_kernel<<<1, 64, 0, st>>>(ticks);
     HIPCHK(hipMemcpyAsync((uint8_t *)s->emu_buf + (bytes - part), (uint8_t *)d_words + (bytes - part), part,
                           hipMemcpyDeviceToDevice, st));                                                   // "all-gather"
+    emu_hold_kernel<<<1, 64, 0, st>>>(ticks);
+    HIPCHK(hipGetLastError());
     s->exchange_calls++;
     s->exchange_bytes += 2 * part;
+    s->emu_modelled_us += 2.0 * coll_us;
     return PS_OK;
 }
 
@@ -2785,6 +2813,16 @@ extern "C" int ps_sim_exchange_stats(ps_sim *s, int reset, uint64_t *calls, uint
     if (calls) *calls = s->exchange_calls;
     if (bytes) *bytes = s->exchange_bytes;
     if (reset) s->exchange_calls = s->exchange_bytes = 0;
+    return PS_OK;
+}
+
+extern "C" int ps_sim_emulated_link_time(ps_sim *s, int reset, double *modelled_us, double *link_gbps, double *latency_us)
+{
+    if (!s) return ps_fail(PS_ERR_INVALID, "null handle");
+    if (modelled_us) *modelled_us = s->emu_modelled_us;
+    if (link_gbps) *link_gbps = s->emu_link_gbps;
+    if (latency_us) *latency_us = s->emu_latency_us;
+    if (reset) s->emu_modelled_us = 0.0;
     return PS_OK;
 }
 
@@ -3318,3 +3356,6 @@ extern "C" int ps_multi_write(ps_multi *m, const char *outpref)
     PSCHK(rc);
     return ps_write(m->shard[0]->acc, outpref);
 }
+
+// the native RCCL provider of ps_exchange_fn (ps_rccl_*, ps_exchange_rccl)
+#include "exchange_rccl.h"

@@ -23,28 +23,47 @@ class _DevWords:
         self.__cuda_array_interface__ = {"shape": (int(n_words),), "typestr": "<i8", "data": (int(ptr), False), "version": 2}
 
 
-def or_all_reduce(buf, group=None):
-    """in-place bitwise OR of the int64 tensor `buf` over the ranks of `group`: all-to-all of the K slices, local OR,
-    all-gather of the merged slices (NCCL / RCCL has no OR reduction; gloo has, and takes it on CPU tensors).
-    Returns the bytes this rank sent + received."""
-    import torch
+class OrScratch:
+    """the three buffers of the all-to-all form of or_all_reduce, allocated once per (length, world, device): `send`
+    (K slices of `part` words: the padded delta, later the gathered result), `recv` (slice `rank` of every rank's delta)
+    and `mine` (their OR).  The pad words behind the delta are zeroed here and stay zero: the all-gather writes the OR of
+    zeros over them."""
+
+    def __init__(self, n, K, like):
+        import torch
+        self.n, self.K, self.part = int(n), int(K), (int(n) + int(K) - 1) // int(K)
+        self.send = torch.zeros(self.K * self.part, dtype=like.dtype, device=like.device)
+        self.recv = torch.empty_like(self.send)
+        self.mine = torch.empty(self.part, dtype=like.dtype, device=like.device)
+
+    def fits(self, buf, K):
+        return self.n == buf.numel() and self.K == K and self.send.device == buf.device and self.send.dtype == buf.dtype
+
+
+def or_all_reduce(buf, group=None, force_a2a=False, scratch=None):
+    """in-place bitwise OR of the int64 tensor `buf` over the ranks of `group`.  NCCL / RCCL has no OR reduction: an
+    all-to-all of the K slices (slice k of every rank's buffer arrives at rank k), a local OR, and an all-gather of the
+    merged slices.  gloo has ReduceOp.BOR and takes it on CPU tensors unless `force_a2a` -- which runs the very same
+    slice / pad / OR / all-gather logic over gloo, so that the RCCL branch is covered by CPU tests.  `scratch`
+    (an OrScratch) keeps the three work buffers between calls.  Returns the bytes this rank sent + received."""
     import torch.distributed as dist
     K = dist.get_world_size(group)
     if K == 1:
         return 0
     n = buf.numel()
-    if dist.get_backend(group) != "nccl":
+    backend = dist.get_backend(group)
+    if backend != "nccl" and not force_a2a:
         host = buf if buf.device.type == "cpu" else buf.cpu()
         dist.all_reduce(host, op=dist.ReduceOp.BOR, group=group)
         if host is not buf:
             buf.copy_(host)
         return 2 * n * 8 * (K - 1) // K
-    part = (n + K - 1) // K
-    send = torch.zeros(K * part, dtype=buf.dtype, device=buf.device)
-    send[:n] = buf
-    recv = torch.empty_like(send)
+    if scratch is None or not scratch.fits(buf, K):
+        scratch = OrScratch(n, K, buf)
+    part, send, recv, mine = scratch.part, scratch.send, scratch.recv, scratch.mine
+    send[:n].copy_(buf)                                         # (words n .. K * part stay zero)
     dist.all_to_all_single(recv, send, group=group)             # slice k of every rank's delta arrives at rank k
-    mine = recv[:part].clone()
+    mine.copy_(recv[:part])
     for k in range(1, K):
         mine |= recv[k * part:(k + 1) * part]
     dist.all_gather_into_tensor(send, mine, group=group)        # the merged slices, everywhere
@@ -53,11 +72,16 @@ def or_all_reduce(buf, group=None):
 
 
 class TorchExchange:
-    """ps_exchange_fn over torch.distributed: `fn` is the ctypes thunk to hand to Simulation.set_exchange."""
+    """ps_exchange_fn over torch.distributed: `fn` is the ctypes thunk to hand to Simulation.set_exchange.  `device` is
+    the HIP ordinal of the simulation whose delta buffer the calls will carry (None: torch's current device).  A Python
+    exception inside a call is kept in `error` (and the call returns -1, which fails ps_sim_run); `reraise()` surfaces it."""
 
-    def __init__(self, group=None):
+    def __init__(self, group=None, device=None, force_a2a=False):
         from ._lib import EXCHANGE_FN
         self.group = group
+        self.device = device
+        self.force_a2a = force_a2a
+        self.scratch = None
         self.calls = 0
         self.bytes = 0
         self.error = None
@@ -66,20 +90,85 @@ class TorchExchange:
     def _call(self, ctx, d_words, n_words, hip_stream):
         try:
             import torch
-            stream = torch.cuda.ExternalStream(int(hip_stream or 0)) if hip_stream else torch.cuda.current_stream()
-            with torch.cuda.stream(stream):
-                buf = torch.as_tensor(_DevWords(d_words, n_words), device="cuda")
-                import torch.distributed as dist
-                if dist.get_backend(self.group) != "nccl":
-                    stream.synchronize()                # the delta is complete before it leaves the device
-                self.bytes += or_all_reduce(buf, self.group)
-                if dist.get_backend(self.group) != "nccl":
-                    stream.synchronize()
+            import torch.distributed as dist
+            dev = torch.device("cuda", torch.cuda.current_device() if self.device is None or self.device < 0 else int(self.device))
+            with torch.cuda.device(dev):
+                stream = torch.cuda.ExternalStream(int(hip_stream), device=dev) if hip_stream else torch.cuda.current_stream(dev)
+                with torch.cuda.stream(stream):
+                    buf = torch.as_tensor(_DevWords(d_words, n_words), device=dev)
+                    K = dist.get_world_size(self.group)
+                    on_device = dist.get_backend(self.group) == "nccl"
+                    if not on_device:
+                        stream.synchronize()                # the delta is complete before it leaves the device
+                        host = buf.cpu()
+                        if self.force_a2a and (self.scratch is None or not self.scratch.fits(host, K)):
+                            self.scratch = OrScratch(n_words, K, host)
+                        self.bytes += or_all_reduce(host, self.group, self.force_a2a, self.scratch)
+                        buf.copy_(host)
+                        stream.synchronize()
+                    else:
+                        if self.scratch is None or not self.scratch.fits(buf, K):
+                            self.scratch = OrScratch(n_words, K, buf)   # (allocated once: 3 x 33 MB at N = 65536)
+                        self.bytes += or_all_reduce(buf, self.group, False, self.scratch)
             self.calls += 1
             return 0
         except Exception as e:          # never let an exception cross the C boundary
             self.error = e
             return -1
+
+    def reraise(self, cause=None):
+        """raise the Python exception a failed call kept (chained to the library's error), if any"""
+        if self.error is not None:
+            err, self.error = self.error, None
+            raise err from cause
+
+
+class RcclExchange:
+    """The library's own ps_exchange_fn over RCCL (ps_rccl_*: no Python and no torch inside the per-generation call).
+    torch.distributed is used ONCE, to carry rank 0's 128-byte communicator id to the other ranks; a host without torch
+    carries it any other way.  `fn` / `ctx` are what Simulation.set_exchange takes."""
+
+    def __init__(self, rank, world, device, group=None):
+        import torch
+        import torch.distributed as dist
+        from . import _lib
+        self._lib = _lib.load()
+        ident = np.zeros(128, np.uint8)
+        if rank == 0:
+            _lib.check(self._lib.ps_rccl_unique_id(ident))
+        if world > 1:
+            t = torch.from_numpy(ident)
+            if dist.get_backend(group) == "nccl":
+                t = t.cuda()
+            dist.broadcast(t, src=0, group=group)
+            ident = t.cpu().numpy().copy()
+        self._h = C.c_void_p()
+        _lib.check(self._lib.ps_rccl_exchange_create(ident, int(rank), int(world), int(device), C.byref(self._h)))
+        self.fn = C.cast(self._lib.ps_exchange_rccl, C.c_void_p)
+        self.ctx = self._h
+        self.error = None
+
+    def stats(self, reset=False):
+        from . import _lib
+        n, b = C.c_uint64(), C.c_uint64()
+        _lib.check(self._lib.ps_rccl_exchange_stats(self._h, int(reset), C.byref(n), C.byref(b)))
+        return n.value, b.value
+
+    calls = property(lambda self: self.stats()[0])
+    bytes = property(lambda self: self.stats()[1])
+
+    def __call__(self, d_words, n_words, hip_stream=0):
+        """one exchange on a raw device buffer (tests)"""
+        from . import _lib
+        _lib.check(self._lib.ps_exchange_rccl(self._h, C.c_void_p(int(d_words)), int(n_words), C.c_void_p(int(hip_stream))))
+
+    def reraise(self, cause=None):
+        pass            # (native: failures arrive as the library's own error text)
+
+    def close(self):
+        if self._h:
+            self._lib.ps_rccl_exchange_destroy(self._h)
+            self._h = C.c_void_p()
 
 
 def shard_bounds(core_size, rank, world):
@@ -98,7 +187,7 @@ class ShardedSimulation:
     the HIP-backed pansim_amd.Simulation (tests inject a CPU double to exercise the exchange
     logic over gloo)."""
 
-    def __init__(self, rank, world, engine=None, group=None, shard_hgt_donors=None, **params):
+    def __init__(self, rank, world, engine=None, group=None, shard_hgt_donors=None, exchange="torch", **params):
         if engine is None:
             from .simulation import Simulation, make_params
 
@@ -115,13 +204,24 @@ class ShardedSimulation:
         if shard_hgt_donors is None:
             shard_hgt_donors = params.get("pop_size", 0) >= 4096
         if shard_hgt_donors and world > 1 and hasattr(self.sim, "set_exchange") and world <= params.get("pop_size", world):
-            self.exchange = TorchExchange(group)
-            self.sim.set_exchange(self.exchange.fn)
+            # "torch": torch.distributed collectives (RCCL under nccl, BOR under gloo); "torch_a2a": the RCCL branch's
+            # all-to-all / OR / all-gather logic whatever the backend; "rccl": the library's own provider (ps_rccl_*)
+            if exchange == "rccl":
+                self.exchange = RcclExchange(rank, world, params.get("device", -1), group)
+                self.sim.set_exchange(self.exchange.fn, self.exchange.ctx)
+            else:
+                self.exchange = TorchExchange(group, device=params.get("device", None), force_a2a=(exchange == "torch_a2a"))
+                self.sim.set_exchange(self.exchange.fn)
 
     def run(self, count):
-        self.sim.run(count)
-        if self.exchange is not None and self.exchange.error is not None:
-            raise self.exchange.error
+        try:
+            self.sim.run(count)
+        except Exception as e:          # the library only knows "the exchange failed (-1)": show why
+            if self.exchange is not None:
+                self.exchange.reraise(e)
+            raise
+        if self.exchange is not None:
+            self.exchange.reraise()
 
     def sync(self):
         self.sim.sync()
@@ -170,3 +270,5 @@ class ShardedSimulation:
 
     def close(self):
         self.sim.close()
+        if isinstance(self.exchange, RcclExchange):
+            self.exchange.close()

@@ -114,15 +114,22 @@ class Simulation:
         check(self._lib.ps_sim_last_parents(self._h, out))
         return out
 
-    def set_exchange(self, fn):
-        """shard the HGT donors over the site shards of this run; `fn` (an _lib.EXCHANGE_FN object) ORs the shards'
-        delta buffers once per generation (ps_sim_set_exchange).  Every shard of the run must install one."""
+    def set_exchange(self, fn, ctx=None):
+        """shard the HGT donors over the site shards of this run; `fn` (an _lib.EXCHANGE_FN object, or the address of a
+        native ps_exchange_fn such as ps_exchange_rccl with its handle as `ctx`) ORs the shards' delta buffers once per
+        generation (ps_sim_set_exchange).  Every shard of the run must install one."""
         self._exchange_fn = fn          # keep the ctypes thunk alive
-        check(self._lib.ps_sim_set_exchange(self._h, C.cast(fn, C.c_void_p), None))
+        check(self._lib.ps_sim_set_exchange(self._h, C.cast(fn, C.c_void_p), ctx))
 
     def emulate_exchange(self, n_shards):
         """bench.py --emulate-shard: shard 0 of n_shards, exchange stood in for by device-local copies (timing only)"""
         check(self._lib.ps_sim_emulate_exchange(self._h, int(n_shards)))
+
+    def emulated_link_time(self, reset=True):
+        """(modelled microseconds of link time charged by the emulated exchange since the last reset, GB/s per link, latency us)"""
+        a, b, c = C.c_double(), C.c_double(), C.c_double()
+        check(self._lib.ps_sim_emulated_link_time(self._h, int(reset), C.byref(a), C.byref(b), C.byref(c)))
+        return a.value, b.value, c.value
 
     def exchange_stats(self, reset=True):
         """(exchange calls, bytes sent + received by this shard in them) since the last reset -- library providers only"""

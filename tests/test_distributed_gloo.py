@@ -111,31 +111,42 @@ def test_shard_bounds_partition():
     assert core_distances_from_counts([2, 3, 10], 9).tolist() == [1 / 9, 1 / 9, 5 / 9]
 
 
-def _or_worker(rank, world, port, out):
+OR_SIZES = (1, 7, 4096, 10001)
+
+
+def _or_worker(rank, world, port, out, force_a2a):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    from pansim_amd.distributed import or_all_reduce
+    from pansim_amd.distributed import OrScratch, or_all_reduce
     rng = np.random.default_rng(100 + rank)
-    for n in (1, 7, 4096, 10001):
+    scratch = None
+    for rep, n in enumerate(OR_SIZES + OR_SIZES[-1:]):          # (the last size twice: the scratch buffers are reused)
         mine = torch.from_numpy(rng.integers(-2**62, 2**62, n, dtype=np.int64) & rng.integers(-2**62, 2**62, n, dtype=np.int64))
         buf = mine.clone()
-        sent = or_all_reduce(buf)
-        np.save(os.path.join(out, "or_%d_%d.npy" % (n, rank)), buf.numpy())
-        np.save(os.path.join(out, "in_%d_%d.npy" % (n, rank)), mine.numpy())
-        assert sent > 0
+        if force_a2a and (scratch is None or not scratch.fits(buf, world)):
+            scratch = OrScratch(n, world, buf)
+        sent = or_all_reduce(buf, force_a2a=force_a2a, scratch=scratch)
+        np.save(os.path.join(out, "or_%d_%d.npy" % (rep, rank)), buf.numpy())
+        np.save(os.path.join(out, "in_%d_%d.npy" % (rep, rank)), mine.numpy())
+        part = (n + world - 1) // world
+        assert sent == (2 * part * 8 * (world - 1) if force_a2a else 2 * n * 8 * (world - 1) // world)
+        if force_a2a:                                           # the pad words behind the delta must still be zero
+            assert not scratch.send[n:].any() or world * part == n
     dist.destroy_process_group()
 
 
-def test_or_all_reduce_of_hgt_deltas(tmp_path):
-    # the per-generation exchange step of the donor-sharded HGT: every rank ends with the OR of all ranks' buffers
-    world = 3
-    port = 27000 + os.getpid() % 2000
-    mp.spawn(_or_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
-    for n in (1, 7, 4096, 10001):
+@pytest.mark.parametrize("world,force_a2a", [(3, False), (2, True), (3, True), (8, True)])
+def test_or_all_reduce_of_hgt_deltas(tmp_path, world, force_a2a):
+    # the per-generation exchange step of the donor-sharded HGT: every rank ends with the OR of all ranks' buffers.
+    # force_a2a runs the RCCL branch's logic (pad to K slices, all-to-all, local OR, all-gather) over gloo; the sizes
+    # include lengths that K does not divide and lengths below K (empty slices)
+    port = 27000 + (os.getpid() * 7 + world * 2 + int(force_a2a)) % 2000
+    mp.spawn(_or_worker, args=(world, port, str(tmp_path), force_a2a), nprocs=world, join=True)
+    for rep, n in enumerate(OR_SIZES + OR_SIZES[-1:]):
         want = np.zeros(n, np.int64)
         for r in range(world):
-            want |= np.load(tmp_path / ("in_%d_%d.npy" % (n, r)))
+            want |= np.load(tmp_path / ("in_%d_%d.npy" % (rep, r)))
         for r in range(world):
-            assert np.array_equal(np.load(tmp_path / ("or_%d_%d.npy" % (n, r))), want)
+            assert np.array_equal(np.load(tmp_path / ("or_%d_%d.npy" % (rep, r))), want)

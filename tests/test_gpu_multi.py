@@ -66,7 +66,7 @@ def test_cli_gpus_2_equals_gpus_1(pa, tmp_path):
             assert filecmp.cmp(str(outs[0][0]) + suffix, str(pref) + suffix, shallow=False), suffix
 
 
-def _hip_worker(rank, world, port, out):
+def _hip_worker(rank, world, port, out, exchange="torch"):
     # one rank of a two-process site-sharded run with the REAL HIP engine (both ranks share the box's one GPU);
     # the exchange is pansim_amd.distributed over gloo (the driver's multi-GPU runs use nccl = RCCL)
     import sys
@@ -76,7 +76,8 @@ def _hip_worker(rank, world, port, out):
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from pansim_amd.distributed import ShardedSimulation
-    s = ShardedSimulation(rank, world, seed=21, n_gen=3, max_distances=900, device=0, shard_hgt_donors=True, **_MP_KW)
+    s = ShardedSimulation(rank, world, seed=21, n_gen=3, max_distances=900, device=0, shard_hgt_donors=True, exchange=exchange,
+                          **_MP_KW)
     s.run(3)
     assert s.exchange is not None and s.exchange.calls == 3 and s.exchange.error is None
     agree = s.parents_agree()
@@ -93,14 +94,16 @@ def _hip_worker(rank, world, port, out):
 _MP_KW = dict(pop_size=260, core_size=3001, pan_genes=400, core_genes=100, HR_rate=0.3, HGT_rate=0.3)
 
 
-def test_two_processes_with_the_hip_engine(pa, orc, tmp_path):
+@pytest.mark.parametrize("exchange", ["torch", "torch_a2a"])
+def test_two_processes_with_the_hip_engine(pa, orc, tmp_path, exchange):
     # SURVEY 8(e) with one PROCESS per shard: every rank runs libpansim_hip with shard_count = 2, draws the same
-    # parents, and the all-reduced integer numerators give the unsharded distances
+    # parents, and the all-reduced integer numerators give the unsharded distances.  "torch_a2a": the HGT deltas take
+    # the RCCL branch's all-to-all / OR / all-gather logic (over gloo: RCCL cannot put two ranks on one GPU)
     import torch.multiprocessing as mp
     from orc_sim import OracleSim
     world = 2
-    port = 31000 + os.getpid() % 2000
-    mp.spawn(_hip_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    port = 31000 + (os.getpid() + 7 * len(exchange)) % 2000
+    mp.spawn(_hip_worker, args=(world, port, str(tmp_path), exchange), nprocs=world, join=True)
     full = OracleSim(seed=21, **_MP_KW)
     for g in range(3):
         full.generation(g)
@@ -203,3 +206,41 @@ def test_multi_donor_sharded_hgt_forms(pa, orc, env):
             os.environ.pop(k, None)
             if v is not None:
                 os.environ[k] = v
+
+
+def test_native_rccl_exchange_provider(pa, orc):
+    # ps_rccl_* / ps_exchange_rccl, the library's own ps_exchange_fn (dlopen of librccl.so, ncclSend / ncclRecv group, OR
+    # kernel, ncclAllGather).  One GPU allows a communicator of ONE rank only (RCCL refuses two ranks on a device), which
+    # still runs every call of the provider: the OR over one rank leaves the buffer as it was.
+    import torch
+    from pansim_amd.distributed import RcclExchange
+    assert pa.load().ps_rccl_available() == 1
+    x = RcclExchange(0, 1, 0)
+    rng = np.random.default_rng(3)
+    st = torch.cuda.Stream()
+    for n in (1, 1000, 4099, 4099):
+        host = rng.integers(-2**62, 2**62, n, dtype=np.int64)
+        with torch.cuda.stream(st):
+            buf = torch.from_numpy(host).cuda()
+            x(buf.data_ptr(), n, st.cuda_stream)
+        st.synchronize()
+        assert np.array_equal(buf.cpu().numpy(), host)
+    assert x.stats() == (4, 0)
+    # inside the generation loop: shard 0 of 2 whose exchange is the one-rank communicator applies its own donors' events
+    # only -- exactly what the hook-less form (fn == NULL) does
+    kw = dict(pop_size=200, core_size=600, pan_genes=500, core_genes=100, HR_rate=0.2, HGT_rate=0.6)
+    mats = []
+    for native in (False, True):
+        sim = pa.Simulation(pa.make_params(seed=9, n_gen=3, max_distances=50, shard_rank=0, shard_count=2, device=0, **kw))
+        if native:
+            sim.set_exchange(x.fn, x.ctx)
+        else:
+            sim.set_exchange(None)
+        sim.run(3)
+        sim.sync()
+        mats.append((sim.pan_genome.read_matrix(), sim.core_genome.read_matrix(), sim.last_parents()))
+        sim.close()
+    assert x.stats()[0] == 4 + 3
+    for a, b in zip(*mats):
+        assert np.array_equal(a, b)
+    x.close()

@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol(pa):
     assert not missing, "declared in include/pansim_hip.h but not exported: %s" % missing
     from pansim_amd import _lib
     assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
-    assert lib.ps_abi_version() == 2      # round 3: ps_sim_params gained reference_seed_stream
+    assert lib.ps_abi_version() == 3      # round 4: ps_rccl_*, ps_sim_emulated_link_time, ps_last_sweep_form
 
 
 def test_no_cpu_fallback_without_device(pa):
@@ -38,6 +38,16 @@ def test_no_cpu_fallback_without_device(pa):
         pa.hamming_bitwise_fast([1, 2], [2, 2])
     with pytest.raises(pa.PansimError):
         pa.Simulation(pa.make_params(pop_size=10, core_size=100, pan_genes=60, core_genes=20))
+    # the native RCCL exchange provider: librccl.so loads (dlopen) or not, but nothing runs without a device
+    lib = pa.load()
+    assert lib.ps_rccl_available() in (0, 1)
+    ident = np.zeros(128, np.uint8)
+    assert lib.ps_rccl_unique_id(ident) in (0, -2)      # (drawing an id needs no device in some RCCL builds)
+    import ctypes
+    h = ctypes.c_void_p()
+    assert lib.ps_rccl_exchange_create(ident, 0, 1, 0, ctypes.byref(h)) == -2 and not h.value
+    assert lib.ps_rccl_exchange_create(ident, 3, 2, 0, ctypes.byref(h)) == -1      # rank outside the world
+    assert lib.ps_exchange_rccl(None, None, 0, None) == -1
 
 
 def test_product_does_not_import_oracle():
