@@ -159,6 +159,18 @@ enum {
     PS_PAIR_FORM_ALLPAIRS_MFMA_FP4 = 7 /* the same on the block-scaled FP4 path (E2M1 {0, 1}, scales 2^0; exact f32 counts) */
 };
 int ps_last_pair_form(ps_population *p);
+/* Which kernel the last core sweep of this handle (ps_step, ps_next_generation, ps_mutate_alleles, ps_recombine, a
+ * generation of ps_sim_run) was launched as -- the library chooses by population width, rates, parent order and the room
+ * for a second buffer; bench.py labels and prices its roofline line from this: */
+enum {
+    PS_SWEEP_FORM_NONE = 0,
+    PS_SWEEP_FORM_WAVE = 1,        /* core_sweep_wave_kernel, one wave per site row (N <= 1024) */
+    PS_SWEEP_FORM_WAVE_STASH = 2,  /* the same with the level-1 nibble carried in the child byte (every candidate byte < 16) */
+    PS_SWEEP_FORM_WINDOW = 3,      /* core_sweep_window_kernel: N > 1024, children in ascending parent order, out of place */
+    PS_SWEEP_FORM_BLOCK = 4,       /* core_sweep_block_kernel: N > 1024, whole rows in workgroup-shared LDS, in place */
+    PS_SWEEP_FORM_INLINE = 5       /* core_sweep_inline_kernel: the queue-free form for any rates */
+};
+int ps_last_sweep_form(ps_population *p);
 /* Population::gene_frequencies (population.rs:840-863): ncols + core_genes values */
 int ps_gene_frequencies(ps_population *p, double *out);
 /* Population::calc_gene_freq (population.rs:244-268) */
@@ -345,7 +357,10 @@ typedef struct ps_multi ps_multi;
 int ps_multi_create(const ps_sim_params *p, int n_shards, const int *devices, ps_multi **out);
 void ps_multi_destroy(ps_multi *m);
 int ps_multi_shards(ps_multi *m);
-ps_sim *ps_multi_shard(ps_multi *m, int k);      /* borrowed: selection coefficients, pair list, accessory matrix */
+/* borrowed, for reading: selection coefficients, pair list, matrices, timings.  A shard's generations and its HGT take
+ * part in exchanges between ALL shards (parent weights, HGT deltas): ps_sim_run / ps_recombine on a borrowed shard fail
+ * with PS_ERR_STATE -- drive the shards through ps_multi_run. */
+ps_sim *ps_multi_shard(ps_multi *m, int k);
 /* main.rs:429-464 for generations [first, first+count) on every shard */
 int ps_multi_run(ps_multi *m, uint32_t first_generation, uint32_t count);
 int ps_multi_sync(ps_multi *m);

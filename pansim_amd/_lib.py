@@ -82,6 +82,7 @@ SIGNATURES = {
     "ps_pairwise_distances": (_int, [_vp, _u64, _u32p, _u32p, _f64p]),
     "ps_pairwise_counts": (_int, [_vp, _u64, _u32p, _u32p, _vp, _vp, _int]),
     "ps_last_pair_form": (_int, [_vp]),
+    "ps_last_sweep_form": (_int, [_vp]),
     "ps_gene_frequencies": (_int, [_vp, _f64p]),
     "ps_calc_gene_freq": (_int, [_vp, C.POINTER(_f64)]),
     "ps_write": (_int, [_vp, C.c_char_p]),

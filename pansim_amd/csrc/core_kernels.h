@@ -138,7 +138,7 @@ __global__ void __launch_bounds__(1024) core_sweep_inline_kernel(core_sweep_args
             }
             uint32_t hm = 0;
             if (events) {
-                const ps_u4 l1 = ps_philox(site, c, a.gen, PS_STREAM_CORE_L1, a.k0, a.k1);
+                const ps_u4 l1 = ps_philox_l1(site, c, a.gen, a.k0, a.k1);
                 uint32_t cm = ps_candidate_mask(l1, pl.bC);
                 while (cm) {
                     const uint32_t k = __builtin_ctz(cm);
@@ -382,7 +382,7 @@ __global__ void __launch_bounds__(256, PS_ROWS >= 4 ? 6 : 8) core_sweep_wave_ker
             cm[rr] = 0;
             l1[rr] = ps_u4{ 0, 0, 0, 0 };
             if (events) {
-                l1[rr] = ps_philox(a.site_offset + min(r0 + rr, a.rows - 1u), lane, a.gen, PS_STREAM_CORE_L1, a.k0, a.k1);
+                l1[rr] = ps_philox_l1(a.site_offset + min(r0 + rr, a.rows - 1u), lane, a.gen, a.k0, a.k1);
                 cm[rr] = ps_candidates_swar(l1[rr], c4) & vperm;
                 if (STASH) {
                     d.x = ps_stash(d.x, l1[rr].x); d.y = ps_stash(d.y, l1[rr].y);
@@ -439,7 +439,7 @@ __global__ void __launch_bounds__(256, PS_ROWS >= 4 ? 6 : 8) core_sweep_wave_ker
             for (uint32_t rr = 0; rr < PS_ROWS; rr++) {
                 uint8_t *row = rowbuf + rr * 1024u;
                 const uint32_t site = a.site_offset + min(r0 + rr, a.rows - 1u);
-                const ps_u4 l1r = ps_philox(site, lane, a.gen, PS_STREAM_CORE_L1, a.k0, a.k1);
+                const ps_u4 l1r = ps_philox_l1(site, lane, a.gen, a.k0, a.k1);
                 uint32_t cmr = ps_candidates_swar(l1r, c4) & vperm;
                 uint32_t hm = 0;
                 while (cmr) {
@@ -615,7 +615,7 @@ __device__ __forceinline__ uint32_t ps_donor_value(const core_sweep_args &a, con
 {
     uint32_t val = old_row[a.idx[donor]];                       // population.rs:450-465: the donor's gathered byte
     if (do_mut) {
-        const ps_u4 l1 = ps_philox(site, donor >> 4, a.gen, PS_STREAM_CORE_L1, a.k0, a.k1);
+        const ps_u4 l1 = ps_philox_l1(site, donor >> 4, a.gen, a.k0, a.k1);
         const uint32_t byte = ps_l1_byte(l1, donor & 15u);
         if (byte <= pl.bC) {
             const ps_u4 l2 = ps_philox(site, donor, a.gen, PS_STREAM_CORE_L2, a.k0, a.k1);
@@ -733,7 +733,7 @@ __global__ void __launch_bounds__(256, PS_WLB) core_sweep_window_kernel(core_swe
                 }
             }
             uint4 d = make_uint4(w[0], w[1], w[2], w[3]);
-            l1[rr] = ps_philox(site, chunk, a.gen, PS_STREAM_CORE_L1, a.k0, a.k1);
+            l1[rr] = ps_philox_l1(site, chunk, a.gen, a.k0, a.k1);
             cm[rr] = ps_candidates_swar(l1[rr], c4) & vperm;
             if (STASH) {
                 d.x = ps_stash(d.x, l1[rr].x); d.y = ps_stash(d.y, l1[rr].y);
@@ -780,7 +780,7 @@ __global__ void __launch_bounds__(256, PS_WLB) core_sweep_window_kernel(core_swe
                 uint8_t *row = rowbuf + rr * PS_WSTRIDE;
                 const uint32_t rg = min(r0 + rr, a.rows - 1u), site = a.site_offset + rg;
                 const uint8_t *old_row = a.state + (size_t)rg * a.pitch;
-                const ps_u4 l1r = ps_philox(site, chunk, a.gen, PS_STREAM_CORE_L1, a.k0, a.k1);
+                const ps_u4 l1r = ps_philox_l1(site, chunk, a.gen, a.k0, a.k1);
                 uint32_t cmr = ps_candidates_swar(l1r, c4) & vperm;
                 while (cmr) {
                     const uint32_t p = __builtin_ctz(cmr);
@@ -1047,7 +1047,7 @@ __global__ void __launch_bounds__(1024) core_sweep_block_kernel(core_sweep_args 
                     }
                     if (events) {
                         const uint32_t vperm = FULL ? 0xF0F0F0F0u : PRE ? vperm_pre[s] : ps_valid_cells(i0, a.N);
-                        const ps_u4 l1 = ps_philox(s_site[s], chunk, a.gen, PS_STREAM_CORE_L1, a.k0, a.k1);
+                        const ps_u4 l1 = ps_philox_l1(s_site[s], chunk, a.gen, a.k0, a.k1);
                         uint32_t cm = ps_candidates_swar(l1, c4) & vperm;
                         if (STASH) {
                             // child bytes with the level-1 nibbles (see the wave sweep); the push happens below
@@ -1233,7 +1233,7 @@ __global__ void __launch_bounds__(1024) core_sweep_block_kernel(core_sweep_args 
                     const uint4 cur = ps_strip(*(const uint4 *)(row + i0), STASH);
                     d[0] = cur.x; d[1] = cur.y; d[2] = cur.z; d[3] = cur.w;
                 }
-                const ps_u4 l1 = ps_philox(site, chunk, a.gen, PS_STREAM_CORE_L1, a.k0, a.k1);
+                const ps_u4 l1 = ps_philox_l1(site, chunk, a.gen, a.k0, a.k1);
                 uint32_t cm = ps_candidate_mask(l1, pl.bC), hm = 0;
                 while (cm) {
                     const uint32_t k = __builtin_ctz(cm);

@@ -249,6 +249,7 @@ struct ps_population {
     bool no_block_preload = false;      // tests: block sweep reads its parent indices per batch
     uint32_t block_batch = 0;           // block sweep: segments per wave batch (0 = 4, falling back to 2; 2 = force 2)
     uint32_t sweep_queue_cap = 0;       // tests: the sweeps treat their candidate queues / HR lists as this short (0 = real size)
+    int last_sweep_form = 0;            // PS_SWEEP_FORM_* of the last core sweep launch (ps_last_sweep_form)
     int window_sweep = -1;              // window sweep for N > 1024 when the parents are sorted: -1 = choose, 0 = never, 1 = whenever possible
     uint32_t *h_flag = nullptr, *d_flag = nullptr;   // host-mapped sticky device error word
     unsigned long long *h_stamps = nullptr, *d_stamps = nullptr;   // diagnostic phase stamps
@@ -859,6 +860,9 @@ static int launch_core_sweep(ps_population *p, const uint32_t *d_idx, uint32_t g
     a.work_ctr = p->d_work;
     a.launch_parity = (uint32_t)(p->sweep_launches++ & 1u);
     a.idxT = p->d_idxT;
+    p->last_sweep_form = window ? PS_SWEEP_FORM_WINDOW
+                         : wave ? ((a.plan.has_events && a.plan.bC <= 15u && p->nibble_safe) ? PS_SWEEP_FORM_WAVE_STASH : PS_SWEEP_FORM_WAVE)
+                         : inline_form ? PS_SWEEP_FORM_INLINE : PS_SWEEP_FORM_BLOCK;
     if (window) return hr ? launch_core_sweep_window<true>(p, a, st) : launch_core_sweep_window<false>(p, a, st);
 #define PS_DISPATCH(G_, M_, H_)                                              \
     if (ga == G_ && mu == M_ && hr == H_)                                    \
@@ -937,6 +941,25 @@ static uint32_t hgt_partitions(const ps_population *p)
     return (uint32_t)((p->d.N + part_cap - 1) / part_cap);
 }
 
+// which form launch_acc_hgt will take for this handle's rates (its callers decide from it whether the step before the HGT
+// should leave the light form's snapshot: the binned form never reads one)
+static bool hgt_takes_binned_form(const ps_population *p)
+{
+    double expected = 0.0;
+    uint32_t max_comp = 1;
+    for (int c = 0; c < p->aplan.n_comp; c++) {
+        if (p->aplan.lam_rec[c] == 0.0 || p->ptab_len[c] == 0) continue;
+        expected += (double)p->d.N * p->aplan.lam_rec[c];
+        max_comp = std::max(max_comp, p->aplan.comp_end[c] - p->aplan.comp_begin[c]);
+    }
+    const uint32_t list_lds = ((max_comp * 2u + 15u) & ~15u);
+    const uint32_t parts = hgt_partitions(p);
+    const uint32_t rpp = parts ? (p->d.N + parts - 1) / parts : 0;
+    return parts >= 1 && parts <= 1024 && rpp >= 2 && p->d.G <= 65536u && (uint64_t)p->d.N * rpp < (1ull << 32)
+           && (p->hgt_mode == 2 || (p->hgt_mode == 0 && expected >= 1.0e7))
+           && list_lds + parts * 4u + 64u <= p->lds_limit;
+}
+
 static int launch_acc_hgt(ps_population *p, uint32_t gen, hipStream_t st, hipEvent_t wait_before_apply = nullptr)
 {
     if (p->d.G == 0 || p->d.N < 2) return PS_OK;
@@ -982,10 +1005,7 @@ static int launch_acc_hgt(ps_population *p, uint32_t gen, hipStream_t st, hipEve
     // one 64-bit atomicOr per event; that form needs no static LDS and co-runs with the sweep.
     const uint64_t row_bytes = (uint64_t)p->d.GW * 8;
     const uint32_t parts = hgt_partitions(p);
-    const uint32_t rpp = parts ? (p->d.N + parts - 1) / parts : 0;
-    const bool binned = parts >= 1 && parts <= 1024 && rpp >= 2 && p->d.G <= 65536u && (uint64_t)p->d.N * rpp < (1ull << 32)
-                        && (p->hgt_mode == 2 || (p->hgt_mode == 0 && expected >= 1.0e7))
-                        && list_lds + parts * 4u + 64u <= p->lds_limit;
+    const bool binned = hgt_takes_binned_form(p);
     // event counts per donor; the light form's snapshot copy rides along (donors read the
     // pre-recombination matrix, population.rs:693-695, while recipients are edited in place)
     // (both forms draw the count of an item where they serve the item; the light form's snapshot and zeroed work counter
@@ -1848,6 +1868,12 @@ extern "C" int ps_pairwise_counts(ps_population *p, uint64_t P, const uint32_t *
     return PS_OK;
 }
 
+extern "C" int ps_last_sweep_form(ps_population *p)
+{
+    if (!p) return ps_fail(PS_ERR_INVALID, "null handle");
+    return p->last_sweep_form;
+}
+
 extern "C" int ps_last_pair_form(ps_population *p) { return p ? p->last_pair_form : 0; }
 
 extern "C" int ps_pairwise_distances(ps_population *p, uint64_t P, const uint32_t *range1,
@@ -2647,6 +2673,9 @@ static int sim_one_generation(ps_sim *s, uint32_t gen)
     else PSCHK(sim_host_weights(s, gen, w.data()));
     th0 = clk::now();
     s->last_slot = slot;
+    // the step leaves the pre-recombination snapshot only for the light HGT form, the one that reads it (the binned form of
+    // cfg3 / cfg4 / cfg5 does not: a third N x GW x 8-byte buffer written per generation with no reader)
+    const bool want_snap = p.HGT_rate > 0.0 && !hgt_takes_binned_form(acc);
     if (s->device_draw) {
         // cumulative table on the host (sequential f64 sums, as WeightedIndex::new builds it), copied to the
         // device (8*N bytes; the 16 dependent reads of every search would otherwise cross PCIe: 155 us at
@@ -2669,7 +2698,7 @@ static int sim_one_generation(ps_sim *s, uint32_t gen)
         HIPCHK(hipGetLastError());
         s->host_draw_ms += ms_since(th0);
         s->host_calls++;
-        PSCHK(launch_acc_step(acc, s->d_idx[slot], gen, true, true, sa, nullptr, p.HGT_rate > 0.0));
+        PSCHK(launch_acc_step(acc, s->d_idx[slot], gen, true, true, sa, nullptr, want_snap));
     } else {
     PSCHK(ps_draw_parents(w.data(), N, p.seed, gen, s->h_idx[slot]));
     {
@@ -2687,7 +2716,7 @@ static int sim_one_generation(ps_sim *s, uint32_t gen)
     // straight from the host-mapped slot (4*N bytes over PCIe) and publishes the device copy the
     // core sweep uses: no copy kernel has to fight the sweep for a CU.
     if (G == 0) HIPCHK(hipMemcpyAsync(s->d_idx[slot], s->h_idx[slot], N * sizeof(uint32_t), hipMemcpyHostToDevice, sa));
-    PSCHK(launch_acc_step(acc, s->m_idx[slot], gen, true, true, sa, s->d_idx[slot], p.HGT_rate > 0.0));
+    PSCHK(launch_acc_step(acc, s->m_idx[slot], gen, true, true, sa, s->d_idx[slot], want_snap));
     }
     HIPCHK(hipEventRecord(s->ev_idx[slot], sa));
     // Heavy HGT (cfg3-like rates, >= 1e7 expected events): its scattered loads and the streaming
@@ -3003,6 +3032,7 @@ struct ps_multi {
     size_t bar_count = 0;
     uint64_t bar_gen = 0;
     bool failed = false;
+    bool in_call = false;               // a ps_multi_* call is driving every shard (multi_for_each): the barriers are complete
     bool donor_sharded = false;
     bool peers_ok = true;               // every shard's device can read every other's memory
     std::vector<uint64_t *> delta;
@@ -3019,6 +3049,11 @@ struct ps_multi {
 static int multi_barrier(ps_multi *m)
 {
     std::unique_lock<std::mutex> lk(m->mu);
+    // a shard handle borrowed with ps_multi_shard and driven on its own (ps_sim_run, ps_recombine) would wait here for
+    // peers that never come: fail instead
+    if (!m->in_call)
+        return ps_fail(PS_ERR_STATE, "this shard belongs to a ps_multi: its generations and its HGT take part in exchanges between "
+                                     "all shards and can only be driven through ps_multi_run");
     if (m->failed) return ps_fail(PS_ERR_STATE, "another shard failed");
     const uint64_t gen = m->bar_gen;
     if (++m->bar_count == m->shard.size()) {
@@ -3086,7 +3121,9 @@ static int multi_for_each(ps_multi *m, F fn)
         std::lock_guard<std::mutex> lk(m->mu);
         m->failed = false;
         m->bar_count = 0;
+        m->in_call = true;
     }
+    struct leave { ps_multi *m; ~leave() { std::lock_guard<std::mutex> lk(m->mu); m->in_call = false; } } leave_guard{ m };
     auto body = [&](size_t k) {
         rc[k] = fn(k);
         if (rc[k] != PS_OK) {

@@ -48,7 +48,7 @@ static const Flag FLAGS[] = {
 // visible GPUs (include/pansim_hip.h, ps_multi); results do not depend on it
 static const Flag EXT_FLAGS[] = {
     { "gpus", "Number of core-site shards, one per GPU (more shards than GPUs share them). Results do not depend on it.", "1", true },
-    { "reference_seed_stream", "Draw the selection coefficients from the reference's own seeded stream (ChaCha12 StdRng, restated from the rand / statrs crates: unpinned) instead of the build's Philox stream.", nullptr, false },
+    { "reference_seed_stream", "Draw the selection coefficients from the reference's own seeded stream (ChaCha12 StdRng, restated from the published algorithms of the rand / statrs crates, ziggurat tables recomputed: UNVERIFIED against a Pansim binary) instead of the build's Philox stream.", nullptr, false },
 };
 
 static void print_help()

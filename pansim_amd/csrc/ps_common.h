@@ -35,10 +35,11 @@ PS_HD uint32_t ps_xor3(uint32_t a, uint32_t b, uint32_t c)
 #endif
 }
 
-PS_HD ps_u4 ps_philox(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1)
+template <int ROUNDS>
+PS_HD ps_u4 ps_philox_r(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1)
 {
 #pragma unroll
-    for (int r = 0; r < 10; r++) {
+    for (int r = 0; r < ROUNDS; r++) {
         uint64_t p0 = (uint64_t)0xD2511F53u * c0;
         uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
         uint32_t n0 = ps_xor3((uint32_t)(p1 >> 32), c1, k0);
@@ -52,6 +53,22 @@ PS_HD ps_u4 ps_philox(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32
     }
     ps_u4 o = { c0, c1, c2, c3 };
     return o;
+}
+
+// Philox4x32-10: every stream of the build except the core level-1 bytes
+PS_HD ps_u4 ps_philox(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1)
+{
+    return ps_philox_r<10>(c0, c1, c2, c3, k0, k1);
+}
+
+// the level-1 bytes of the core cell plan: one block per 16 cells of EVERY row, the one Philox call of
+// the sweeps that is not amortised over candidates
+#ifndef PS_L1_ROUNDS
+#define PS_L1_ROUNDS 10
+#endif
+PS_HD ps_u4 ps_philox_l1(uint32_t site, uint32_t chunk, uint32_t gen, uint32_t k0, uint32_t k1)
+{
+    return ps_philox_r<PS_L1_ROUNDS>(site, chunk, gen, PS_STREAM_CORE_L1, k0, k1);
 }
 
 // n-th f64 of a seeded host stream: two per Philox block, top 53 bits x 2^-53

@@ -240,6 +240,10 @@ class Population:
         """kernel form of the last core pair-count call (include/pansim_hip.h, PS_PAIR_FORM_*)"""
         return int(self._lib.ps_last_pair_form(self._h))
 
+    def last_sweep_form(self):
+        """kernel of the last core sweep launch (include/pansim_hip.h, PS_SWEEP_FORM_*)"""
+        return int(self._lib.ps_last_sweep_form(self._h))
+
     def gene_frequencies(self):
         """population.rs:840-863"""
         out = np.zeros(self.ncols + self.core_genes, np.float64)

@@ -40,6 +40,24 @@ def test_multi_shards_equal_unsharded(pa, orc, n_shards):
     multi.close()
 
 
+def test_borrowed_shard_cannot_be_driven_alone(pa):
+    # the shards' generations meet at barriers (shared parent weights, HGT delta exchange): a lone caller gets an error,
+    # not a hang
+    kw = dict(pop_size=300, core_size=900, pan_genes=700, core_genes=100, HGT_rate=0.6)
+    multi = pa.MultiSimulation(pa.make_params(seed=5, n_gen=2, max_distances=20, **kw), 2, devices=[0, 0])
+    multi.run(1)
+    multi.sync()
+    with pytest.raises(pa.PansimError) as e:
+        multi.shards[1].run(1)
+    assert e.value.code == -6
+    with pytest.raises(pa.PansimError) as e:
+        multi.shards[0].pan_genome.recombine(1)
+    assert e.value.code == -6
+    multi.run(1)             # the run itself is unharmed
+    multi.sync()
+    multi.close()
+
+
 def test_multi_rejects_bad_arguments(pa):
     p = pa.make_params(seed=0, n_gen=1, max_distances=10, pop_size=10, core_size=5, pan_genes=20, core_genes=10)
     with pytest.raises(pa.PansimError):
