@@ -135,6 +135,10 @@ int ps_draw_parents(const double *weights, uint64_t n, uint64_t seed, uint32_t g
 
 /* Population::average_distance (population.rs:753-784) */
 int ps_average_distance(ps_population *p, double *out);
+/* Rows [first, first + count) of average_distance (count values): what one rank of a row-sharded D-avg computes -- every
+ * individual's mean is a sum over ALL others in ascending order (:770), so the rows are independent and a run splits
+ * them over its ranks and all-gathers the N doubles. */
+int ps_average_distance_rows(ps_population *p, uint64_t first, uint64_t count, double *out);
 /* Population::pairwise_distances (population.rs:787-837) */
 int ps_pairwise_distances(ps_population *p, uint64_t max_distances, const uint32_t *range1,
                           const uint32_t *range2, double *out);
@@ -189,6 +193,8 @@ int ps_sync(ps_population *p);
  * sampled form of populations too wide for an LDS tile, 5 = all-pairs xor + popcount tiles even for one-hot matrices,
  * 6 = all pairs on the i8 matrix cores; one-hot matrices go to the matrix cores in modes 0 and 2 (FP4 form) and 6 (i8 form)), "pair_ranges" (site ranges of the tiled
  * sampled-pair kernels, 0 = choose; the 16-bit counter cap still applies),
+ * "davg_form" (average_distance: 0 = choose, 1 = LDS-tile popcount kernels, 2 = intersections on the matrix cores -- the default
+ * from pop_size 4096 and for row shards), "davg_nb" (matrix-core form: 32-individual fragments per wave, 0 = choose, 1 or 2),
  * "hgt_mode" (accessory recombination: 0 = choose, 1 = one atomic per event, 2 = two passes: bin
  * by recipient partition, OR in LDS images), "hgt_slices" (binned HGT: event slices, 0 = choose), "hgt_list_in_global" (0/1: donor gene lists in
  * global scratch instead of LDS; "hgt_bin_list_in_global": the same for the bin pass of the binned form),

@@ -79,6 +79,7 @@ SIGNATURES = {
     "ps_sample_weights": (_int, [_i32p, _f64p, _u64, _u64, _i32, _f64p, _int, _f64, _f64, _f64p]),
     "ps_draw_parents": (_int, [_f64p, _u64, _u64, _u32, _u32p]),
     "ps_average_distance": (_int, [_vp, _f64p]),
+    "ps_average_distance_rows": (_int, [_vp, _u64, _u64, _f64p]),
     "ps_pairwise_distances": (_int, [_vp, _u64, _u32p, _u32p, _f64p]),
     "ps_pairwise_counts": (_int, [_vp, _u64, _u32p, _u32p, _vp, _vp, _int]),
     "ps_last_pair_form": (_int, [_vp]),

@@ -848,3 +848,175 @@ __global__ void __launch_bounds__(256, 8) acc_average_from_matrix_kernel(const d
         out[i] = fd;
     }
 }
+
+// ---------------------------------------------------------------------------
+// D-avg on the matrix cores (round 4; population.rs:753-784 + :114-151 for wide populations).
+// |x_i n x_j| over all pairs is the {0, 1} contraction X X^T (K = the G genes): exact on
+// v_mfma_scale_f32_32x32x64_f8f6f4 with both operands E2M1 (a present gene is the FP4 value 1.0 = 0b0010, block scales
+// 2^0) -- {0, 1} products, f32 sums <= G <= 65536 < 2^24.  Unions come from the row counts (|x u y| = |x| + |y| - |x n y|),
+// the distance 1 - ((n + 0.0 + core_genes) / (u + 0.0 + core_genes)) is evaluated in f64 exactly as get_distance writes it,
+// and every individual's distances are added in ASCENDING j by ONE lane (the reference's sequential fold, :770): only the
+// counting is re-associated, and integer counts have no rounding.
+//   * acc_rows_pad_kernel: the individual-major bit rows copied to rows of WP dwords (a multiple of 8: whole 256-gene
+//     chunks) and Npad rows (a multiple of 128), zero padded, plus the row popcounts: the contraction kernel then has no
+//     edge cases in its loads.
+//   * acc_average_distance_mfma_kernel<NB>: a WAVE owns 32 NB individuals i (the B operand: columns of the 32 x 32
+//     accumulator blocks, i = lane & 31 of block b) and sweeps all j in steps of 128 (four A fragments: rows).  Lane
+//     (r, h) of a fragment takes the genes [256 c + 128 h, +128) of chunk c of individual base + r: one 16-byte load per
+//     chunk; K-step t of the chunk expands dword t -- 32 gene bits -- to 32 FP4 nibbles with four reads of a
+//     byte -> 8-nibble table in LDS (256 entries x 64 copies x 4 bytes = 64 KB at LDS offset 0: copy = lane, so the 64
+//     lanes of a ds_read_b32 hit 64 different banks).  The same K order on both operands is all the contraction needs.
+//   * fold: in the accumulator layout a lane holds column i = lane & 31 and the rows (v & 3) + 8 (v >> 2) + 4 (lane >> 5),
+//     i.e. ascending j alternates between the two halves of the wave in groups of four: the running sum of i travels
+//     between lane i and lane i + 32 after every four additions (both halves execute the additions; only the copy that
+//     holds the live sum is ever passed on).
+// Sharding: a rank computes rows [i_lo, i_lo + i_cnt) against all N columns; the N doubles are all-gathered.
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) acc_rows_pad_kernel(const uint64_t *accI, uint32_t *rowsP, uint32_t *rowcnt, acc_dims d,
+                                                           uint32_t WP, uint32_t Npad)
+{
+    // one wave per padded row
+    const uint32_t row = blockIdx.x * 4u + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
+    if (row >= Npad) return;
+    const uint32_t *src = (const uint32_t *)(accI + (uint64_t)row * d.GW);
+    uint32_t cnt = 0;
+    for (uint32_t w = lane; w < WP; w += 64u) {
+        const uint32_t v = (row < d.N && w < 2u * d.GW) ? src[w] : 0u;
+        rowsP[(uint64_t)row * WP + w] = v;
+        cnt += __popc(v);
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) cnt += __shfl_xor(cnt, off);
+    if (lane == 0) rowcnt[row] = cnt;
+}
+
+typedef int ps_da_v8i __attribute__((ext_vector_type(8)));
+typedef float ps_da_v16f __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ uint32_t ps_da_lut(uint32_t raw, uint32_t colofs, uint32_t b)
+{
+    uint32_t addr;      // (byte b of raw) << 8 | colofs  (colofs = lane * 4 < 256); the table sits at LDS offset 0
+    switch (b) {
+    case 0: addr = __builtin_amdgcn_perm(raw, colofs, 0x0c0c0400u); break;
+    case 1: addr = __builtin_amdgcn_perm(raw, colofs, 0x0c0c0500u); break;
+    case 2: addr = __builtin_amdgcn_perm(raw, colofs, 0x0c0c0600u); break;
+    default: addr = __builtin_amdgcn_perm(raw, colofs, 0x0c0c0700u); break;
+    }
+    return *(const __attribute__((address_space(3))) uint32_t *)(uintptr_t)addr;
+}
+
+template <uint32_t NB>
+__global__ void __launch_bounds__(256) acc_average_distance_mfma_kernel(const uint32_t *rowsP, uint32_t WP, const uint32_t *rowcnt,
+                                                                        uint32_t N, uint32_t Npad, uint32_t i_lo, uint32_t i_cnt,
+                                                                        double core_genes, double *out)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t lut[];      // 256 entries x 64 copies x 4 bytes, at LDS offset 0
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    for (uint32_t x = tid; x < 256u * 64u; x += 256u) {
+        const uint32_t e = x >> 6;
+        uint32_t v = 0;
+#pragma unroll
+        for (uint32_t k = 0; k < 8u; k++) v |= ((e >> k) & 1u) ? (2u << (4u * k)) : 0u;       // gene k of the byte -> nibble k = E2M1 1.0
+        *(uint32_t *)(lut + (size_t)x * 4u) = v;         // x = e * 64 + copy
+    }
+    __syncthreads();
+    const uint32_t colofs = lane << 2;
+    const uint32_t r = lane & 31u, h = lane >> 5;
+    const uint32_t i_base = i_lo + (blockIdx.x * 4u + wave) * 32u * NB;
+    if (i_base >= i_lo + i_cnt) return;                  // (wave-uniform; no barrier follows)
+    const uint32_t *srcB[NB];
+    uint32_t ci[NB];
+    double sum[NB];
+#pragma unroll
+    for (uint32_t b = 0; b < NB; b++) {
+        const uint32_t i = min(i_base + 32u * b + r, Npad - 1u);
+        srcB[b] = rowsP + (size_t)i * WP + h * 4u;
+        ci[b] = rowcnt[i];
+        sum[b] = 0.0;
+    }
+    const uint32_t nch = WP / 8u;
+    const int one = 0x7f7f7f7f;          // E8M0 block scale 2^0 in every byte
+    for (uint32_t j0 = 0; j0 < Npad; j0 += 128u) {
+        const uint32_t *srcA[4];
+#pragma unroll
+        for (uint32_t a = 0; a < 4u; a++) srcA[a] = rowsP + (size_t)(j0 + 32u * a + r) * WP + h * 4u;
+        ps_da_v16f acc[4][NB];
+#pragma unroll
+        for (uint32_t a = 0; a < 4u; a++)
+#pragma unroll
+            for (uint32_t b = 0; b < NB; b++)
+#pragma unroll
+                for (int v = 0; v < 16; v++) acc[a][b][v] = 0.0f;
+        uint4 cur[4 + NB], nxt[4 + NB];
+#pragma unroll
+        for (uint32_t f = 0; f < 4u + NB; f++) cur[f] = *(const uint4 *)((f < 4u ? srcA[f] : srcB[f - 4u]));
+        for (uint32_t c = 0; c < nch; c++) {
+            const uint32_t cn = min(c + 1u, nch - 1u);
+#pragma unroll
+            for (uint32_t f = 0; f < 4u + NB; f++) nxt[f] = *(const uint4 *)((f < 4u ? srcA[f] : srcB[f - 4u]) + (size_t)cn * 8u);
+#pragma unroll
+            for (uint32_t t = 0; t < 4u; t++) {
+                ps_da_v8i op[4 + NB];
+#pragma unroll
+                for (uint32_t f = 0; f < 4u + NB; f++) {
+                    const uint32_t raw = t == 0u ? cur[f].x : t == 1u ? cur[f].y : t == 2u ? cur[f].z : cur[f].w;
+                    op[f] = ps_da_v8i{ (int)ps_da_lut(raw, colofs, 0u), (int)ps_da_lut(raw, colofs, 1u), (int)ps_da_lut(raw, colofs, 2u),
+                                       (int)ps_da_lut(raw, colofs, 3u), 0, 0, 0, 0 };
+                }
+#pragma unroll
+                for (uint32_t a = 0; a < 4u; a++)
+#pragma unroll
+                    for (uint32_t b = 0; b < NB; b++)
+                        acc[a][b] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(op[a], op[4u + b], acc[a][b], 4, 4, 0, one, 0, one);
+            }
+#pragma unroll
+            for (uint32_t f = 0; f < 4u + NB; f++) cur[f] = nxt[f];
+        }
+        // distances and the ordered fold.  Block (a, b): column i = i_base + 32 b + r, rows j0 + 32 a + (v & 3) + 8 (v >> 2) + 4 h
+#pragma unroll
+        for (uint32_t a = 0; a < 4u; a++) {
+#pragma unroll
+            for (uint32_t g = 0; g < 4u; g++) {
+                const uint32_t jr = j0 + 32u * a + 8u * g + 4u * h;        // this lane's four rows of group g: jr .. jr + 3
+                const uint4 cj4 = *(const uint4 *)(rowcnt + jr);
+                const uint32_t cjv[4] = { cj4.x, cj4.y, cj4.z, cj4.w };
+                double dv[NB][4];
+#pragma unroll
+                for (uint32_t b = 0; b < NB; b++) {
+                    const uint32_t i = i_base + 32u * b + r;
+#pragma unroll
+                    for (uint32_t q = 0; q < 4u; q++) {
+                        const uint32_t in = (uint32_t)acc[a][b][4 * g + q], j = jr + q;
+                        const uint32_t un = ci[b] + cjv[q] - in;
+                        const double pd = 1.0 - (((double)in + 0.0 + core_genes) / ((double)un + 0.0 + core_genes));
+                        dv[b][q] = (j == i || j >= N) ? 0.0 : pd;         // the j == i term is skipped (:126-128); + 0.0 leaves a sum >= 0 as it is
+                    }
+                }
+                // rows 8 g .. 8 g + 3 sit in the lower half of the wave, 8 g + 4 .. 8 g + 7 in the upper; the live sum of column i
+                // is in lane i when the group starts.  Every lane adds its four rows (the upper half on a stale copy), the
+                // sums swap halves -- the live one is now in lane i + 32, which has not added its rows to IT yet -- every
+                // lane adds its four rows again (now the lower half works on the stale copy), and the sums swap back.
+#pragma unroll
+                for (uint32_t b = 0; b < NB; b++) {
+                    double s = sum[b];
+#pragma unroll
+                    for (uint32_t q = 0; q < 4u; q++) s = s + dv[b][q];
+                    s = __shfl_xor(s, 32);
+#pragma unroll
+                    for (uint32_t q = 0; q < 4u; q++) s = s + dv[b][q];
+                    s = __shfl_xor(s, 32);
+                    sum[b] = s;
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (uint32_t b = 0; b < NB; b++) {
+        const uint32_t i = i_base + 32u * b + r;
+        if (h == 0u && i < N && i < i_lo + i_cnt) {
+            double fd = sum[b] / (double)(N - 1u);
+            if (fd == 0.0) fd = 2.2250738585072014e-308;    // f64::MIN_POSITIVE, population.rs:774-776
+            out[i] = fd;
+        }
+    }
+}

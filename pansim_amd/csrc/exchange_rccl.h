@@ -84,14 +84,20 @@ static std::string why_not()
 
 }  // namespace ps_rccl
 
+struct ps_rccl_scratch {
+    // work buffers of one buffer length, allocated at its first call and kept: the padded delta / the gathered result
+    // (K slices of `part` words), the K received slices, their OR
+    uint64_t n_words = 0, part = 0;
+    uint64_t *send = nullptr, *recv = nullptr, *mine = nullptr;
+};
+
 struct ps_rccl_exchange {
     ps_rccl::api *api = nullptr;
     ncclComm_t comm = nullptr;
     int rank = 0, world = 1, device = 0;
-    // work buffers, allocated at the first call for a buffer length and kept: the padded delta / the gathered result
-    // (K slices of `part` words), the K received slices, their OR
-    uint64_t n_words = 0, part = 0;
-    uint64_t *send = nullptr, *recv = nullptr, *mine = nullptr;
+    // a run exchanges buffers of two lengths per generation (the HGT delta matrix; the N average distances of a
+    // --competition_strength run): one scratch set per length, so that alternating calls never reallocate
+    ps_rccl_scratch scratch[4];
     uint64_t calls = 0, bytes = 0;
 };
 
@@ -133,9 +139,11 @@ extern "C" void ps_rccl_exchange_destroy(ps_rccl_exchange *x)
 {
     if (!x) return;
     (void)hipSetDevice(x->device);
-    if (x->send) (void)hipFree(x->send);
-    if (x->recv) (void)hipFree(x->recv);
-    if (x->mine) (void)hipFree(x->mine);
+    for (ps_rccl_scratch &c : x->scratch) {
+        if (c.send) (void)hipFree(c.send);
+        if (c.recv) (void)hipFree(c.recv);
+        if (c.mine) (void)hipFree(c.mine);
+    }
     if (x->comm && x->api) (void)x->api->CommDestroy(x->comm);
     delete x;
 }
@@ -179,34 +187,42 @@ extern "C" int ps_exchange_rccl(void *ctx, void *d_words, uint64_t n_words, void
     hipStream_t st = (hipStream_t)hip_stream;
     const uint64_t K = (uint64_t)x->world;     // (K = 1 runs the same calls: a send / receive to itself, a gather of one)
     HIPCHK(hipSetDevice(x->device));
-    if (x->n_words != n_words) {
-        if (x->send) HIPCHK(hipFree(x->send));
-        if (x->recv) HIPCHK(hipFree(x->recv));
-        if (x->mine) HIPCHK(hipFree(x->mine));
-        x->send = x->recv = x->mine = nullptr;
-        x->n_words = 0;
+    ps_rccl_scratch *sc = nullptr;
+    for (ps_rccl_scratch &c : x->scratch)
+        if (c.n_words == n_words) { sc = &c; break; }
+    if (!sc) {
+        for (ps_rccl_scratch &c : x->scratch)
+            if (c.n_words == 0) { sc = &c; break; }
+        if (!sc) {                               // all four sets taken by other lengths: recycle the first
+            sc = &x->scratch[0];
+            HIPCHK(hipStreamSynchronize(st));
+            if (sc->send) HIPCHK(hipFree(sc->send));
+            if (sc->recv) HIPCHK(hipFree(sc->recv));
+            if (sc->mine) HIPCHK(hipFree(sc->mine));
+            *sc = ps_rccl_scratch{};
+        }
         const uint64_t part = (n_words + K - 1) / K;
-        HIPCHK(hipMalloc(&x->send, K * part * 8));
-        HIPCHK(hipMalloc(&x->recv, K * part * 8));
-        HIPCHK(hipMalloc(&x->mine, part * 8));
+        HIPCHK(hipMalloc(&sc->send, K * part * 8));
+        HIPCHK(hipMalloc(&sc->recv, K * part * 8));
+        HIPCHK(hipMalloc(&sc->mine, part * 8));
         // the pad words behind the delta are zeroed once and stay zero (the all-gather writes the OR of zeros there)
-        HIPCHK(hipMemsetAsync(x->send, 0, K * part * 8, st));
-        x->part = part;
-        x->n_words = n_words;
+        HIPCHK(hipMemsetAsync(sc->send, 0, K * part * 8, st));
+        sc->part = part;
+        sc->n_words = n_words;
     }
-    const uint64_t part = x->part;
+    const uint64_t part = sc->part;
     ps_rccl::api *a = x->api;
-    HIPCHK(hipMemcpyAsync(x->send, d_words, n_words * 8, hipMemcpyDeviceToDevice, st));
+    HIPCHK(hipMemcpyAsync(sc->send, d_words, n_words * 8, hipMemcpyDeviceToDevice, st));
     NCCLCHK(a, a->GroupStart());
     for (uint64_t k = 0; k < K; k++) {
-        NCCLCHK(a, a->Send(x->send + k * part, part, ncclUint64, (int)k, x->comm, st));
-        NCCLCHK(a, a->Recv(x->recv + k * part, part, ncclUint64, (int)k, x->comm, st));
+        NCCLCHK(a, a->Send(sc->send + k * part, part, ncclUint64, (int)k, x->comm, st));
+        NCCLCHK(a, a->Recv(sc->recv + k * part, part, ncclUint64, (int)k, x->comm, st));
     }
     NCCLCHK(a, a->GroupEnd());
-    rccl_or_slices_kernel<<<(uint32_t)((part + 255) / 256), 256, 0, st>>>(x->mine, x->recv, part, (uint32_t)K);
+    rccl_or_slices_kernel<<<(uint32_t)((part + 255) / 256), 256, 0, st>>>(sc->mine, sc->recv, part, (uint32_t)K);
     HIPCHK(hipGetLastError());
-    NCCLCHK(a, a->AllGather(x->mine, x->send, part, ncclUint64, x->comm, st));
-    HIPCHK(hipMemcpyAsync(d_words, x->send, n_words * 8, hipMemcpyDeviceToDevice, st));
+    NCCLCHK(a, a->AllGather(sc->mine, sc->send, part, ncclUint64, x->comm, st));
+    HIPCHK(hipMemcpyAsync(d_words, sc->send, n_words * 8, hipMemcpyDeviceToDevice, st));
     x->calls++;
     x->bytes += 2 * part * 8 * (K - 1);
     return PS_OK;

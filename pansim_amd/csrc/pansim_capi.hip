@@ -229,6 +229,10 @@ struct ps_population {
     double *d_logw = nullptr;        // N
     uint32_t *d_H = nullptr;         // all-pairs Hamming numerators N x N
     double *d_Dt = nullptr;          // all-pairs Jaccard distances (D-avg), N x N
+    void *d_davg = nullptr;          // matrix-core D-avg: the padded bit rows + row counts
+    uint64_t davg_cap = 0;
+    int davg_form = 0;               // 0 = choose, 1 = LDS-tile popcount kernels, 2 = matrix cores
+    uint32_t davg_nb = 0;            // matrix-core D-avg: B fragments per wave (0 = choose, 1 or 2)
     uint64_t H_cap = 0;
     int pair_mode = 0;               // 0 auto, 1 sampled kernel, 2 all-pairs kernel (tuning/tests)
     int last_pair_form = 0;          // kernel form of the last core pair-count call (ps_last_pair_form)
@@ -267,7 +271,7 @@ extern "C" void ps_population_destroy(ps_population *p)
     (void)hipSetDevice(p->device);
     if (p->stream) (void)hipStreamSynchronize(p->stream);
     void *ptrs[] = { p->state, p->state2, p->d_delta, p->hgt_ovf_img, p->G[0], p->G[1], p->I[0], p->I[1], p->I_snap, p->d_ptab[0], p->d_ptab[1], p->hgt_scratch, p->cnt, p->d_idx, p->d_idxT, p->d_work,
-                     p->d_log1p, p->d_num_genes, p->d_logw, p->d_pairs, p->d_H, p->d_Dt, p->d_pack2, p->d_pair_part };
+                     p->d_log1p, p->d_num_genes, p->d_logw, p->d_pairs, p->d_H, p->d_Dt, p->d_davg, p->d_pack2, p->d_pair_part };
     for (void *q : ptrs)
         if (q) (void)hipFree(q);
     if (p->h_flag) (void)hipHostFree(p->h_flag);
@@ -441,6 +445,12 @@ extern "C" int ps_set_tuning(ps_population *p, const char *key, int64_t value)
     } else if (k == "sweep_out_of_place") {
         if (value < -1 || value > 2) return ps_fail(PS_ERR_INVALID, "sweep_out_of_place must be -1 (choose), 0 (in place), 1 (out of place) or 2 (out of place, nontemporal loads and stores)");
         p->sweep_oop = (int)value;
+    } else if (k == "davg_form") {
+        if (value < 0 || value > 2) return ps_fail(PS_ERR_INVALID, "davg_form must be 0 (choose), 1 (LDS-tile popcount kernels) or 2 (matrix cores)");
+        p->davg_form = (int)value;
+    } else if (k == "davg_nb") {
+        if (value < 0 || value > 2) return ps_fail(PS_ERR_INVALID, "davg_nb must be 0 (choose), 1 or 2");
+        p->davg_nb = (uint32_t)value;
     } else if (k == "hgt_mode") {
         if (value < 0 || value > 2) return ps_fail(PS_ERR_INVALID, "hgt_mode must be 0 (auto), 1 (one atomic per event) or 2 (binned by recipient partition, two passes)");
         p->hgt_mode = (int)value;
@@ -1471,11 +1481,42 @@ extern "C" int ps_sample_indices(ps_population *acc, uint32_t generation, int32_
 // ---------------------------------------------------------------------------
 // distances
 // ---------------------------------------------------------------------------
-// D-avg (population.rs:753-784) into a device buffer of N doubles
-static int average_distance_device(ps_population *p, double *d_out, hipStream_t st)
+// D-avg (population.rs:753-784) into a device buffer of N doubles.  Rows [i_lo, i_lo + i_cnt) only (a row shard of a
+// sharded run, DESIGN.md 6: the other entries of d_out are left alone); the whole population when i_cnt == N.
+static int average_distance_device(ps_population *p, double *d_out, hipStream_t st, uint64_t i_lo = 0, uint64_t i_cnt = ~0ull)
 {
     const uint64_t N = p->cfg.pop_size;
-    if (N <= 8192) {
+    if (i_cnt == ~0ull) i_cnt = N - i_lo;
+    // wide populations (and every row shard): intersections on the matrix cores, ordered f64 fold in the accumulator layout
+    // (acc_kernels.h); "davg_form": 0 = choose, 1 = LDS-tile popcount kernels, 2 = matrix cores
+    const bool whole = i_lo == 0 && i_cnt == N;
+    const bool mfma = p->d.G > 0 && N >= 2 && (p->davg_form == 2 || !whole || (p->davg_form == 0 && N >= 4096));
+    if (mfma) {
+        const uint32_t WP = (2u * p->d.GW + 7u) & ~7u, Npad = (uint32_t)((N + 127) & ~127ull);
+        const uint64_t need = (uint64_t)Npad * WP * 4 + (uint64_t)Npad * 4 + 64;
+        if (p->davg_cap < need) {
+            if (p->d_davg) HIPCHK(hipFree(p->d_davg));
+            p->d_davg = nullptr;
+            p->davg_cap = 0;
+            HIPCHK(hipMalloc(&p->d_davg, need));
+            p->davg_cap = need;
+        }
+        uint32_t *rowsP = (uint32_t *)p->d_davg, *rowcnt = rowsP + (uint64_t)Npad * WP;
+        acc_rows_pad_kernel<<<(Npad + 3u) / 4u, 256, 0, st>>>(p->I[p->cur], rowsP, rowcnt, p->d, WP, Npad);
+        // 64 individuals per wave (two B fragments: fewer table reads per MFMA) when that still gives every SIMD a wave
+        const uint32_t nb = p->davg_nb ? p->davg_nb : (i_cnt >= 64u * 1024u ? 2u : 1u);
+        const uint32_t waves = (uint32_t)((i_cnt + 32u * nb - 1) / (32u * nb)), grid = (waves + 3u) / 4u;
+        const uint32_t lds = 256u * 64u * 4u;
+        if (nb == 2u) {
+            HIPCHK(hipFuncSetAttribute((const void *)acc_average_distance_mfma_kernel<2u>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            acc_average_distance_mfma_kernel<2u><<<grid, 256, lds, st>>>(rowsP, WP, rowcnt, (uint32_t)N, Npad, (uint32_t)i_lo, (uint32_t)i_cnt,
+                                                                        (double)p->cfg.core_genes, d_out);
+        } else {
+            HIPCHK(hipFuncSetAttribute((const void *)acc_average_distance_mfma_kernel<1u>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            acc_average_distance_mfma_kernel<1u><<<grid, 256, lds, st>>>(rowsP, WP, rowcnt, (uint32_t)N, Npad, (uint32_t)i_lo, (uint32_t)i_cnt,
+                                                                        (double)p->cfg.core_genes, d_out);
+        }
+    } else if (N <= 8192) {
         if (!p->d_Dt) HIPCHK(hipMalloc(&p->d_Dt, N * N * sizeof(double)));
         const uint32_t nt = (uint32_t)((N + 63) / 64);
         if (nt * (nt + 1u) / 2u < 512u) {
@@ -1906,6 +1947,33 @@ extern "C" int ps_average_distance(ps_population *p, double *out)
     HIPCHK(hipMalloc(&d_out, N * sizeof(double)));
     PSCHK(average_distance_device(p, d_out, p->stream));
     HIPCHK(hipMemcpyAsync(out, d_out, N * sizeof(double), hipMemcpyDeviceToHost, p->stream));
+    HIPCHK(hipStreamSynchronize(p->stream));
+    HIPCHK(hipFree(d_out));
+    return PS_OK;
+}
+
+// the rows [first, first + count) of average_distance: what one rank of a row-sharded D-avg computes
+extern "C" int ps_average_distance_rows(ps_population *p, uint64_t first, uint64_t count, double *out)
+{
+    if (!p || !out) return ps_fail(PS_ERR_INVALID, "null argument");
+    if (p->cfg.core)
+        return ps_fail(PS_ERR_INVALID, "average_distance is only reached on the accessory matrix (main.rs:439)");
+    const uint64_t N = p->cfg.pop_size;
+    if (N < 2) return ps_fail(PS_ERR_INVALID, "average_distance needs pop_size >= 2");
+    if (count < 1 || first >= N || count > N - first) return ps_fail(PS_ERR_INVALID, "rows [%llu, +%llu) outside the population",
+                                                                     (unsigned long long)first, (unsigned long long)count);
+    if (p->d.G == 0) {
+        // no accessory genes: every pair is 1 - core_genes / core_genes (get_distance, population.rs:144-145)
+        std::vector<double> all(N);
+        PSCHK(ps_average_distance(p, all.data()));
+        memcpy(out, all.data() + first, count * sizeof(double));
+        return PS_OK;
+    }
+    PSCHK(use_device(p));
+    double *d_out = nullptr;
+    HIPCHK(hipMalloc(&d_out, N * sizeof(double)));
+    PSCHK(average_distance_device(p, d_out, p->stream, first, count));
+    HIPCHK(hipMemcpyAsync(out, d_out + first, count * sizeof(double), hipMemcpyDeviceToHost, p->stream));
     HIPCHK(hipStreamSynchronize(p->stream));
     HIPCHK(hipFree(d_out));
     return PS_OK;
@@ -2620,9 +2688,33 @@ extern "C" int ps_sim_create(const ps_sim_params *p, ps_sim **out)
     return PS_OK;
 }
 
+// D-avg of a generation (main.rs:438-440) into s->d_avg on the accessory stream.  In a run whose shards exchange (the
+// donor-sharded HGT's hook is installed) the rows are sharded the same way: this shard computes the rows of ITS individuals
+// [N r / K, N (r + 1) / K) -- every individual's mean is an ordered sum over all others, so rows are independent -- into a
+// zeroed vector, and the OR exchange of the N doubles' bit patterns is the all-gather (disjoint slices, zeros elsewhere).
+static int sim_average_distance(ps_sim *s)
+{
+    ps_population *acc = s->acc;
+    const uint64_t N = s->prm.pop_size;
+    hipStream_t sa = acc->stream;
+    const bool sharded = acc->exchange && acc->donor_cnt != 0 && acc->d.G > 0 && N >= 2;
+    if (!sharded) return average_distance_device(acc, s->d_avg, sa);
+    HIPCHK(hipMemsetAsync(s->d_avg, 0, N * sizeof(double), sa));
+    PSCHK(average_distance_device(acc, s->d_avg, sa, acc->donor_lo, acc->donor_cnt));
+    const std::string prev = g_err;
+    g_err.clear();
+    const int rc = acc->exchange(acc->exchange_ctx, s->d_avg, N, (void *)sa);
+    if (rc != 0) {
+        const std::string inner = g_err;
+        return ps_fail(PS_ERR_STATE, "the all-gather of the average distances failed (%d)%s%s", rc, inner.empty() ? "" : ": ", inner.c_str());
+    }
+    g_err = prev;
+    return PS_OK;
+}
+
 // main.rs:435-443 up to the weights: D-avg when competition is on, the device half of sample_indices (gene counts and
 // log-fitness per individual, written straight into host-mapped memory), then the three softmaxes on the host
-static int sim_host_weights(ps_sim *s, uint32_t gen, double *w)
+static int sim_host_weights(ps_sim *s, uint32_t gen, double *w, bool avg_ready = false)
 {
     (void)gen;
     ps_population *acc = s->acc;
@@ -2633,7 +2725,7 @@ static int sim_host_weights(ps_sim *s, uint32_t gen, double *w)
     auto ms_since = [](clk::time_point t0) { return std::chrono::duration<double, std::milli>(clk::now() - t0).count(); };
     for (uint64_t i = 0; i < N; i++) s->h_avg[i] = 1.0;                 // main.rs:435
     if (p.competition_strength > 0.0) {                                  // :438-440
-        PSCHK(average_distance_device(acc, s->d_avg, sa));
+        if (!avg_ready) PSCHK(sim_average_distance(s));
         HIPCHK(hipMemcpyAsync(s->h_avg, s->d_avg, N * sizeof(double), hipMemcpyDeviceToHost, sa));
     }
     if (s->need_logw)
@@ -3098,8 +3190,14 @@ static int multi_weights(void *vctx, ps_sim *s, uint32_t gen, double *w)
     multi_ctx *c = (multi_ctx *)vctx;
     ps_multi *m = c->m;
     const uint64_t N = m->prm.pop_size;
+    // D-avg sharded by rows over the shards like the HGT donors: every shard computes its rows and takes part in the exchange
+    bool avg_ready = false;
+    if (m->prm.competition_strength > 0.0 && s->acc->exchange && s->acc->donor_cnt != 0 && s->acc->d.G > 0) {
+        PSCHK(sim_average_distance(s));
+        avg_ready = true;
+    }
     if (c->k == 0) {
-        m->shared_rc = sim_host_weights(s, gen, m->shared_w.data());
+        m->shared_rc = sim_host_weights(s, gen, m->shared_w.data(), avg_ready);
         if (m->shared_rc != PS_OK) m->shared_err = g_err;
     }
     PSCHK(multi_barrier(m));                     // shard 0 has published the weights

@@ -81,7 +81,7 @@ class TorchExchange:
         self.group = group
         self.device = device
         self.force_a2a = force_a2a
-        self.scratch = None
+        self.scratch = {}           # one OrScratch per buffer length (the HGT deltas; the N average distances of D-avg)
         self.calls = 0
         self.bytes = 0
         self.error = None
@@ -101,15 +101,17 @@ class TorchExchange:
                     if not on_device:
                         stream.synchronize()                # the delta is complete before it leaves the device
                         host = buf.cpu()
-                        if self.force_a2a and (self.scratch is None or not self.scratch.fits(host, K)):
-                            self.scratch = OrScratch(n_words, K, host)
-                        self.bytes += or_all_reduce(host, self.group, self.force_a2a, self.scratch)
+                        sc = self.scratch.get(int(n_words))
+                        if self.force_a2a and (sc is None or not sc.fits(host, K)):
+                            sc = self.scratch[int(n_words)] = OrScratch(n_words, K, host)
+                        self.bytes += or_all_reduce(host, self.group, self.force_a2a, sc)
                         buf.copy_(host)
                         stream.synchronize()
                     else:
-                        if self.scratch is None or not self.scratch.fits(buf, K):
-                            self.scratch = OrScratch(n_words, K, buf)   # (allocated once: 3 x 33 MB at N = 65536)
-                        self.bytes += or_all_reduce(buf, self.group, False, self.scratch)
+                        sc = self.scratch.get(int(n_words))
+                        if sc is None or not sc.fits(buf, K):
+                            sc = self.scratch[int(n_words)] = OrScratch(n_words, K, buf)   # (allocated once: 3 x 33 MB at N = 65536)
+                        self.bytes += or_all_reduce(buf, self.group, False, sc)
             self.calls += 1
             return 0
         except Exception as e:          # never let an exception cross the C boundary

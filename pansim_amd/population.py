@@ -206,6 +206,12 @@ class Population:
         check(self._lib.ps_average_distance(self._h, out))
         return out
 
+    def average_distance_rows(self, first, count):
+        """rows [first, first + count) of average_distance (one rank's share of a row-sharded D-avg)"""
+        out = np.zeros(int(count), np.float64)
+        check(self._lib.ps_average_distance_rows(self._h, int(first), int(count), out))
+        return out
+
     def pairwise_distances(self, max_distances, range1, range2):
         """population.rs:787-837"""
         r1, r2 = _u32(range1)[:max_distances], _u32(range2)[:max_distances]

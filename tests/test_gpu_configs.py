@@ -146,6 +146,33 @@ def test_average_distance_large_populations(pa, orc, N, G, cg):
     pop.close()
 
 
+@pytest.mark.parametrize("N,G,cg,nb", [(2, 9, 0, 0), (33, 65, 0, 1), (130, 257, 3, 2), (1000, 4000, 2000, 1), (2100, 130, 7, 2),
+                                       (4100, 4000, 2000, 0), (9000, 64, 0, 0), (20000, 300, 11, 0)])
+def test_average_distance_on_the_matrix_cores(pa, orc, N, G, cg, nb):
+    # D-avg with the intersections as a {0, 1} X X^T on the FP4 matrix cores and the ordered f64 fold in the accumulator
+    # layout (acc_average_distance_mfma_kernel; population.rs:753-784, :114-151): ragged populations and gene counts, both
+    # fragment counts per wave, a zero distance and an empty row inside the fold, cg = 0 (an empty union is NaN and must
+    # stay out of the fold only where j == i), and row shards against slices of the whole
+    rng = np.random.default_rng(N * 7 + G)
+    m = (rng.random((N, G)) < 0.3).astype(np.uint8)
+    if N > 6:
+        m[5] = m[6]                                   # a zero distance inside the fold
+        m[3] = 0                                      # an individual without genes
+    want = orc.average_distance(m, False, cg)
+    pop = pa.Population(N, G, 2, False, 0.3, 0, cg)
+    pop.load_matrix(m)
+    pop.set_tuning("davg_form", 2)
+    pop.set_tuning("davg_nb", nb)
+    assert np.array_equal(pop.average_distance(), want, equal_nan=True)
+    K = 3 if N >= 3 else 2
+    got = np.concatenate([pop.average_distance_rows(N * r // K, N * (r + 1) // K - N * r // K) for r in range(K)])
+    assert np.array_equal(got, want, equal_nan=True)
+    if N == 20000:
+        pop.set_tuning("davg_form", 1)                # the LDS-tile popcount kernel agrees
+        assert np.array_equal(pop.average_distance(), want, equal_nan=True)
+    pop.close()
+
+
 def test_randomised_stress_subset(pa, orc):
     # a time-boxed subset of scripts/stress_parity.py (the long run): random geometries of the distance,
     # HGT and sweep kernels and short generation loops, every result compared with the oracle
@@ -213,3 +240,106 @@ def test_window_sweep_of_wide_populations(pa, orc, kw, extra, window):
     core_d, acc_d = sim.final_distances()
     assert np.array_equal(core_d, orc.pairwise_distances(ref.core, True, kw["core_genes"], sim.range1, sim.range2))
     sim.close()
+
+
+# ----------------------------------------------------------------------------- full-size properties of configs[2..4]
+# Siblings of test_gpu_parity.py::test_config2_full_size_properties: the whole 1.2 M-site genome at each BASELINE
+# population, checked through size-independent properties with device-side reductions only (no 78 GB read-back):
+# one-hot alleles <=> every pair's xor-popcount is even (population.rs:817), deterministic replay under --seed, 8 site
+# shards' numerators summing to the unsharded ones (the shards are keyed at their global offsets, so this compares the
+# full-length launch -- row ranges per XCD group, chunk counters, second buffer -- with eight short ones), HGT gain-only.
+def _shard_counts_sum(pa, kw, gens, P, n_shards, seed=0):
+    total = None
+    for r in range(n_shards):
+        sh = pa.Simulation(pa.make_params(seed=seed, n_gen=gens, max_distances=P, shard_rank=r, shard_count=n_shards, **kw))
+        sh.run(gens)
+        (c,) = sh.core_genome.pairwise_counts(sh.range1, sh.range2)
+        total = c.astype(np.uint64) if total is None else total + c
+        sh.close()
+    return total
+
+
+def test_config3_full_size_properties(pa):
+    # BASELINE configs[2]: HR_rate = HGT_rate = 0.5 at the full 1.2 M sites (the plain, non-STASH wave sweep: bC = 18;
+    # the binned HGT taking turns with the sweep)
+    kw = dict(pop_size=1000, core_size=1200000, pan_genes=6000, core_genes=2000, HR_rate=0.5, HGT_rate=0.5)
+    P, gens = 50000, 4
+    runs = []
+    for _ in range(2):
+        sim = pa.Simulation(pa.make_params(seed=0, n_gen=gens, max_distances=P, **kw))
+        sim.run(gens)
+        (cnt,) = sim.core_genome.pairwise_counts(sim.range1, sim.range2)
+        runs.append((sim.last_parents(), cnt, sim.pan_genome.gene_frequencies(), sim.pan_genome.read_matrix()))
+        if len(runs) == 1:
+            assert sim.core_genome.last_sweep_form() == 1                # PS_SWEEP_FORM_WAVE (plain)
+            assert (cnt % 2 == 0).all() and cnt.max() > 0                # alleles stay one-hot
+            # HGT never clears a gene (population.rs:632): one more recombination on the same state only adds bits
+            before = runs[0][3]
+            sim.pan_genome.recombine(gens)
+            after = sim.pan_genome.read_matrix()
+            assert (after >= before).all() and after.sum() > before.sum()
+        sim.close()
+    for a, b in zip(runs[0], runs[1]):                                   # deterministic replay under --seed
+        assert np.array_equal(a, b)
+    assert np.array_equal(_shard_counts_sum(pa, kw, gens, P, 8), runs[0][1].astype(np.uint64))
+
+
+def test_config4_full_size_properties(pa):
+    # BASELINE configs[3]: --pop_size 65536 with all 1.2 M sites on one GPU (2 x 78.6 GB: the window sweep is out of
+    # place), two generations; nothing of the core matrix comes back to the host
+    import torch
+    free, _total = torch.cuda.mem_get_info()
+    if free < 170e9:
+        pytest.skip("needs 2 x 78.6 GB of HBM")
+    kw = dict(pop_size=65536, core_size=1200000, pan_genes=6000, core_genes=2000)
+    P, gens = 100000, 2
+    runs = []
+    for _ in range(2):
+        sim = pa.Simulation(pa.make_params(seed=0, n_gen=gens, max_distances=P, **kw))
+        sim.run(gens)
+        (cnt,) = sim.core_genome.pairwise_counts(sim.range1, sim.range2)
+        runs.append((sim.last_parents(), cnt, sim.pan_genome.gene_frequencies()))
+        if len(runs) == 1:
+            assert sim.core_genome.last_sweep_form() == 3                # PS_SWEEP_FORM_WINDOW
+            assert sim.core_genome.last_pair_form() == 4                 # transposed strings, two streamed per pair
+            assert (cnt % 2 == 0).all() and cnt.max() > 0
+            par = runs[0][0]
+            assert (np.diff(par.astype(np.int64)) >= 0).all()            # children in ascending parent order
+        sim.close()
+    for a, b in zip(runs[0], runs[1]):
+        assert np.array_equal(a, b)
+    # eight site shards of 150 000 sites (what the 8 ranks of the north-star run hold), one after the other
+    assert np.array_equal(_shard_counts_sum(pa, kw, gens, P, 8), runs[0][1].astype(np.uint64))
+
+
+def test_config5_full_size_distance_forms_agree(pa):
+    # BASELINE configs[4]: --pop_size 8192 --max_distances 33554432 at the full 1.2 M sites: the 2^25-pair phase through
+    # the block-scaled FP4 matrix-core form (the default), the i8 matrix-core form and the xor + popcount tiles must give
+    # the same integers; two generations first so that the population is not clonal
+    kw = dict(pop_size=8192, core_size=1200000, pan_genes=6000, core_genes=2000)
+    P, gens = 1 << 25, 2
+    sim = pa.Simulation(pa.make_params(seed=0, n_gen=gens, max_distances=P, **kw))
+    sim.run(gens)
+    sim.sync()
+    assert sim.core_genome.last_sweep_form() == 3
+    got = {}
+    for mode, form in ((0, 7), (6, 6), (5, 2)):
+        sim.core_genome.set_tuning("pair_mode", mode)
+        (cnt,) = sim.core_genome.pairwise_counts(sim.range1, sim.range2)
+        assert sim.core_genome.last_pair_form() == form
+        got[mode] = cnt
+    assert (got[0] % 2 == 0).all() and got[0].max() > 0
+    assert np.array_equal(got[0], got[6]) and np.array_equal(got[0], got[5])
+    # a pair of an individual with itself would count 0; the pair list never holds one (main.rs:413-427)
+    assert (sim.range1 != sim.range2).all()
+    # replay: the same generations again give the same numerators and gene frequencies
+    freqs = sim.pan_genome.gene_frequencies()
+    parents = sim.last_parents()
+    sim.close()
+    sim = pa.Simulation(pa.make_params(seed=0, n_gen=gens, max_distances=P, **kw))
+    sim.run(gens)
+    (cnt,) = sim.core_genome.pairwise_counts(sim.range1, sim.range2)
+    assert np.array_equal(cnt, got[0]) and np.array_equal(sim.pan_genome.gene_frequencies(), freqs)
+    assert np.array_equal(sim.last_parents(), parents)
+    sim.close()
+    assert np.array_equal(_shard_counts_sum(pa, kw, gens, 1 << 20, 8), got[0][:1 << 20].astype(np.uint64))

@@ -84,7 +84,7 @@ def test_cli_gpus_2_equals_gpus_1(pa, tmp_path):
             assert filecmp.cmp(str(outs[0][0]) + suffix, str(pref) + suffix, shallow=False), suffix
 
 
-def _hip_worker(rank, world, port, out, exchange="torch"):
+def _hip_worker(rank, world, port, out, exchange="torch", comp=0.0):
     # one rank of a two-process site-sharded run with the REAL HIP engine (both ranks share the box's one GPU);
     # the exchange is pansim_amd.distributed over gloo (the driver's multi-GPU runs use nccl = RCCL)
     import sys
@@ -95,9 +95,10 @@ def _hip_worker(rank, world, port, out, exchange="torch"):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from pansim_amd.distributed import ShardedSimulation
     s = ShardedSimulation(rank, world, seed=21, n_gen=3, max_distances=900, device=0, shard_hgt_donors=True, exchange=exchange,
-                          **_MP_KW)
+                          competition_strength=comp, **_MP_KW)
     s.run(3)
-    assert s.exchange is not None and s.exchange.calls == 3 and s.exchange.error is None
+    # one exchange per generation (the HGT deltas), two with competition (the row-sharded average distances first)
+    assert s.exchange is not None and s.exchange.calls == (6 if comp > 0.0 else 3) and s.exchange.error is None
     agree = s.parents_agree()
     core, acc = s.final_distances()
     np.save(os.path.join(out, "core_%d.npy" % rank), core)
@@ -121,8 +122,9 @@ def test_two_processes_with_the_hip_engine(pa, orc, tmp_path, exchange):
     from orc_sim import OracleSim
     world = 2
     port = 31000 + (os.getpid() + 7 * len(exchange)) % 2000
-    mp.spawn(_hip_worker, args=(world, port, str(tmp_path), exchange), nprocs=world, join=True)
-    full = OracleSim(seed=21, **_MP_KW)
+    comp = 3.0 if exchange == "torch_a2a" else 0.0          # (the second form also shards D-avg by rows over the ranks)
+    mp.spawn(_hip_worker, args=(world, port, str(tmp_path), exchange, comp), nprocs=world, join=True)
+    full = OracleSim(seed=21, competition_strength=comp, **_MP_KW)
     for g in range(3):
         full.generation(g)
     r1, r2 = orc.sample_pairs(21, _MP_KW["pop_size"], 900)
@@ -262,3 +264,28 @@ def test_native_rccl_exchange_provider(pa, orc):
     for a, b in zip(*mats):
         assert np.array_equal(a, b)
     x.close()
+
+
+@pytest.mark.parametrize("kw,n_shards", [
+    (dict(pop_size=300, core_size=900, pan_genes=700, core_genes=100, HR_rate=0.2, HGT_rate=0.6, competition_strength=4.0), 3),
+    (dict(pop_size=1300, core_size=500, pan_genes=3000, core_genes=1000, HGT_rate=0.3, competition_strength=9.0), 4),
+])
+def test_multi_competition_average_distance_sharded_by_rows(pa, orc, kw, n_shards):
+    # --competition_strength > 0 in a sharded run: D-avg (population.rs:753-784) is sharded by rows like the HGT donors
+    # -- shard k folds the rows of its individuals on the matrix cores, the OR exchange of the N doubles is the
+    # all-gather -- and the parents every shard draws from it equal the unsharded oracle run's
+    from orc_sim import OracleSim
+    ref = OracleSim(seed=3, **kw)
+    multi = pa.MultiSimulation(pa.make_params(seed=3, n_gen=3, max_distances=100, **kw), n_shards, devices=[0] * n_shards)
+    for g in range(3):
+        multi.run(1)
+        multi.sync()
+        ref.generation(g)
+        for s in multi.shards:
+            assert np.array_equal(s.last_parents(), ref.last_idx), "parents differ at generation %d" % g
+    assert np.array_equal(np.concatenate([s.core_genome.read_matrix() for s in multi.shards], axis=1), ref.core)
+    for s in multi.shards:
+        assert np.array_equal(s.pan_genome.read_matrix(), ref.acc)
+    # two exchanges per generation and shard: the average distances, then the HGT deltas
+    assert [s.exchange_stats()[0] for s in multi.shards] == [6] * n_shards
+    multi.close()
