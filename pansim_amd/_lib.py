@@ -142,7 +142,11 @@ _lib = None
 
 
 def load():
-    """Load libpansim_hip.so; raises if it has not been built (no fallback)."""
+    """Load libpansim_hip.so; raises if it has not been built (no fallback).
+
+    A process that also uses torch (pansim_amd.distributed, bench.py) must `import torch` BEFORE this call: torch wheels
+    bundle their own HIP / HSA / RCCL libraries under the same sonames, and only when they are loaded first does the
+    process end up with a single HIP runtime (tests/conftest.py has the details)."""
     global _lib
     if _lib is not None:
         return _lib

@@ -194,6 +194,11 @@ struct ps_population {
     acc_dims d{};
     uint64_t *G[2] = { nullptr, nullptr };   // gene-major view (G[0] only): rebuilt from the rows when g_valid is false
     bool g_valid = false;
+    // ps_sim, neutral selection: where the reduce pass of a binned HGT leaves the rows' gene counts (host-mapped), and
+    // whether they describe the matrix as it is now (any other edit of the matrix clears the flag)
+    int32_t *fuse_counts_out = nullptr;
+    double *fuse_logw_out = nullptr;
+    bool counts_fresh = false;
     uint64_t *I[2] = { nullptr, nullptr };
     uint32_t *d_ptab[PS_MAX_COMP] = {};  // Poisson threshold tables of the HGT event counts (ps_set_rates)
     uint32_t ptab_kmin[PS_MAX_COMP] = {}, ptab_len[PS_MAX_COMP] = {};
@@ -532,6 +537,7 @@ extern "C" int ps_load_matrix(ps_population *p, const uint8_t *rows)
         acc_pack_rows_kernel<<<(uint32_t)((nI + 255) / 256), 256, 0, p->stream>>>(d_rows, p->I[p->cur],
                                                                               p->d);
         p->g_valid = false;
+        p->counts_fresh = false;
     }
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(p->stream));
@@ -928,6 +934,7 @@ static int launch_acc_step(ps_population *p, const uint32_t *d_idx, uint32_t gen
     HIPCHK(hipGetLastError());
     p->cur = 1 - p->cur;
     p->g_valid = false;
+    p->counts_fresh = false;
     return PS_OK;
 }
 
@@ -970,9 +977,14 @@ static bool hgt_takes_binned_form(const ps_population *p)
            && list_lds + parts * 4u + 64u <= p->lds_limit;
 }
 
-static int launch_acc_hgt(ps_population *p, uint32_t gen, hipStream_t st, hipEvent_t wait_before_apply = nullptr)
+// wait_before_apply / record_after_apply: the turn-taking of a heavy HGT with the core sweep (ps_sim) -- the LDS-image pass
+// waits for the previous sweep, and the next sweep waits for it: not for the reduce pass behind it, a small streaming
+// kernel that fits beside a sweep (nor, in a donor-sharded run, for the exchange and the merge that follow)
+static int launch_acc_hgt(ps_population *p, uint32_t gen, hipStream_t st, hipEvent_t wait_before_apply = nullptr,
+                          hipEvent_t record_after_apply = nullptr)
 {
     if (p->d.G == 0 || p->d.N < 2) return PS_OK;
+    bool counts_left = false;
     acc_hgt_args a{};
     a.n_comp = (uint32_t)p->aplan.n_comp;
     double expected = 0.0;
@@ -1089,6 +1101,20 @@ static int launch_acc_hgt(ps_population *p, uint32_t gen, hipStream_t st, hipEve
         if (lds > 64 * 1024)
             HIPCHK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(kern, dim3(parts * n_slices), dim3(1024), lds, st, a, donor_blocks, n_slices);
+        // (a donor-sharded run keeps the sweep behind the exchange and the merge as well: the copies / collective kernels of
+        // an exchange do not fit beside the sweep's 7 workgroups per CU -- they would wait for its END, and with them the
+        // whole chain of the next generation: measured with the emulated exchange, 0.9 -> 1.6 ms exposed per generation)
+        if (record_after_apply && !sharded) {
+            HIPCHK(hipEventRecord(record_after_apply, st));
+            record_after_apply = nullptr;
+        }
+        if (!sharded && p->fuse_counts_out) {
+            // (ps_sim, neutral selection: the reduce pass also leaves the gene counts the next generation's host half reads)
+            acc_hgt_reduce_rows_kernel<<<(uint32_t)((p->d.N + 3) / 4), 256, 0, st>>>((const uint64_t *)p->hgt_scratch, p->I[p->cur], p->d,
+                                                                                    n_slices, (unsigned long long *)p->hgt_ovf_img,
+                                                                                    p->fuse_counts_out, p->fuse_logw_out);
+            counts_left = true;
+        } else
         acc_hgt_reduce_kernel<<<(uint32_t)((words + 255) / 256), 256, 0, st>>>((const uint64_t *)p->hgt_scratch,
                                                                               sharded ? p->d_delta : p->I[p->cur], words, n_slices,
                                                                               sharded ? 1 : 0, (unsigned long long *)p->hgt_ovf_img);
@@ -1142,7 +1168,9 @@ static int launch_acc_hgt(ps_population *p, uint32_t gen, hipStream_t st, hipEve
         acc_or_kernel<<<(uint32_t)((mat_words + 255) / 256), 256, 0, st>>>(p->I[p->cur], p->d_delta, mat_words);
         HIPCHK(hipGetLastError());
     }
+    if (record_after_apply) HIPCHK(hipEventRecord(record_after_apply, st));      // (light form under a forced turn-taking schedule; sharded runs)
     p->g_valid = false;       // only the individual-major view is edited (ensure_gene_major)
+    p->counts_fresh = counts_left;
     return PS_OK;
 }
 
@@ -1492,7 +1520,7 @@ static int average_distance_device(ps_population *p, double *d_out, hipStream_t 
     const bool whole = i_lo == 0 && i_cnt == N;
     const bool mfma = p->d.G > 0 && N >= 2 && (p->davg_form == 2 || !whole || (p->davg_form == 0 && N >= 4096));
     if (mfma) {
-        const uint32_t WP = (2u * p->d.GW + 7u) & ~7u, Npad = (uint32_t)((N + 127) & ~127ull);
+        const uint32_t WP = (2u * p->d.GW + 7u) & ~7u, Npad = (uint32_t)((N + 255) & ~255ull);       // (the kernel's 128-row steps come in pairs)
         const uint64_t need = (uint64_t)Npad * WP * 4 + (uint64_t)Npad * 4 + 64;
         if (p->davg_cap < need) {
             if (p->d_davg) HIPCHK(hipFree(p->d_davg));
@@ -2669,6 +2697,12 @@ static int sim_create_impl(const ps_sim_params *p, ps_sim *s)
         HIPCHK(hipMalloc(&s->d_log1p, G * sizeof(double)));
         HIPCHK(hipMemcpy(s->d_log1p, l1p.data(), G * sizeof(double), hipMemcpyHostToDevice));
     }
+    // neutral selection: the reduce pass of a binned HGT leaves the gene counts the next generation's host half reads
+    // (PANSIM_FUSE_COUNTS=0: the separate kernel, for A/B runs)
+    if (G && !s->need_logw && !(getenv("PANSIM_FUSE_COUNTS") && atoi(getenv("PANSIM_FUSE_COUNTS")) == 0)) {
+        s->acc->fuse_counts_out = s->m_num_genes;
+        s->acc->fuse_logw_out = s->m_logw;
+    }
     return PS_OK;
 }
 
@@ -2731,7 +2765,7 @@ static int sim_host_weights(ps_sim *s, uint32_t gen, double *w, bool avg_ready =
     if (s->need_logw)
         acc_fitness_kernel<<<(uint32_t)((N + 255) / 256), 256, 0, sa>>>(acc->I[acc->cur], s->d_log1p, 1,
                                                                      s->m_num_genes, s->m_logw, acc->d);
-    else
+    else if (!acc->counts_fresh)         // (else: left by the reduce pass of the previous generation's HGT)
         acc_gene_count_rows_kernel<<<(uint32_t)((N + 3) / 4), 256, 0, sa>>>(acc->I[acc->cur], s->m_num_genes,
                                                                          s->m_logw, acc->d);
     HIPCHK(hipGetLastError());
@@ -2820,8 +2854,8 @@ static int sim_one_generation(ps_sim *s, uint32_t gen)
         const int prev = (slot + PS_RING - 1) % PS_RING;
         // only the LDS-image passes (apply, reduce) wait for the previous sweep: the bin pass -- LDS-local
         // gathers, streaming appends -- runs beside its tail (cfg3: 1359 -> 1411 generations/s)
-        PSCHK(launch_acc_hgt(acc, gen, sa, s->slot_used[prev] ? s->ev_core[prev] : nullptr));
-        HIPCHK(hipEventRecord(s->ev_hgt, sa));
+        HIPCHK(hipEventRecord(s->ev_hgt, sa));       // (recorded again after the LDS-image pass; this one covers an HGT that launches nothing)
+        PSCHK(launch_acc_hgt(acc, gen, sa, s->slot_used[prev] ? s->ev_core[prev] : nullptr, s->ev_hgt));
         HIPCHK(hipStreamWaitEvent(sc, s->ev_hgt, 0));
     }
 

@@ -235,6 +235,7 @@ def test_native_rccl_exchange_provider(pa, orc):
     import torch
     from pansim_amd.distributed import RcclExchange
     assert pa.load().ps_rccl_available() == 1
+    torch.cuda.set_device(0)
     x = RcclExchange(0, 1, 0)
     rng = np.random.default_rng(3)
     st = torch.cuda.Stream()
