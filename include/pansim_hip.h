@@ -194,7 +194,7 @@ int ps_sync(ps_population *p);
  * 6 = all pairs on the i8 matrix cores; one-hot matrices go to the matrix cores in modes 0 and 2 (FP4 form) and 6 (i8 form)), "pair_ranges" (site ranges of the tiled
  * sampled-pair kernels, 0 = choose; the 16-bit counter cap still applies),
  * "davg_form" (average_distance: 0 = choose, 1 = LDS-tile popcount kernels, 2 = intersections on the matrix cores -- the default
- * from pop_size 4096 and for row shards), "davg_nb" (matrix-core form: 32-individual fragments per wave, 0 = choose, 1 or 2),
+ * above pop_size 8192 and for row shards), "davg_nb" (matrix-core form: 32-individual fragments per wave, 0 = choose, 1 or 2),
  * "hgt_mode" (accessory recombination: 0 = choose, 1 = one atomic per event, 2 = two passes: bin
  * by recipient partition, OR in LDS images), "hgt_slices" (binned HGT: event slices, 0 = choose), "hgt_list_in_global" (0/1: donor gene lists in
  * global scratch instead of LDS; "hgt_bin_list_in_global": the same for the bin pass of the binned form),

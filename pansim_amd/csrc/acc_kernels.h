@@ -939,51 +939,8 @@ __device__ __forceinline__ double ps_da_half_bcast(double s, bool upper)
     return upper ? __hiloint2double((int)r1[1], (int)r0[1]) : __hiloint2double((int)r1[0], (int)r0[0]);
 }
 
-// one row (q = 0 .. 3) of epilogue group e = (a, g) of a finished 128-row step: the distances of the lane's column
-// individuals to row j = jp0 + 32 a + 8 g + 4 h + q, and after the fourth row the ordered fold of the group (see above).
-// e and q are compile-time after unrolling.  jp0 = Npad marks the empty step before the first one (every j >= N: adds 0.0).
 template <uint32_t NB>
-__device__ __forceinline__ void ps_da_epilogue_row(const ps_da_v16f (&prev)[4][NB], uint32_t jp0, uint32_t e, uint32_t q, const uint32_t *rowcnt,
-                                                   uint32_t Npad, uint32_t N, uint32_t i_base, uint32_t r, uint32_t h, const uint32_t (&ci)[NB],
-                                                   double core_genes, uint4 &cj4, double (&dv)[NB][4], double (&sum)[NB])
-{
-    const uint32_t a = e >> 2, g = e & 3u;
-    const uint32_t jr = jp0 + 32u * a + 8u * g + 4u * h;        // this lane's four rows of the group: jr .. jr + 3
-    if (q == 0u) cj4 = *(const uint4 *)(rowcnt + min(jr, Npad - 4u));
-    const uint32_t cj = q == 0u ? cj4.x : q == 1u ? cj4.y : q == 2u ? cj4.z : cj4.w;
-#pragma unroll
-    for (uint32_t b = 0; b < NB; b++) {
-        const uint32_t i = i_base + 32u * b + r, j = jr + q;
-        const uint32_t in = (uint32_t)prev[a][b][4u * g + q];
-        const uint32_t un = ci[b] + cj - in;
-        const double pd = 1.0 - (((double)in + 0.0 + core_genes) / ((double)un + 0.0 + core_genes));
-        dv[b][q] = (j == i || j >= N) ? 0.0 : pd;                // the j == i term is skipped (:126-128); + 0.0 leaves a sum >= 0 as it is
-    }
-    if (q == 3u) {
-        // rows 8 g .. 8 g + 3 sit in the lower half of the wave, 8 g + 4 .. 8 g + 7 in the upper; the live sum of column i is in
-        // lane i when the group starts.  Every lane adds its four rows (the upper half on a stale copy), the lower half's sums
-        // go to both halves -- the live one is now in lane i + 32 as well, which has not added its rows to IT yet -- every
-        // lane adds its four rows again (now the lower half works on a stale copy), and the upper half's sums go to both.
-#pragma unroll
-        for (uint32_t b = 0; b < NB; b++) {
-            double s = sum[b];
-#pragma unroll
-            for (uint32_t k = 0; k < 4u; k++) s = s + dv[b][k];
-            s = ps_da_half_bcast(s, false);
-#pragma unroll
-            for (uint32_t k = 0; k < 4u; k++) s = s + dv[b][k];
-            s = ps_da_half_bcast(s, true);
-            sum[b] = s;
-        }
-    }
-}
-
-// Software pipeline over the 128-row steps (round 4, second form): the sixteen epilogue groups of step s - 1 -- 32 NB f64
-// divisions and the fold each -- are spread over the first sixteen chunks of step s, one row per K-step behind that
-// K-step's MFMAs, so that the VALU works while the matrix pipe does (two accumulator sets in AGPRs, one wave per SIMD);
-// the table reads of K-step t + 1 are issued before the MFMAs of step t (ping-pong operand sets).
-template <uint32_t NB>
-__global__ void __launch_bounds__(256) acc_average_distance_mfma_kernel(const uint32_t *rowsP, uint32_t WP, const uint32_t *rowcnt,
+__global__ void __launch_bounds__(256, 2) acc_average_distance_mfma_kernel(const uint32_t *rowsP, uint32_t WP, const uint32_t *rowcnt,
                                                                         uint32_t N, uint32_t Npad, uint32_t i_lo, uint32_t i_cnt,
                                                                         double core_genes, double *out)
 {
@@ -1013,36 +970,11 @@ __global__ void __launch_bounds__(256) acc_average_distance_mfma_kernel(const ui
     }
     const uint32_t nch = WP / 8u;
     const int one = 0x7f7f7f7f;          // E8M0 block scale 2^0 in every byte
-    ps_da_v16f accA[4][NB], accB[4][NB];
+    for (uint32_t j0 = 0; j0 < Npad; j0 += 128u) {
+        const uint32_t *srcA[4];
 #pragma unroll
-    for (uint32_t a = 0; a < 4u; a++)
-#pragma unroll
-        for (uint32_t b = 0; b < NB; b++)
-#pragma unroll
-            for (int v = 0; v < 16; v++) accB[a][b][v] = 0.0f;
-    uint4 cj4 = make_uint4(0, 0, 0, 0);
-    double dv[NB][4];
-#pragma unroll
-    for (uint32_t b = 0; b < NB; b++)
-#pragma unroll
-        for (uint32_t k = 0; k < 4u; k++) dv[b][k] = 0.0;
-
-    // the four FP4 operand dwords of fragment word `raw` (32 gene bits)
-    auto fetch = [&](uint32_t raw, uint32_t (&op)[4]) __attribute__((always_inline)) {
-        op[0] = ps_da_lut(raw, colofs, 0u);
-        op[1] = ps_da_lut(raw, colofs, 1u);
-        op[2] = ps_da_lut(raw, colofs, 2u);
-        op[3] = ps_da_lut(raw, colofs, 3u);
-    };
-    auto word = [](const uint4 &w, uint32_t t) __attribute__((always_inline)) -> uint32_t { return t == 0u ? w.x : t == 1u ? w.y : t == 2u ? w.z : w.w; };
-
-    // one step: the contraction of rows j0 .. j0 + 127 into acc, the epilogue of the previous step (prev, rows from jp0) beside it
-    auto jstep = [&](ps_da_v16f (&acc)[4][NB], const ps_da_v16f (&prev)[4][NB], uint32_t j0, uint32_t jp0) __attribute__((always_inline)) {
-        const uint32_t *src[4 + NB];
-#pragma unroll
-        for (uint32_t f = 0; f < 4u; f++) src[f] = rowsP + (size_t)(j0 + 32u * f + r) * WP + h * 4u;
-#pragma unroll
-        for (uint32_t b = 0; b < NB; b++) src[4 + b] = srcB[b];
+        for (uint32_t a = 0; a < 4u; a++) srcA[a] = rowsP + (size_t)(j0 + 32u * a + r) * WP + h * 4u;
+        ps_da_v16f acc[4][NB];
 #pragma unroll
         for (uint32_t a = 0; a < 4u; a++)
 #pragma unroll
@@ -1050,64 +982,68 @@ __global__ void __launch_bounds__(256) acc_average_distance_mfma_kernel(const ui
 #pragma unroll
                 for (int v = 0; v < 16; v++) acc[a][b][v] = 0.0f;
         uint4 cur[4 + NB], nxt[4 + NB];
-        uint32_t opA[4 + NB][4], opB[4 + NB][4];
 #pragma unroll
-        for (uint32_t f = 0; f < 4u + NB; f++) cur[f] = *(const uint4 *)src[f];
-#pragma unroll
-        for (uint32_t f = 0; f < 4u + NB; f++) fetch(cur[f].x, opA[f]);
-        // K-steps of chunk c (cur holds it, opA / opB the operands of its first K-step by the parity carried over the chunks);
-        // `e` < 16: epilogue group e of the previous step rides behind the MFMAs, one row per K-step
-        auto chunk = [&](uint32_t c, uint32_t e) __attribute__((always_inline)) {
+        for (uint32_t f = 0; f < 4u + NB; f++) cur[f] = *(const uint4 *)((f < 4u ? srcA[f] : srcB[f - 4u]));
+        for (uint32_t c = 0; c < nch; c++) {
             const uint32_t cn = min(c + 1u, nch - 1u);
 #pragma unroll
-            for (uint32_t f = 0; f < 4u + NB; f++) nxt[f] = *(const uint4 *)(src[f] + (size_t)cn * 8u);
+            for (uint32_t f = 0; f < 4u + NB; f++) nxt[f] = *(const uint4 *)((f < 4u ? srcA[f] : srcB[f - 4u]) + (size_t)cn * 8u);
 #pragma unroll
             for (uint32_t t = 0; t < 4u; t++) {
-                // the table reads of the next K-step first (dword t + 1 of this chunk, or dword 0 of the next one)
+                ps_da_v8i op[4 + NB];
 #pragma unroll
                 for (uint32_t f = 0; f < 4u + NB; f++) {
-                    const uint32_t raw = (t == 3u) ? nxt[f].x : word(cur[f], t + 1u);
-                    if (t & 1u) fetch(raw, opA[f]);
-                    else fetch(raw, opB[f]);
+                    const uint32_t raw = t == 0u ? cur[f].x : t == 1u ? cur[f].y : t == 2u ? cur[f].z : cur[f].w;
+                    op[f] = ps_da_v8i{ (int)ps_da_lut(raw, colofs, 0u), (int)ps_da_lut(raw, colofs, 1u), (int)ps_da_lut(raw, colofs, 2u),
+                                       (int)ps_da_lut(raw, colofs, 3u), 0, 0, 0, 0 };
                 }
-                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (uint32_t a = 0; a < 4u; a++)
 #pragma unroll
-                    for (uint32_t b = 0; b < NB; b++) {
-                        const uint32_t *xa = (t & 1u) ? opB[a] : opA[a], *xb = (t & 1u) ? opB[4u + b] : opA[4u + b];
-                        const ps_da_v8i va = { (int)xa[0], (int)xa[1], (int)xa[2], (int)xa[3], 0, 0, 0, 0 };
-                        const ps_da_v8i vb = { (int)xb[0], (int)xb[1], (int)xb[2], (int)xb[3], 0, 0, 0, 0 };
-                        acc[a][b] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(va, vb, acc[a][b], 4, 4, 0, one, 0, one);
-                    }
-                if (e < 16u) ps_da_epilogue_row<NB>(prev, jp0, e, t, rowcnt, Npad, N, i_base, r, h, ci, core_genes, cj4, dv, sum);
-                __builtin_amdgcn_sched_barrier(0);
+                    for (uint32_t b = 0; b < NB; b++)
+                        acc[a][b] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(op[a], op[4u + b], acc[a][b], 4, 4, 0, one, 0, one);
             }
 #pragma unroll
             for (uint32_t f = 0; f < 4u + NB; f++) cur[f] = nxt[f];
-        };
+        }
+        // distances and the ordered fold.  Block (a, b): column i = i_base + 32 b + r, rows j0 + 32 a + (v & 3) + 8 (v >> 2) + 4 h
 #pragma unroll
-        for (uint32_t cc = 0; cc < 16u; cc++) {
-            if (cc < nch) chunk(cc, cc);
-            else {
-                // fewer than sixteen chunks (G < 3841): the rest of the previous step's epilogue without MFMAs beside it
+        for (uint32_t a = 0; a < 4u; a++) {
 #pragma unroll
-                for (uint32_t t = 0; t < 4u; t++)
-                    ps_da_epilogue_row<NB>(prev, jp0, cc, t, rowcnt, Npad, N, i_base, r, h, ci, core_genes, cj4, dv, sum);
+            for (uint32_t g = 0; g < 4u; g++) {
+                const uint32_t jr = j0 + 32u * a + 8u * g + 4u * h;        // this lane's four rows of group g: jr .. jr + 3
+                const uint4 cj4 = *(const uint4 *)(rowcnt + jr);
+                const uint32_t cjv[4] = { cj4.x, cj4.y, cj4.z, cj4.w };
+                double dv[NB][4];
+#pragma unroll
+                for (uint32_t b = 0; b < NB; b++) {
+                    const uint32_t i = i_base + 32u * b + r;
+#pragma unroll
+                    for (uint32_t q = 0; q < 4u; q++) {
+                        const uint32_t in = (uint32_t)acc[a][b][4 * g + q], j = jr + q;
+                        const uint32_t un = ci[b] + cjv[q] - in;
+                        const double pd = 1.0 - (((double)in + 0.0 + core_genes) / ((double)un + 0.0 + core_genes));
+                        dv[b][q] = (j == i || j >= N) ? 0.0 : pd;         // the j == i term is skipped (:126-128); + 0.0 leaves a sum >= 0 as it is
+                    }
+                }
+                // rows 8 g .. 8 g + 3 sit in the lower half of the wave, 8 g + 4 .. 8 g + 7 in the upper; the live sum of column i
+                // is in lane i when the group starts.  Every lane adds its four rows (the upper half on a stale copy), the
+                // sums swap halves -- the live one is now in lane i + 32, which has not added its rows to IT yet -- every
+                // lane adds its four rows again (now the lower half works on the stale copy), and the sums swap back.
+#pragma unroll
+                for (uint32_t b = 0; b < NB; b++) {
+                    double s = sum[b];
+#pragma unroll
+                    for (uint32_t q = 0; q < 4u; q++) s = s + dv[b][q];
+                    s = ps_da_half_bcast(s, false);        // the lower half's sums, in both halves
+#pragma unroll
+                    for (uint32_t q = 0; q < 4u; q++) s = s + dv[b][q];
+                    s = ps_da_half_bcast(s, true);         // the upper half's sums, in both halves
+                    sum[b] = s;
+                }
             }
         }
-        for (uint32_t c = 16u; c < nch; c++) chunk(c, 16u);
-    };
-    // Npad is a multiple of 256: the steps alternate between the two accumulator sets
-    for (uint32_t j0 = 0; j0 < Npad; j0 += 256u) {
-        jstep(accA, accB, j0, j0 == 0u ? Npad : j0 - 128u);
-        jstep(accB, accA, j0 + 128u, j0);
     }
-#pragma unroll
-    for (uint32_t e = 0; e < 16u; e++)
-#pragma unroll
-        for (uint32_t q = 0; q < 4u; q++)
-            ps_da_epilogue_row<NB>(accB, Npad - 128u, e, q, rowcnt, Npad, N, i_base, r, h, ci, core_genes, cj4, dv, sum);
 #pragma unroll
     for (uint32_t b = 0; b < NB; b++) {
         const uint32_t i = i_base + 32u * b + r;

@@ -1518,9 +1518,9 @@ static int average_distance_device(ps_population *p, double *d_out, hipStream_t 
     // wide populations (and every row shard): intersections on the matrix cores, ordered f64 fold in the accumulator layout
     // (acc_kernels.h); "davg_form": 0 = choose, 1 = LDS-tile popcount kernels, 2 = matrix cores
     const bool whole = i_lo == 0 && i_cnt == N;
-    const bool mfma = p->d.G > 0 && N >= 2 && (p->davg_form == 2 || !whole || (p->davg_form == 0 && N >= 4096));
+    const bool mfma = p->d.G > 0 && N >= 2 && (p->davg_form == 2 || !whole || (p->davg_form == 0 && N > 8192));
     if (mfma) {
-        const uint32_t WP = (2u * p->d.GW + 7u) & ~7u, Npad = (uint32_t)((N + 255) & ~255ull);       // (the kernel's 128-row steps come in pairs)
+        const uint32_t WP = (2u * p->d.GW + 7u) & ~7u, Npad = (uint32_t)((N + 127) & ~127ull);
         const uint64_t need = (uint64_t)Npad * WP * 4 + (uint64_t)Npad * 4 + 64;
         if (p->davg_cap < need) {
             if (p->d_davg) HIPCHK(hipFree(p->d_davg));
@@ -2948,6 +2948,14 @@ static int emulated_exchange(void *ctx, void *d_words, uint64_t n_words, void *h
                           hipMemcpyDeviceToDevice, st));                                                   // "all-gather"
     emu_hold_kernel<<<1, 64, 0, st>>>(ticks);
     HIPCHK(hipGetLastError());
+    if (n_words == s->prm.pop_size && s->prm.competition_strength > 0.0) {
+        // the row-sharded D-avg vector (sim_average_distance): the other shards' slices never arrive, and zeros there would
+        // give 7/8 of the population the weight 0 -- a different simulation (every parent from shard 0's individuals, narrow
+        // windows).  Stand-in values: shard 0's slice repeated, so that the run keeps the dynamics of the unsharded one.
+        const uint64_t own = n_words / (uint64_t)s->emu_shards;
+        for (uint64_t k = 1; own && k * own < n_words; k++)
+            HIPCHK(hipMemcpyAsync((uint64_t *)d_words + k * own, d_words, std::min(own, n_words - k * own) * 8, hipMemcpyDeviceToDevice, st));
+    }
     s->exchange_calls++;
     s->exchange_bytes += 2 * part;
     s->emu_modelled_us += 2.0 * coll_us;

@@ -119,6 +119,26 @@ def run(trials, seed=1, log=print):
                 bad += 1
                 log("SWEEP ERROR", t, N, L, lm, lh, tune, e)
         core.close()
+        # ---- D-avg: LDS-tile popcount kernels against the matrix-core form (either fragment count), whole and in row shards
+        if t % 2 == 0:
+            N = int(rng.choice([2, 3, 31, 64, 65, 200, 1000, 2300]))
+            G = int(rng.choice([1, 8, 63, 64, 65, 300, 1000, 4000, 4200]))
+            cg = int(rng.choice([0, 1, 7, 2000]))
+            a = (rng.random((N, G)) < rng.choice([0.0, 0.05, 0.3, 0.9])).astype(np.uint8)
+            if N > 4 and rng.random() < 0.5:
+                a[1] = a[0]
+            want = o.average_distance(a, False, cg)
+            acc = pa.Population(N, G, 2, False, 0.3, 0, cg)
+            acc.load_matrix(a)
+            acc.set_tuning("davg_form", int(rng.integers(0, 3)))
+            acc.set_tuning("davg_nb", int(rng.integers(0, 3)))
+            got = acc.average_distance()
+            K = int(rng.integers(1, min(N, 5) + 1))
+            rows = np.concatenate([acc.average_distance_rows(N * r // K, N * (r + 1) // K - N * r // K) for r in range(K)])
+            if not (np.array_equal(got, want, equal_nan=True) and np.array_equal(rows, want, equal_nan=True)):
+                bad += 1
+                log("D-AVG MISMATCH", t, N, G, cg, K)
+            acc.close()
         # ---- whole generation loop (every 5th trial): random parameters, 4 generations without host sync
         if t % 5 == 0:
             from orc_sim import OracleSim
