@@ -940,7 +940,7 @@ __device__ __forceinline__ double ps_da_half_bcast(double s, bool upper)
 }
 
 template <uint32_t NB>
-__global__ void __launch_bounds__(256, 2) acc_average_distance_mfma_kernel(const uint32_t *rowsP, uint32_t WP, const uint32_t *rowcnt,
+__global__ void __launch_bounds__(256, NB == 2u ? 2 : 1) acc_average_distance_mfma_kernel(const uint32_t *rowsP, uint32_t WP, const uint32_t *rowcnt,
                                                                         uint32_t N, uint32_t Npad, uint32_t i_lo, uint32_t i_cnt,
                                                                         double core_genes, double *out)
 {
