@@ -258,6 +258,8 @@ struct ps_population {
     bool no_block_preload = false;      // tests: block sweep reads its parent indices per batch
     uint32_t block_batch = 0;           // block sweep: segments per wave batch (0 = 4, falling back to 2; 2 = force 2)
     uint32_t sweep_queue_cap = 0;       // tests: the sweeps treat their candidate queues / HR lists as this short (0 = real size)
+    uint32_t window_blocks_per_cu = 0;  // window sweep: workgroups per CU (0 = PS_WBPC)
+    bool exchange_beside_sweep = false; // donor-sharded HGT: the next sweep waits for the LDS-image pass only (ps_sim sets it)
     int last_sweep_form = 0;            // PS_SWEEP_FORM_* of the last core sweep launch (ps_last_sweep_form)
     int window_sweep = -1;              // window sweep for N > 1024 when the parents are sorted: -1 = choose, 0 = never, 1 = whenever possible
     uint32_t *h_flag = nullptr, *d_flag = nullptr;   // host-mapped sticky device error word
@@ -309,6 +311,7 @@ static int pop_create_impl(const ps_config *cfg, const uint8_t *init_vec, ps_pop
     if (const char *e = getenv("PANSIM_HGT_MODE")) p->hgt_mode = atoi(e);
     if (const char *e = getenv("PANSIM_SWEEP_OOP")) p->sweep_oop = std::max(-1, std::min(2, atoi(e)));
     if (const char *e = getenv("PANSIM_WINDOW_SWEEP")) p->window_sweep = std::max(-1, std::min(1, atoi(e)));
+    if (const char *e = getenv("PANSIM_WINDOW_BPC")) p->window_blocks_per_cu = (uint32_t)std::max(0, std::min(8, atoi(e)));
     if (const char *e = getenv("PANSIM_BLOCK_BATCH")) p->block_batch = (uint32_t)atoi(e);
     if (const char *e = getenv("PANSIM_BLOCK_WAVES")) p->block_waves = (uint32_t)atoi(e);
     if (const char *e = getenv("PANSIM_HGT_SLICES")) p->hgt_slices = (uint32_t)atoi(e);
@@ -450,6 +453,9 @@ extern "C" int ps_set_tuning(ps_population *p, const char *key, int64_t value)
     } else if (k == "sweep_out_of_place") {
         if (value < -1 || value > 2) return ps_fail(PS_ERR_INVALID, "sweep_out_of_place must be -1 (choose), 0 (in place), 1 (out of place) or 2 (out of place, nontemporal loads and stores)");
         p->sweep_oop = (int)value;
+    } else if (k == "window_blocks_per_cu") {
+        if (value < 0 || value > 8) return ps_fail(PS_ERR_INVALID, "window_blocks_per_cu must be 0 (choose) or 1..8");
+        p->window_blocks_per_cu = (uint32_t)value;
     } else if (k == "davg_form") {
         if (value < 0 || value > 2) return ps_fail(PS_ERR_INVALID, "davg_form must be 0 (choose), 1 (LDS-tile popcount kernels) or 2 (matrix cores)");
         p->davg_form = (int)value;
@@ -788,7 +794,8 @@ static int launch_core_sweep_window(ps_population *p, const core_sweep_args &a, 
 {
     constexpr uint32_t ROWS = 3;
     const uint32_t lds = 4u * (ROWS * PS_WSTRIDE + PS_WQCAP * 4u);
-    const uint32_t bpc = std::max(1u, std::min((uint32_t)PS_WBPC, p->lds_limit / lds));
+    // ("window_blocks_per_cu": a donor-sharded run leaves the exchange's kernels room beside the sweep)
+    const uint32_t bpc = std::max(1u, std::min(p->window_blocks_per_cu ? p->window_blocks_per_cu : (uint32_t)PS_WBPC, p->lds_limit / lds));
     const uint32_t segs = (a.N + 1023u) / 1024u;
     // at least one wave per (XCD group, segment); a multiple of the 8 groups
     const uint32_t grid = (std::max(8u * ((segs + 3u) / 4u), 256u * bpc) + 7u) & ~7u;
@@ -1104,7 +1111,7 @@ static int launch_acc_hgt(ps_population *p, uint32_t gen, hipStream_t st, hipEve
         // (a donor-sharded run keeps the sweep behind the exchange and the merge as well: the copies / collective kernels of
         // an exchange do not fit beside the sweep's 7 workgroups per CU -- they would wait for its END, and with them the
         // whole chain of the next generation: measured with the emulated exchange, 0.9 -> 1.6 ms exposed per generation)
-        if (record_after_apply && !sharded) {
+        if (record_after_apply && (!sharded || p->exchange_beside_sweep)) {
             HIPCHK(hipEventRecord(record_after_apply, st));
             record_after_apply = nullptr;
         }
@@ -2897,11 +2904,24 @@ static int sim_one_generation(ps_sim *s, uint32_t gen)
     return PS_OK;
 }
 
+// PANSIM_EXCHANGE_BESIDE_SWEEP=1 (experiment): a donor-sharded run lets sweep(g) start behind the LDS-image pass of HGT(g)
+// like an unsharded one, with the reduce pass, the exchange and the merge BESIDE it -- for which the window sweep leaves a
+// workgroup's worth of wave slots, registers and LDS per CU free (6 workgroups per CU instead of 7)
+static void sim_exchange_schedule(ps_sim *s)
+{
+    const char *e = getenv("PANSIM_EXCHANGE_BESIDE_SWEEP");
+    const bool on = e && atoi(e) != 0 && s->acc->exchange != nullptr;
+    s->acc->exchange_beside_sweep = on;
+    if (on && s->core->window_blocks_per_cu == 0) s->core->window_blocks_per_cu = 6;
+}
+
 extern "C" int ps_sim_set_exchange(ps_sim *s, ps_exchange_fn fn, void *ctx)
 {
     if (!s) return ps_fail(PS_ERR_INVALID, "null handle");
     if (s->prm.shard_count < 2) return ps_fail(PS_ERR_INVALID, "the HGT donors are sharded over the site shards of a run: shard_count must be >= 2");
-    return ps_set_donor_shard(s->acc, (uint32_t)s->prm.shard_rank, (uint32_t)s->prm.shard_count, fn, ctx);
+    PSCHK(ps_set_donor_shard(s->acc, (uint32_t)s->prm.shard_rank, (uint32_t)s->prm.shard_count, fn, ctx));
+    sim_exchange_schedule(s);
+    return PS_OK;
 }
 
 // bench.py --emulate-shard K: this process plays shard 0 of K.  Its HGT serves donors [0, N / K) and the exchange is
@@ -2967,7 +2987,9 @@ extern "C" int ps_sim_emulate_exchange(ps_sim *s, int n_shards)
     if (!s) return ps_fail(PS_ERR_INVALID, "null handle");
     if (n_shards < 2) return ps_fail(PS_ERR_INVALID, "n_shards must be >= 2");
     s->emu_shards = n_shards;
-    return ps_set_donor_shard(s->acc, 0u, (uint32_t)n_shards, emulated_exchange, s);
+    PSCHK(ps_set_donor_shard(s->acc, 0u, (uint32_t)n_shards, emulated_exchange, s));
+    sim_exchange_schedule(s);
+    return PS_OK;
 }
 
 extern "C" int ps_sim_exchange_stats(ps_sim *s, int reset, uint64_t *calls, uint64_t *bytes)
