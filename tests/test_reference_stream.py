@@ -123,6 +123,24 @@ def test_chacha_block_rfc7539_vector(pa):
     assert out.tolist() == chacha_block(key.tolist(), 5, 0, 12)
 
 
+def test_chacha12_and_chacha8_published_zero_key_vectors(pa):
+    # draft-strombergson-chacha-test-vectors-01, TC1 (256-bit key of zeros, IV of zeros, block 0): the published keystreams of
+    # the 12-round core -- the one behind rand 0.8's StdRng -- and of the 8- and 20-round ones.  An EXTERNAL vector for the
+    # round count the library actually uses (RFC 7539 only pins 20 rounds); it pins the block function,
+    # not rand's buffering / seed expansion, which stay unpinned.
+    import struct
+    lib = pa.load()
+    key = np.zeros(8, np.uint32)
+    out = np.zeros(16, np.uint32)
+    want = {8: "3e00ef2f895f40d67f5bb8e81f09a5a12c840ec3ce9a7f3b181be188ef711a1e",
+            12: "9bf49a6a0755f953811fce125f2683d50429c3bb49e074147e0089a52eae155f",
+            20: "76b8e0ada0f13d90405d6ae55386bd28bdd219b8a08ded1aa836efcc8b770dc7"}
+    for rounds, hexstr in want.items():
+        lib.ps_chacha_block(key, 0, 0, rounds, out)
+        assert struct.pack("<16I", *out.tolist()).hex()[:64] == hexstr
+        assert struct.pack("<16I", *chacha_block([0] * 8, 0, 0, rounds)).hex()[:64] == hexstr
+
+
 def test_reference_selection_stream_matches_the_python_restatement(pa):
     lib = pa.load()
     for seed, G, pp, pl, nl in [(0, 4000, 0.3, 10.0, 10.0), (12345678901234567, 700, 0.0, 2.0, 0.7), (7, 300, 1.0, 50.0, 10.0),
