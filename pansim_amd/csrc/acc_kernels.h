@@ -939,10 +939,10 @@ __device__ __forceinline__ double ps_da_half_bcast(double s, bool upper)
     return upper ? __hiloint2double((int)r1[1], (int)r0[1]) : __hiloint2double((int)r1[0], (int)r0[0]);
 }
 
-template <uint32_t NB>
+template <uint32_t NB, bool FAST>
 __global__ void __launch_bounds__(256, NB == 2u ? 2 : 1) acc_average_distance_mfma_kernel(const uint32_t *rowsP, uint32_t WP, const uint32_t *rowcnt,
                                                                         uint32_t N, uint32_t Npad, uint32_t i_lo, uint32_t i_cnt,
-                                                                        double core_genes, double *out)
+                                                                        double core_genes, uint32_t cg_int, double *out)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t lut[];      // 256 entries x 64 copies x 4 bytes, at LDS offset 0
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1006,7 +1006,18 @@ __global__ void __launch_bounds__(256, NB == 2u ? 2 : 1) acc_average_distance_mf
 #pragma unroll
             for (uint32_t f = 0; f < 4u + NB; f++) cur[f] = nxt[f];
         }
-        // distances and the ordered fold.  Block (a, b): column i = i_base + 32 b + r, rows j0 + 32 a + (v & 3) + 8 (v >> 2) + 4 h
+        // distances and the ordered fold.  Block (a, b): column i = i_base + 32 b + r, rows j0 + 32 a + (v & 3) + 8 (v >> 2) + 4 h.
+        // The epilogue is VALU work -- PMC: 30 instructions per distance in the plain form, more wave-cycles than the
+        // contraction itself -- so it is written lean, without changing a bit of any distance:
+        //   * (double)n + 0.0 + core_genes == (double)(n + core_genes) for integers below 2^32 (x + 0.0 == x for x >= 0; the sum
+        //     of two integers below 2^53 is exact): one integer add + one conversion instead of a conversion + two f64 adds;
+        //   * the quotient by the arithmetic core of the compiler's own f64 division -- v_rcp_f64, two Newton steps, the
+        //     product, its residual, one correction: the very fmas of the IEEE sequence -- without v_div_scale / v_div_fmas /
+        //     v_div_fixup, which only act on operands near the ends of the exponent range, zeros, infinities (here: integers in
+        //     [0, 2^32), and 0 / 0 still gives NaN through rcp(0) = inf, 0 * inf);
+        //   * the j == i / j >= N selects only in the steps that can contain such a j (wave-uniform).
+        const bool need_mask = (j0 + 128u > N) || (j0 < i_base + 32u * NB && j0 + 128u > i_base);
+        auto epilogue = [&](const bool masked) __attribute__((always_inline)) {
 #pragma unroll
         for (uint32_t a = 0; a < 4u; a++) {
 #pragma unroll
@@ -1022,8 +1033,21 @@ __global__ void __launch_bounds__(256, NB == 2u ? 2 : 1) acc_average_distance_mf
                     for (uint32_t q = 0; q < 4u; q++) {
                         const uint32_t in = (uint32_t)acc[a][b][4 * g + q], j = jr + q;
                         const uint32_t un = ci[b] + cjv[q] - in;
-                        const double pd = 1.0 - (((double)in + 0.0 + core_genes) / ((double)un + 0.0 + core_genes));
-                        dv[b][q] = (j == i || j >= N) ? 0.0 : pd;         // the j == i term is skipped (:126-128); + 0.0 leaves a sum >= 0 as it is
+                        double pd;
+                        if (FAST) {
+                            const double num = (double)(in + cg_int), den = (double)(un + cg_int);
+                            double rc = __builtin_amdgcn_rcp(den);
+                            double er = __builtin_fma(-den, rc, 1.0);
+                            rc = __builtin_fma(rc, er, rc);
+                            er = __builtin_fma(-den, rc, 1.0);
+                            rc = __builtin_fma(rc, er, rc);
+                            const double q0 = num * rc;
+                            const double rem = __builtin_fma(-den, q0, num);
+                            pd = 1.0 - __builtin_fma(rem, rc, q0);
+                        } else {
+                            pd = 1.0 - (((double)in + 0.0 + core_genes) / ((double)un + 0.0 + core_genes));
+                        }
+                        dv[b][q] = (masked && (j == i || j >= N)) ? 0.0 : pd;     // the j == i term is skipped (:126-128); + 0.0 leaves a sum >= 0 as it is
                     }
                 }
                 // rows 8 g .. 8 g + 3 sit in the lower half of the wave, 8 g + 4 .. 8 g + 7 in the upper; the live sum of column i
@@ -1043,6 +1067,9 @@ __global__ void __launch_bounds__(256, NB == 2u ? 2 : 1) acc_average_distance_mf
                 }
             }
         }
+        };
+        if (need_mask) epilogue(true);
+        else epilogue(false);
     }
 #pragma unroll
     for (uint32_t b = 0; b < NB; b++) {

@@ -238,6 +238,7 @@ struct ps_population {
     uint64_t davg_cap = 0;
     int davg_form = 0;               // 0 = choose, 1 = LDS-tile popcount kernels, 2 = matrix cores
     uint32_t davg_nb = 0;            // matrix-core D-avg: B fragments per wave (0 = choose, 1 or 2)
+    bool davg_plain_division = false; // matrix-core D-avg: the compiler's f64 division in the epilogue ("davg_plain_division": A/B, tests)
     uint64_t H_cap = 0;
     int pair_mode = 0;               // 0 auto, 1 sampled kernel, 2 all-pairs kernel (tuning/tests)
     int last_pair_form = 0;          // kernel form of the last core pair-count call (ps_last_pair_form)
@@ -459,6 +460,8 @@ extern "C" int ps_set_tuning(ps_population *p, const char *key, int64_t value)
     } else if (k == "davg_form") {
         if (value < 0 || value > 2) return ps_fail(PS_ERR_INVALID, "davg_form must be 0 (choose), 1 (LDS-tile popcount kernels) or 2 (matrix cores)");
         p->davg_form = (int)value;
+    } else if (k == "davg_plain_division") {
+        p->davg_plain_division = value != 0;
     } else if (k == "davg_nb") {
         if (value < 0 || value > 2) return ps_fail(PS_ERR_INVALID, "davg_nb must be 0 (choose), 1 or 2");
         p->davg_nb = (uint32_t)value;
@@ -1542,15 +1545,18 @@ static int average_distance_device(ps_population *p, double *d_out, hipStream_t 
         const uint32_t nb = p->davg_nb ? p->davg_nb : (i_cnt >= 64u * 1024u ? 2u : 1u);
         const uint32_t waves = (uint32_t)((i_cnt + 32u * nb - 1) / (32u * nb)), grid = (waves + 3u) / 4u;
         const uint32_t lds = 256u * 64u * 4u;
-        if (nb == 2u) {
-            HIPCHK(hipFuncSetAttribute((const void *)acc_average_distance_mfma_kernel<2u>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            acc_average_distance_mfma_kernel<2u><<<grid, 256, lds, st>>>(rowsP, WP, rowcnt, (uint32_t)N, Npad, (uint32_t)i_lo, (uint32_t)i_cnt,
-                                                                        (double)p->cfg.core_genes, d_out);
-        } else {
-            HIPCHK(hipFuncSetAttribute((const void *)acc_average_distance_mfma_kernel<1u>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            acc_average_distance_mfma_kernel<1u><<<grid, 256, lds, st>>>(rowsP, WP, rowcnt, (uint32_t)N, Npad, (uint32_t)i_lo, (uint32_t)i_cnt,
-                                                                        (double)p->cfg.core_genes, d_out);
+        // (the lean epilogue needs core_genes + the largest union below 2^32: always, short of an absurd --core_genes)
+        const bool fast = p->cfg.core_genes < (1ull << 31) && !p->davg_plain_division;
+        const uint32_t cgi = fast ? (uint32_t)p->cfg.core_genes : 0u;
+#define PS_DAVG_LAUNCH(NB_, FAST_)                                                                                                    \
+        {                                                                                                                             \
+            HIPCHK(hipFuncSetAttribute((const void *)acc_average_distance_mfma_kernel<NB_, FAST_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+            acc_average_distance_mfma_kernel<NB_, FAST_><<<grid, 256, lds, st>>>(rowsP, WP, rowcnt, (uint32_t)N, Npad, (uint32_t)i_lo, (uint32_t)i_cnt, \
+                                                                                (double)p->cfg.core_genes, cgi, d_out);                \
         }
+        if (nb == 2u) { if (fast) PS_DAVG_LAUNCH(2u, true) else PS_DAVG_LAUNCH(2u, false) }
+        else { if (fast) PS_DAVG_LAUNCH(1u, true) else PS_DAVG_LAUNCH(1u, false) }
+#undef PS_DAVG_LAUNCH
     } else if (N <= 8192) {
         if (!p->d_Dt) HIPCHK(hipMalloc(&p->d_Dt, N * N * sizeof(double)));
         const uint32_t nt = (uint32_t)((N + 63) / 64);
