@@ -200,6 +200,8 @@ int ps_sync(ps_population *p);
  * global scratch instead of LDS; "hgt_bin_list_in_global": the same for the bin pass of the binned form),
  * "hgt_events_per_thread" (light HGT kernel inside the generation loop: events a thread handles in sequence -- the launch is that
  * narrow; 0 = whole chip; ps_sim sets it from the estimated sweep time),
+ * "hgt_apply_threads" (binned HGT: threads per workgroup of the LDS-image pass, 256 / 512 / 1024), "window_blocks_per_cu" (window sweep:
+ * workgroups per CU, 0 = choose), "davg_plain_division" (matrix-core D-avg: the compiler's f64 division in the epilogue),
  * "hgt_bin_cap" (tests: the bins of the binned HGT hold at most this many events; the rest take the overflow image),
  * "sweep_queue_cap" (tests: the sweeps treat their candidate queues and HR lists as this short, so that the queue-free
  * redo of a batch / row group -- what a full queue falls back to -- runs; 0 = real size),

@@ -351,7 +351,8 @@ __global__ void __launch_bounds__(1024) acc_hgt_apply_kernel(acc_hgt_args a, uin
     __syncthreads();
     const uint32_t cap = a.bin_cap;
     const uint32_t quarter = threadIdx.x >> 8, qt = threadIdx.x & 255u;
-    for (uint32_t bb = slice + quarter * n_slices; bb < donor_blocks; bb += 4u * n_slices) {
+    const uint32_t nq = blockDim.x >> 8;           // 256-thread quarters of the workgroup (4; 1 or 2 for a workgroup that fits beside a sweep)
+    for (uint32_t bb = slice + quarter * n_slices; bb < donor_blocks; bb += nq * n_slices) {
         const uint32_t n = a.counts[(uint64_t)bb * a.parts + part];
         const uint32_t *src = a.bins + ((uint64_t)bb * a.parts + part) * cap;
         for (uint32_t k = qt; k < n; k += 1024u) {

@@ -259,6 +259,7 @@ struct ps_population {
     bool no_block_preload = false;      // tests: block sweep reads its parent indices per batch
     uint32_t block_batch = 0;           // block sweep: segments per wave batch (0 = 4, falling back to 2; 2 = force 2)
     uint32_t sweep_queue_cap = 0;       // tests: the sweeps treat their candidate queues / HR lists as this short (0 = real size)
+    uint32_t hgt_apply_threads = 1024;  // binned HGT, LDS-image pass: threads per workgroup (256 / 512 / 1024; "hgt_apply_threads")
     uint32_t window_blocks_per_cu = 0;  // window sweep: workgroups per CU (0 = PS_WBPC)
     bool exchange_beside_sweep = false; // donor-sharded HGT: the next sweep waits for the LDS-image pass only (ps_sim sets it)
     int last_sweep_form = 0;            // PS_SWEEP_FORM_* of the last core sweep launch (ps_last_sweep_form)
@@ -312,6 +313,8 @@ static int pop_create_impl(const ps_config *cfg, const uint8_t *init_vec, ps_pop
     if (const char *e = getenv("PANSIM_HGT_MODE")) p->hgt_mode = atoi(e);
     if (const char *e = getenv("PANSIM_SWEEP_OOP")) p->sweep_oop = std::max(-1, std::min(2, atoi(e)));
     if (const char *e = getenv("PANSIM_WINDOW_SWEEP")) p->window_sweep = std::max(-1, std::min(1, atoi(e)));
+    if (const char *e = getenv("PANSIM_ACC_LDS_LIMIT")) { const int v = atoi(e); if (v >= 1024 && v <= 160 * 1024 && !cfg->core) p->lds_limit = (uint32_t)v; }
+    if (const char *e = getenv("PANSIM_HGT_APPLY_THREADS")) { const int v = atoi(e); if (v == 256 || v == 512 || v == 1024) p->hgt_apply_threads = (uint32_t)v; }
     if (const char *e = getenv("PANSIM_WINDOW_BPC")) p->window_blocks_per_cu = (uint32_t)std::max(0, std::min(8, atoi(e)));
     if (const char *e = getenv("PANSIM_BLOCK_BATCH")) p->block_batch = (uint32_t)atoi(e);
     if (const char *e = getenv("PANSIM_BLOCK_WAVES")) p->block_waves = (uint32_t)atoi(e);
@@ -454,6 +457,9 @@ extern "C" int ps_set_tuning(ps_population *p, const char *key, int64_t value)
     } else if (k == "sweep_out_of_place") {
         if (value < -1 || value > 2) return ps_fail(PS_ERR_INVALID, "sweep_out_of_place must be -1 (choose), 0 (in place), 1 (out of place) or 2 (out of place, nontemporal loads and stores)");
         p->sweep_oop = (int)value;
+    } else if (k == "hgt_apply_threads") {
+        if (value != 256 && value != 512 && value != 1024) return ps_fail(PS_ERR_INVALID, "hgt_apply_threads must be 256, 512 or 1024");
+        p->hgt_apply_threads = (uint32_t)value;
     } else if (k == "window_blocks_per_cu") {
         if (value < 0 || value > 8) return ps_fail(PS_ERR_INVALID, "window_blocks_per_cu must be 0 (choose) or 1..8");
         p->window_blocks_per_cu = (uint32_t)value;
@@ -1110,7 +1116,7 @@ static int launch_acc_hgt(ps_population *p, uint32_t gen, hipStream_t st, hipEve
         auto kern = acc_hgt_apply_kernel;
         if (lds > 64 * 1024)
             HIPCHK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(kern, dim3(parts * n_slices), dim3(1024), lds, st, a, donor_blocks, n_slices);
+        hipLaunchKernelGGL(kern, dim3(parts * n_slices), dim3(p->hgt_apply_threads), lds, st, a, donor_blocks, n_slices);
         // (a donor-sharded run keeps the sweep behind the exchange and the merge as well: the copies / collective kernels of
         // an exchange do not fit beside the sweep's 7 workgroups per CU -- they would wait for its END, and with them the
         // whole chain of the next generation: measured with the emulated exchange, 0.9 -> 1.6 ms exposed per generation)

@@ -60,6 +60,8 @@ def run(trials, seed=1, log=print):
             acc.set_tuning("hgt_slices", int(rng.integers(1, 9)))
         if rng.random() < 0.25:
             acc.set_tuning("hgt_bin_cap", int(rng.choice([1, 5, 64])))        # full bins: the overflow image
+        if rng.random() < 0.3:
+            acc.set_tuning("hgt_apply_threads", int(rng.choice([256, 512])))  # smaller workgroups of the LDS-image pass
         acc.set_rates([0.0] * len(comps), lr, cb, ce)
         acc.load_matrix(a)
         acc.recombine(gen)
