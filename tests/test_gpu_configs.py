@@ -169,9 +169,19 @@ def test_average_distance_on_the_matrix_cores(pa, orc, N, G, cg, nb):
     K = 3 if N >= 3 else 2
     got = np.concatenate([pop.average_distance_rows(N * r // K, N * (r + 1) // K - N * r // K) for r in range(K)])
     assert np.array_equal(got, want, equal_nan=True)
+    # the lean epilogue's quotient (rcp + Newton + residual: the arithmetic core of the IEEE division) against the compiler's
+    # own f64 division inside the same kernel
+    pop.set_tuning("davg_plain_division", 1)
+    assert np.array_equal(pop.average_distance(), want, equal_nan=True)
+    pop.set_tuning("davg_plain_division", 0)
     if N == 20000:
         pop.set_tuning("davg_form", 1)                # the LDS-tile popcount kernel agrees
         assert np.array_equal(pop.average_distance(), want, equal_nan=True)
+    # rows outside the population are refused (PS_ERR_INVALID), like every bad argument of the boundary
+    for first, count in ((N, 1), (0, N + 1), (N - 1, 2), (0, 0)):
+        with pytest.raises(pa.PansimError) as e:
+            pop.average_distance_rows(first, count)
+        assert e.value.code == -1
     pop.close()
 
 
