@@ -148,24 +148,141 @@ def cpu_baseline(kw, seed, pairs, budget_s=20.0):
 
 
 class Ctx:
-    """process-group plumbing shared by every workload of one bench.py invocation"""
+    """Process-group plumbing shared by every workload of one bench.py invocation.
+
+    Two planes.  CONTROL (barriers, the max / min of a timing over the ranks, the 128-byte RCCL id): always the default
+    gloo group on CPU tensors -- a few bytes per call, and it works whatever state the GPU fabric is in.  DATA (the sum of
+    the u32 distance numerators, the OR exchange of TorchExchange): an nccl (= RCCL) group when the backend is nccl AND a
+    probe collective went through on every rank; otherwise the same collectives run over gloo on host copies and the JSON
+    line says so (`data_plane`)."""
 
     def __init__(self, torch, dist, world, rank, local_rank, backend):
         self.torch, self.dist, self.world, self.rank, self.local_rank, self.backend = torch, dist, world, rank, local_rank, backend
-        self.coll_dev = "cuda" if backend == "nccl" else "cpu"
+        self.data_group = None                  # None: the default (gloo) group
+        self.data_plane = "none (one rank)" if world == 1 else "gloo (host copies)"
+        self.notes = []
+
+    def probe_data_plane(self):
+        """create the nccl group and push one tiny all-reduce + one all-to-all through it; every rank must succeed"""
+        torch, dist = self.torch, self.dist
+        if self.world == 1 or self.backend != "nccl":
+            return
+        err = None
+        try:
+            g = dist.new_group(backend="nccl", timeout=_timeout())
+            t = torch.full((self.world,), float(self.rank + 1), device="cuda")
+            dist.all_reduce(t, group=g)
+            o = torch.empty_like(t)
+            dist.all_to_all_single(o, t, group=g)
+            torch.cuda.synchronize()
+            want = self.world * (self.world + 1) / 2.0
+            if abs(float(o[0].item()) - want) > 1e-6:
+                raise RuntimeError("probe all-reduce returned %r, expected %r" % (float(o[0].item()), want))
+        except Exception as e:          # (RCCL refusing two ranks on one device, a missing IPC mode, ...)
+            err = "%s: %s" % (type(e).__name__, str(e).splitlines()[0][:200] if str(e) else "")
+        bad = self.reduce(1.0 if err else 0.0, "max")
+        if bad == 0.0:
+            self.data_group, self.data_plane = g, "nccl (RCCL)"
+        else:
+            self.data_plane = "gloo (host copies; fallback: the nccl probe failed on %s)" % (
+                "this rank: " + err if err else "another rank")
+            self.notes.append(self.data_plane)
 
     def barrier(self):
         if self.world > 1:
-            self.dist.barrier()
+            self.dist.all_reduce(self.torch.zeros(1))          # control plane: gloo, CPU
         self.torch.cuda.synchronize()
 
     def reduce(self, x, op="max"):
-        """all-reduce of one float over the ranks (max or min)"""
+        """all-reduce of one float over the ranks (max or min), control plane"""
         if self.world == 1:
             return float(x)
-        t = self.torch.tensor([x], device=self.coll_dev, dtype=self.torch.float64)
+        t = self.torch.tensor([x], dtype=self.torch.float64)
         self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX if op == "max" else self.dist.ReduceOp.MIN)
         return float(t.item())
+
+    def sum_counts(self, cnt):
+        """sum of an int32 device tensor over the ranks (the distance phase's one collective), data plane"""
+        if self.world == 1:
+            return cnt
+        if self.data_group is not None:
+            self.dist.all_reduce(cnt, group=self.data_group)
+            return cnt
+        c = cnt.cpu()
+        self.dist.all_reduce(c)
+        return c
+
+
+def _timeout():
+    import datetime
+    return datetime.timedelta(seconds=float(os.environ.get("PANSIM_BENCH_PG_TIMEOUT", "120")))
+
+
+def _probe_buffer(torch, rank, world, n):
+    """a delta-like buffer whose OR over the ranks is known: word w carries bit (rank) and, on its own residue, bit 32 + rank"""
+    w = torch.arange(n, dtype=torch.int64)
+    mine = (torch.ones(n, dtype=torch.int64) << rank) | torch.where(w % world == rank, torch.ones(n, dtype=torch.int64) << (32 + rank),
+                                                                  torch.zeros(n, dtype=torch.int64))
+    want = torch.zeros(n, dtype=torch.int64)
+    for r in range(world):
+        want |= (torch.ones(n, dtype=torch.int64) << r) | torch.where(w % world == r, torch.ones(n, dtype=torch.int64) << (32 + r),
+                                                                   torch.zeros(n, dtype=torch.int64))
+    return mine, want
+
+
+def pick_exchange(ctx, shard_rank, shard_count, wanted=None):
+    """The provider of the per-generation OR exchange, chosen by a FALLBACK CHAIN: the library's own RCCL provider
+    (ps_exchange_rccl) -> torch.distributed (RCCL group if the data plane is nccl, else gloo) -> none (the HGT chain stays
+    replicated on every rank).  Each candidate is built and pushed through one small exchange whose result is known
+    (lengths the world does not divide); it is taken only if EVERY rank got the right words.  Returns (mode, provider or
+    None, chain) where chain records what was tried and why it was dropped -- the JSON line carries it."""
+    torch = ctx.torch
+    order = [wanted] if wanted and wanted not in ("auto", "") else ["rccl", "torch"]
+    chain = []
+
+    def make_rccl():
+        if ctx.data_group is None:
+            raise RuntimeError("the nccl data plane is not up (%s): a second RCCL communicator would fail the same way" % ctx.data_plane)
+        from pansim_amd.distributed import RcclExchange
+        return RcclExchange(shard_rank, shard_count, ctx.local_rank)
+
+    def make_torch():
+        from pansim_amd.distributed import TorchExchange
+        return TorchExchange(group=ctx.data_group, device=ctx.local_rank)
+
+    factories, dev = {"rccl": make_rccl, "torch": make_torch}, "cuda"
+    if os.environ.get("PANSIM_BENCH_STUB"):          # CPU test double of the providers (tests/bench_stub.py)
+        import importlib
+        factories, dev = importlib.import_module(os.environ["PANSIM_BENCH_STUB"]).providers(ctx, shard_rank, shard_count), "cpu"
+    for mode in order:
+        if mode == "none":
+            break
+        x, err = None, None
+        try:
+            if mode not in factories:
+                raise ValueError("unknown exchange provider %r" % mode)
+            x = factories[mode]()
+            n = 1000 + 37                                   # (not a multiple of 2, 3, 4, 8)
+            mine, want = _probe_buffer(torch, shard_rank, shard_count, n)
+            d = mine.to(dev)
+            ctx.torch.cuda.synchronize()
+            x(d.data_ptr(), n, 0)
+            ctx.torch.cuda.synchronize()
+            if not torch.equal(d.cpu(), want):
+                raise RuntimeError("the probe exchange returned wrong words")
+        except Exception as e:
+            err = "%s: %s" % (type(e).__name__, str(e).splitlines()[0][:200] if str(e) else "")
+        bad = ctx.reduce(1.0 if err else 0.0, "max")
+        if bad == 0.0:
+            chain.append({"provider": mode, "ok": True})
+            return mode, x, chain
+        chain.append({"provider": mode, "ok": False, "error": err or "failed on another rank"})
+        if x is not None and hasattr(x, "close"):
+            try:
+                x.close()
+            except Exception:
+                pass
+    return "none", None, chain
 
 
 def distance_roofline(form, N, L_local, G_acc, P, core_ms, acc_ms):
@@ -221,28 +338,44 @@ def distance_roofline(form, N, L_local, G_acc, P, core_ms, acc_ms):
     return out
 
 
-def measure(ctx, kw, P, steps, warmup, shard_rank, shard_count, seed=0, want_pairs=False, exchange=None):
+def _with_chain(r, exchange, chain):
+    """records what pick_exchange tried; a run that ended without a provider says why in `mode`"""
+    if chain is not None:
+        r["exchange"]["provider_chain"] = chain
+        failed = [c for c in chain if not c["ok"]]
+        if exchange is None and failed:
+            r["exchange"]["mode"] = "none (fallback: %s)" % "; ".join("%s: %s" % (c["provider"], c["error"]) for c in failed)
+    return r
+
+
+def measure(ctx, kw, P, steps, warmup, shard_rank, shard_count, seed=0, want_pairs=False, exchange=None, xchg=None, chain=None):
     """One workload: create the simulation (this rank's shard), settle, warm up, time exactly `steps` generations
-    between barriers (max over ranks), then the distance phase.  Returns a dict of raw measurements."""
+    between barriers (max over ranks), then the distance phase.  Returns a dict of raw measurements.
+    `exchange` names the per-generation exchange step of a strong-scaling run (HGT donors sharded over the ranks, deltas
+    ORed across them): "rccl" / "torch" = the provider object `xchg` that pick_exchange built and probed (the caller owns
+    it); "emulate" = this process plays shard 0 of shard_count and device-local copies of the same volume stand in for
+    the collectives; None / "none" = the accessory chain replicated on every rank."""
+    if os.environ.get("PANSIM_BENCH_STUB"):
+        import importlib
+        if xchg is None and exchange != "emulate":
+            exchange = None
+        r = importlib.import_module(os.environ["PANSIM_BENCH_STUB"]).measure(ctx, kw, P, steps, warmup, shard_rank, shard_count,
+                                                                            exchange=exchange, want_pairs=want_pairs)
+        return _with_chain(r, exchange, chain)
     import pansim_amd as pa
     torch, dist, world = ctx.torch, ctx.dist, ctx.world
     sim = pa.Simulation(pa.make_params(seed=seed, n_gen=steps + warmup, max_distances=P, shard_rank=shard_rank,
                                        shard_count=shard_count, device=ctx.local_rank, **kw))
     N = kw["pop_size"]
-    # the per-generation exchange step of a strong-scaling run (HGT donors sharded over the ranks, deltas ORed across
-    # them): "torch" = all-to-all + all-gather through torch.distributed (RCCL); "emulate" = this process plays shard 0
-    # of shard_count and device-local copies of the same volume stand in for the collectives
-    xchg = None
     if exchange == "emulate":
         sim.emulate_exchange(shard_count)
-    elif exchange == "torch" and shard_count > 1:
-        from pansim_amd.distributed import TorchExchange
-        xchg = TorchExchange(device=ctx.local_rank)
-        sim.set_exchange(xchg.fn)
-    elif exchange == "rccl" and shard_count > 1:
-        from pansim_amd.distributed import RcclExchange
-        xchg = RcclExchange(shard_rank, shard_count, ctx.local_rank)       # (collective: every rank creates its handle here)
-        sim.set_exchange(xchg.fn, xchg.ctx)
+    elif exchange in ("torch", "rccl") and shard_count > 1 and xchg is not None:
+        if exchange == "rccl":
+            sim.set_exchange(xchg.fn, xchg.ctx)
+        else:
+            sim.set_exchange(xchg.fn)
+    else:
+        exchange, xchg = None, None
     sim.enable_timing(True)
     est_gen_ms = 2.0 * N * sim.core_genome.ncols / 4e9            # sweep at ~4 TB/s
     settle, prev, batch = [], None, int(max(5, min(50, 30.0 / max(est_gen_ms, 1e-3))))
@@ -306,12 +439,7 @@ def measure(ctx, kw, P, steps, warmup, shard_rank, shard_count, seed=0, want_pai
         ctx.barrier()
         t1 = time.perf_counter()
         sim.core_genome.pairwise_counts_device(sim.range1, sim.range2, cnt.data_ptr())
-        if ctx.backend == "nccl":
-            dist.all_reduce(cnt)
-        else:
-            c = cnt.cpu()
-            dist.all_reduce(c)
-            cnt = c
+        cnt = ctx.sum_counts(cnt)
         acc_d = sim.pan_genome.pairwise_distances(P, sim.range1, sim.range2)
         core_d = (cnt.cpu().numpy().astype("uint32") // 2) / float(kw["core_size"])
         ctx.barrier()
@@ -327,14 +455,13 @@ def measure(ctx, kw, P, steps, warmup, shard_rank, shard_count, seed=0, want_pai
          "G_acc": sim.pan_genome.ncols, "P": P, "N": N, "kw": kw,
          "exchange": {"mode": exchange or "none (accessory chain replicated on every rank)", "calls": x_calls,
                       "bytes_sent_plus_received_per_generation": x_bytes / max(steps, 1)}}
+    _with_chain(r, exchange, chain)
     if exchange == "emulate":
         r["exchange"]["modelled_link_ms_per_generation"] = link_us / 1e3 / max(steps, 1)
         r["exchange"]["link_model"] = ("two collectives per generation (all-to-all + all-gather), each charged %.0f us + (K - 1) / K x "
                                        "buffer / %.0f GB/s (one xGMI link: a ring is bound by a single point-to-point link) as a "
                                        "kernel that holds the accessory stream, beside device-local copies of the same volume"
                                        % (link_lat_us, link_gbps))
-    if xchg is not None and hasattr(xchg, "close"):
-        xchg.close()
     if want_pairs:
         r["pairs"] = (sim.range1, sim.range2)
     sim.close()
@@ -357,6 +484,7 @@ def sweep_roofline(r, with_traffic):
     traffic, traffic_src = pmc_traffic(kern, r["bytes_per_launch"]) if with_traffic else (None, None)
     return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+            "traffic_measured_in_this_run": False,
             "kernel": label, "avg_launch_ms": r["sweep_avg_ms"],
             "algorithmic_bytes_per_launch": r["bytes_per_launch"]}
 
@@ -409,30 +537,152 @@ def main():
                          "whole genome, split by site over the ranks (BASELINE configs[3]: --pop_size 65536 --scaling strong)")
     args = ap.parse_args()
 
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # the bare form `python3 bench.py --gpus N`: this process starts the N ranks itself -- BEFORE anything here has
+        # imported torch or touched HIP (a process that has initialised the GPU must never exec or fork GPU children)
+        raise SystemExit(launch(args, sys.argv[1:]))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: start it as `python3 bench.py --gpus %d` (it launches its own ranks) or "
+                         "under torch.distributed.run --nproc-per-node %d" % (args.gpus, world, args.gpus, args.gpus))
+    rank_main(args)
+
+
+def free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def launch(args, argv):
+    """Parent of the bare multi-GPU form: starts `torch.distributed.run --nproc-per-node N bench.py ...` as a CHILD
+    process group (never an exec), relays the ranks' stderr, and prints exactly ONE JSON line: the last complete line
+    rank 0 produced (the final one; or, if the run died or hung in its second workload, the contract line rank 0 had
+    already printed).  A run that fails before any line exists is retried once with the gloo data plane (host copies):
+    a slower exchange, but a measured curve instead of a launch error.  Returns the exit code."""
+    import signal
+    import subprocess
+    import threading
+    budget = float(os.environ.get("PANSIM_BENCH_LAUNCH_TIMEOUT", "1500"))
+    attempts = []
+    backends = [os.environ.get("PANSIM_BENCH_BACKEND", "nccl")]
+    if backends[0] != "gloo":
+        backends.append("gloo")
+    for backend in backends:
+        env = dict(os.environ)
+        env["PANSIM_BENCH_BACKEND"] = backend
+        env["PANSIM_BENCH_LAUNCHED"] = "1"
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        env.setdefault("OMP_NUM_THREADS", str(max(1, host_cores() // args.gpus)))
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + list(argv)
+        t0 = time.perf_counter()
+        proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=None, env=env, text=True, start_new_session=True)
+        lines = []
+
+        def pump():
+            for line in proc.stdout:
+                line = line.strip()
+                if line.startswith("{") and line.endswith("}"):
+                    try:
+                        lines.append(json.loads(line))
+                    except ValueError:
+                        pass
+                elif line:
+                    print(line, file=sys.stderr, flush=True)
+
+        th = threading.Thread(target=pump, daemon=True)
+        th.start()
+        timed_out = False
+        try:
+            rc = proc.wait(timeout=budget)
+        except subprocess.TimeoutExpired:
+            timed_out = True
+            try:
+                os.killpg(proc.pid, signal.SIGTERM)         # (the exact process group this function started)
+                rc = proc.wait(timeout=20)
+            except (subprocess.TimeoutExpired, ProcessLookupError):
+                try:
+                    os.killpg(proc.pid, signal.SIGKILL)
+                except ProcessLookupError:
+                    pass
+                rc = proc.wait()
+        th.join(timeout=10)
+        attempts.append({"backend": backend, "rc": rc, "timed_out": timed_out, "wall_s": round(time.perf_counter() - t0, 1),
+                         "json_lines": len(lines)})
+        if lines:
+            out = lines[-1]
+            out["launcher"] = {"self_launched": True, "attempts": attempts,
+                               "note": "python3 bench.py --gpus N started its own ranks (torch.distributed.run as a child process)"}
+            if rc != 0 or timed_out:
+                out["launcher"]["note"] += "; the ranks ended abnormally after this line was printed"
+            print(json.dumps(out), flush=True)
+            return 0
+        print("bench.py launcher: %d ranks over %s produced no line (rc %s%s)" % (args.gpus, backend, rc, ", timed out" if timed_out else ""),
+              file=sys.stderr, flush=True)
+    return 1
+
+
+class Watchdog:
+    """A rank that sits in a collective its peers never enter cannot be interrupted from Python.  Armed around the
+    optional second workload: when it fires, rank 0 prints the line it was given (the contract line, already complete)
+    with the reason, and every rank leaves with os._exit(0) -- so a hang costs the extras, never the measurement."""
+
+    def __init__(self, seconds, rank, line_fn):
+        import threading
+        self.t = threading.Timer(seconds, self.fire)
+        self.t.daemon = True
+        self.rank, self.line_fn, self.seconds = rank, line_fn, seconds
+
+    def fire(self):
+        try:
+            if self.rank == 0:
+                print(json.dumps(self.line_fn("timed out after %.0f s (watchdog)" % self.seconds)), flush=True)
+        finally:
+            os._exit(0)
+
+    def __enter__(self):
+        self.t.start()
+        return self
+
+    def __exit__(self, *exc):
+        self.t.cancel()
+        return False
+
+
+def rank_main(args):
     import torch
     import torch.distributed as dist
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d"
-                         % (args.gpus, world, args.gpus))
-    if not torch.cuda.is_available():
+    stub = bool(os.environ.get("PANSIM_BENCH_STUB"))
+    if not stub and not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: pansim_amd has no CPU path")
-    # PANSIM_BENCH_BACKEND=gloo lets several ranks share one GPU (debugging the N>1 path on a
-    # 1-GPU box); the driver's multi-GPU runs use nccl (= RCCL over xGMI), one rank per GPU
+    # PANSIM_BENCH_BACKEND=gloo runs every collective over gloo on host copies (several ranks sharing one GPU on a
+    # 1-GPU box; the launcher's retry).  The driver's multi-GPU runs use nccl (= RCCL over xGMI), one rank per GPU.
     backend = os.environ.get("PANSIM_BENCH_BACKEND", "nccl")
-    if backend != "nccl":
-        local_rank = local_rank % torch.cuda.device_count()
-    torch.cuda.set_device(local_rank)
+    ndev = 1 if stub else torch.cuda.device_count()
+    notes = []
+    if world > ndev:
+        notes.append("%d ranks on %d GPU(s): ranks share devices (rank %% %d), RCCL cannot be used" % (world, ndev, ndev))
+        backend = "gloo"
+    local_rank = local_rank % ndev
+    if not stub:
+        torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-        else:
-            dist.init_process_group(backend)
+        dist.init_process_group("gloo", timeout=_timeout())          # the control plane (see Ctx)
     ctx = Ctx(torch, dist, world, rank, local_rank, backend)
+    ctx.notes = notes
+    if stub:
+        torch.cuda.synchronize = lambda *a, **k: None
+    else:
+        ctx.probe_data_plane()
 
     # ---- the main workload
     base_kw, base_P, base_emu, d_steps, d_warmup, label = CONFIGS[args.config or "cfg2"]
@@ -461,10 +711,14 @@ def main():
         kw["competition_strength"] = args.competition_strength
     # HGT donors are sharded (with the per-generation exchange) in strong-scaling runs of wide populations, where the
     # replicated accessory chain is the Amdahl term; the weak cfg2 contract line keeps it replicated (it hides behind the sweep)
-    xmode = None
+    xmode, xchg, chain = None, None, None
     if strong and kw["pop_size"] >= 4096:
-        xmode = "emulate" if emu else (os.environ.get("PANSIM_BENCH_EXCHANGE", "torch") if world > 1 else None)
-    r = measure(ctx, kw, P, steps, warmup, 0 if emu else rank, emu if emu else world, want_pairs=True, exchange=xmode)
+        if emu:
+            xmode = "emulate"
+        elif world > 1:
+            xmode, xchg, chain = pick_exchange(ctx, rank, world, os.environ.get("PANSIM_BENCH_EXCHANGE"))
+    r = measure(ctx, kw, P, steps, warmup, 0 if emu else rank, emu if emu else world, want_pairs=True, exchange=xmode, xchg=xchg,
+                chain=chain)
 
     out = None
     if rank == 0:
@@ -480,6 +734,9 @@ def main():
             # the simulated genome grows with the ranks, so a flat `value` IS perfect scaling; the whole-job aggregates that
             # grow with the ranks are `shard_generations_per_s` (= n_gpus x value) and `cell_updates_per_s`
             "metric": "generations/sec", "value": rate,
+            # schema 2 (round 4 on): with n_gpus > 1 `value` is the whole simulation's rate; the lines of rounds 1-3 summed
+            # shard-generations over the ranks there (= today's shard_generations_per_s), so compare like with like
+            "schema_version": 2,
             "value_semantics": "generations/s of the WHOLE simulation (all ranks advance one generation together)",
             "shard_generations_per_s": world * rate if not strong else None,
             "cell_updates_per_s": rate * float(kw["pop_size"]) * float(kw["core_size"]),
@@ -505,7 +762,10 @@ def main():
             "settle_sweep_ms": r["settle"],
             "exchange": r["exchange"],
             "roofline": roof,
+            "data_plane": ctx.data_plane, "control_plane": "gloo" if world > 1 else "none (one rank)",
         }
+        if ctx.notes:
+            out["notes"] = list(ctx.notes)
         if world > 1:
             out["sweep_avg_ms_over_ranks"] = {"min": r["sweep_avg_ms_min_over_ranks"], "max": r["sweep_avg_ms_max_over_ranks"]}
         if world == 1 and not args.no_cpu_baseline and not emu:
@@ -530,15 +790,30 @@ def main():
                 others[name] = {"error": str(e)[:300]}
         out["other_configs"] = others
 
-    # ---- the north-star's scaling workload at this world size: --pop_size 65536, 1.2 M core sites split over the ranks
+    # ---- the north-star's scaling workload at this world size: --pop_size 65536, 1.2 M core sites split over the ranks.
+    # The contract line is complete at this point: rank 0 prints it NOW, so that whatever happens in the second workload
+    # (a hang inside a collective, a kill from outside) a parseable line exists; the same line, extended, is printed again
+    # at the end (`line`: "final").  The bare form's launcher relays only the last one.
     if default_wl and world > 1:
         okw, oP, _e, osteps, owarm, olabel = CONFIGS["cfg4"]
-        try:
-            ro = measure(ctx, dict(okw), oP, 10, 2, rank, world, exchange=os.environ.get("PANSIM_BENCH_EXCHANGE", "torch"))
-        except Exception as e:       # (the contract line above must survive a failure of the second workload)
-            ro = None
-            if rank == 0:
-                out["north_star_scaling"] = {"error": str(e)[:300]}
+        if rank == 0:
+            print(json.dumps(dict(out, line="contract (north_star_scaling still running)")), flush=True)
+
+        def on_timeout(why):
+            return dict(out, line="final", north_star_scaling={"error": why}, north_star_generations_per_s=None)
+
+        ro, ns_chain = None, None
+        with Watchdog(float(os.environ.get("PANSIM_BENCH_NS_TIMEOUT", "600")), rank, on_timeout):
+            err = None
+            try:
+                if xchg is None:
+                    xmode, xchg, ns_chain = pick_exchange(ctx, rank, world, os.environ.get("PANSIM_BENCH_EXCHANGE"))
+                ro = measure(ctx, dict(okw), oP, 10, 2, rank, world, exchange=xmode, xchg=xchg, chain=ns_chain)
+            except Exception as e:       # (the contract line above must survive a failure of the second workload)
+                err = "%s: %s" % (type(e).__name__, str(e)[:300])
+            if err is not None and rank == 0:
+                out["north_star_scaling"] = {"error": err, "provider_chain": ns_chain}
+                out["north_star_generations_per_s"] = None
         if rank == 0 and ro is not None:
             ns = summary(ro, "BASELINE configs[3] / north_star scaling: --pop_size 65536, %d core sites split over %d ranks (strong "
                              "scaling), P = %d" % (okw["core_size"], world, oP))
@@ -554,15 +829,25 @@ def main():
                 "max": ro["bytes_per_launch"] / (ro["sweep_avg_ms_min_over_ranks"] * 1e-3) / 1e9 / HBM_PEAK_GBS}
             out["north_star_exposed_non_sweep_ms"] = ns["exposed_non_sweep_ms"]
             out["north_star_collective_bytes_per_generation"] = ns["collective_bytes_per_generation"]
+            out["north_star_exchange"] = ro["exchange"]["mode"]
             ns["collectives"] = ("per generation: HGT donors sharded over the ranks, the delta bit matrices (N x G bits) ORed with one "
                                  "all-to-all + one all-gather (bytes above: sent + received per rank); every rank draws the same "
                                  "parents; distance phase: one all-reduce of %d u32 numerators" % oP)
             out["north_star_scaling"] = ns
 
     if rank == 0:
+        out["line"] = "final"
         print(json.dumps(out), flush=True)
+    if xchg is not None and hasattr(xchg, "close"):
+        try:
+            xchg.close()
+        except Exception:
+            pass
     if world > 1:
-        dist.destroy_process_group()
+        try:
+            dist.destroy_process_group()
+        except Exception:
+            pass
 
 
 if __name__ == "__main__":

@@ -124,6 +124,14 @@ class TorchExchange:
             err, self.error = self.error, None
             raise err from cause
 
+    def __call__(self, d_words, n_words, hip_stream=0):
+        """one exchange on a raw device buffer (tests, bench.py's provider probe); raises what the call kept"""
+        if self._call(None, int(d_words), int(n_words), int(hip_stream)) != 0:
+            self.reraise()
+
+    def close(self):
+        self.scratch = {}
+
 
 class RcclExchange:
     """The library's own ps_exchange_fn over RCCL (ps_rccl_*: no Python and no torch inside the per-generation call).
@@ -135,15 +143,26 @@ class RcclExchange:
         import torch.distributed as dist
         from . import _lib
         self._lib = _lib.load()
-        ident = np.zeros(128, np.uint8)
+        # rank 0's id travels with a status byte: if rank 0 cannot produce one (no librccl), EVERY rank raises instead of
+        # the others waiting in the broadcast for a rank that has already left
+        msg = np.zeros(129, np.uint8)
+        first_error = None
         if rank == 0:
-            _lib.check(self._lib.ps_rccl_unique_id(ident))
+            try:
+                ident = np.zeros(128, np.uint8)
+                _lib.check(self._lib.ps_rccl_unique_id(ident))
+                msg[0], msg[1:] = 1, ident
+            except Exception as e:
+                first_error = e
         if world > 1:
-            t = torch.from_numpy(ident)
+            t = torch.from_numpy(msg)
             if dist.get_backend(group) == "nccl":
                 t = t.cuda()
             dist.broadcast(t, src=0, group=group)
-            ident = t.cpu().numpy().copy()
+            msg = t.cpu().numpy().copy()
+        if msg[0] != 1:
+            raise RuntimeError("rank 0 could not create an RCCL communicator id") from first_error
+        ident = np.ascontiguousarray(msg[1:])
         self._h = C.c_void_p()
         _lib.check(self._lib.ps_rccl_exchange_create(ident, int(rank), int(world), int(device), C.byref(self._h)))
         self.fn = C.cast(self._lib.ps_exchange_rccl, C.c_void_p)
