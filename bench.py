@@ -796,6 +796,8 @@ def rank_main(args):
     # at the end (`line`: "final").  The bare form's launcher relays only the last one.
     if default_wl and world > 1:
         okw, oP, _e, osteps, owarm, olabel = CONFIGS["cfg4"]
+        if os.environ.get("PANSIM_BENCH_NS_CORE_SIZE"):      # (smoke runs of the launch path: a shorter genome, labelled as such)
+            okw = dict(okw, core_size=int(os.environ["PANSIM_BENCH_NS_CORE_SIZE"]))
         if rank == 0:
             print(json.dumps(dict(out, line="contract (north_star_scaling still running)")), flush=True)
 

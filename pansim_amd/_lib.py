@@ -49,7 +49,7 @@ class Derived(C.Structure):
                 ("n_pan_mutations", C.c_double * 2), ("n_recombinations_pan", C.c_double * 2)]
 
 
-# every symbol include/pansim_hip.h declares (tests/test_capi_symbols.py checks the header against this)
+# every symbol include/pansim_hip.h declares (tests/test_host_logic.py::test_library_exports_every_declared_symbol checks the header against this)
 _u8p = np.ctypeslib.ndpointer(np.uint8, flags="C_CONTIGUOUS")
 _u32p = np.ctypeslib.ndpointer(np.uint32, flags="C_CONTIGUOUS")
 _i32p = np.ctypeslib.ndpointer(np.int32, flags="C_CONTIGUOUS")

@@ -6,12 +6,23 @@
 //   1. all-to-all of the K row slices (ncclSend / ncclRecv to every peer inside one group: slice k of every rank's
 //      delta arrives at rank k), 2. a local OR of the K received slices, 3. ncclAllGather of the merged slices.
 // Per rank and call 2 (K - 1) / K x the buffer is sent and as much received, point to point over xGMI.
-// librccl.so is opened with dlopen at the first use: libpansim_hip.so itself links no RCCL, and a box without it
-// gets PS_ERR_NO_DEVICE from ps_rccl_* and nothing else changes.
+// librccl.so is opened with dlopen at the first use: libpansim_hip.so itself links no RCCL and includes no RCCL header
+// (the few ABI types the calls need are declared below), so a box without RCCL builds the library unchanged and gets
+// PS_ERR_NO_DEVICE from ps_rccl_* and nothing else.  Failures of RCCL calls themselves are PS_ERR_STATE.
+// PANSIM_RCCL_LIBRARY names another library to open instead (tests/fake_rccl.cpp: a test double that runs several
+// ranks on one GPU, so that K > 1 of this file executes on a one-GPU box).
 #pragma once
 
 #include <dlfcn.h>
-#include <rccl/rccl.h>      // types and enums only; every function is resolved through dlsym below
+
+// The part of the NCCL / RCCL C ABI used here (rccl.h: NCCL_UNIQUE_ID_BYTES 128, ncclResult_t ncclSuccess = 0,
+// ncclDataType_t ncclUint64 = 5, ncclComm_t an opaque pointer).  Every function is resolved through dlsym.
+typedef struct { char internal[128]; } ncclUniqueId;
+typedef struct ncclComm *ncclComm_t;
+typedef int ncclResult_t;
+typedef int ncclDataType_t;
+static const ncclResult_t ncclSuccess = 0;
+static const ncclDataType_t ncclUint64 = 5;
 
 namespace ps_rccl {
 
@@ -105,7 +116,7 @@ struct ps_rccl_exchange {
     do {                                                                                                         \
         ncclResult_t r_ = (expr);                                                                                \
         if (r_ != ncclSuccess)                                                                                   \
-            return ps_fail(PS_ERR_NO_DEVICE, "%s failed: %s (%s:%d)", #expr, (x)->GetErrorString(r_), __FILE__, __LINE__); \
+            return ps_fail(PS_ERR_STATE, "%s failed: %s (%s:%d)", #expr, (x)->GetErrorString(r_), __FILE__, __LINE__); \
     } while (0)
 
 // mine[w] = OR over k of recv[k * part + w]
@@ -172,7 +183,7 @@ extern "C" int ps_rccl_exchange_create(const uint8_t *id, int rank, int world, i
     if (r != ncclSuccess) {
         x->comm = nullptr;
         ps_rccl_exchange_destroy(x);
-        return ps_fail(PS_ERR_NO_DEVICE, "ncclCommInitRank(rank %d of %d, device %d) failed: %s", rank, world, device, a->GetErrorString(r));
+        return ps_fail(PS_ERR_STATE, "ncclCommInitRank(rank %d of %d, device %d) failed: %s", rank, world, device, a->GetErrorString(r));
     }
     *out = x;
     return PS_OK;
@@ -214,11 +225,23 @@ extern "C" int ps_exchange_rccl(void *ctx, void *d_words, uint64_t n_words, void
     ps_rccl::api *a = x->api;
     HIPCHK(hipMemcpyAsync(sc->send, d_words, n_words * 8, hipMemcpyDeviceToDevice, st));
     NCCLCHK(a, a->GroupStart());
-    for (uint64_t k = 0; k < K; k++) {
-        NCCLCHK(a, a->Send(sc->send + k * part, part, ncclUint64, (int)k, x->comm, st));
-        NCCLCHK(a, a->Recv(sc->recv + k * part, part, ncclUint64, (int)k, x->comm, st));
+    // a failure inside the bracket must not leave the group open on this thread (later RCCL calls -- the destroy, a
+    // retry, torch's own collectives on the same librccl -- would queue into a group that never closes): keep the
+    // first error, always close the group, then fail
+    ncclResult_t first = ncclSuccess;
+    const char *what = "";
+    for (uint64_t k = 0; k < K && first == ncclSuccess; k++) {
+        first = a->Send(sc->send + k * part, part, ncclUint64, (int)k, x->comm, st);
+        what = "ncclSend";
+        if (first != ncclSuccess) break;
+        first = a->Recv(sc->recv + k * part, part, ncclUint64, (int)k, x->comm, st);
+        what = "ncclRecv";
     }
-    NCCLCHK(a, a->GroupEnd());
+    const ncclResult_t closed = a->GroupEnd();
+    if (first != ncclSuccess)
+        return ps_fail(PS_ERR_STATE, "%s failed inside the all-to-all group: %s", what, a->GetErrorString(first));
+    if (closed != ncclSuccess)
+        return ps_fail(PS_ERR_STATE, "ncclGroupEnd failed: %s", a->GetErrorString(closed));
     rccl_or_slices_kernel<<<(uint32_t)((part + 255) / 256), 256, 0, st>>>(sc->mine, sc->recv, part, (uint32_t)K);
     HIPCHK(hipGetLastError());
     NCCLCHK(a, a->AllGather(sc->mine, sc->send, part, ncclUint64, x->comm, st));

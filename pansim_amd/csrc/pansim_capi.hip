@@ -2980,7 +2980,7 @@ static int emulated_exchange(void *ctx, void *d_words, uint64_t n_words, void *h
                           hipMemcpyDeviceToDevice, st));                                                   // "all-gather"
     emu_hold_kernel<<<1, 64, 0, st>>>(ticks);
     HIPCHK(hipGetLastError());
-    if (n_words == s->prm.pop_size && s->prm.competition_strength > 0.0) {
+    if (d_words == (void *)s->d_avg) {       // (told apart by the buffer itself: an HGT delta of N words exists, pan_genes <= 64)
         // the row-sharded D-avg vector (sim_average_distance): the other shards' slices never arrive, and zeros there would
         // give 7/8 of the population the weight 0 -- a different simulation (every parent from shard 0's individuals, narrow
         // windows).  Stand-in values: shard 0's slice repeated, so that the run keeps the dynamics of the unsharded one.

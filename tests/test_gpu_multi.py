@@ -290,3 +290,29 @@ def test_multi_competition_average_distance_sharded_by_rows(pa, orc, kw, n_shard
     # two exchanges per generation and shard: the average distances, then the HGT deltas
     assert [s.exchange_stats()[0] for s in multi.shards] == [6] * n_shards
     multi.close()
+
+
+def test_bench_bare_form_two_ranks_one_gpu(pa):
+    # `python3 bench.py --gpus 2` with NO launcher around it starts its own two ranks (both on
+    # this box's one GPU: the nccl data plane is refused, the run falls back to gloo host copies and says so), prints ONE
+    # line with n_gpus 2 and the north-star figure filled.  The second workload runs on a shortened genome here
+    # (PANSIM_BENCH_NS_CORE_SIZE); profiles/r05_a_bare_2ranks_one_gpu.json is the full-size run of the same command.
+    import json
+    import sys
+    env = dict(os.environ, PANSIM_BENCH_NS_CORE_SIZE="120000")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "PANSIM_BENCH_BACKEND", "PANSIM_BENCH_STUB"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "5"], env=env,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 20 and d["line"] == "final" and d["launcher"]["self_launched"]
+    assert d["value"] > 100 and d["roofline"]["frac"] > 0.1
+    assert d["north_star_generations_per_s"] > 0
+    assert d["data_plane"].startswith("gloo") and d["control_plane"] == "gloo"
+    ns = d["north_star_scaling"]
+    assert ns["exchange"]["mode"] == "torch" and ns["exchange"]["calls"] == 10
+    chain = ns["exchange"]["provider_chain"]
+    assert [c["provider"] for c in chain] == ["rccl", "torch"] and not chain[0]["ok"] and chain[1]["ok"]
