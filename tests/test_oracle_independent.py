@@ -277,3 +277,82 @@ def test_sample_weights_against_the_second_restatement(orc, case):
     assert np.allclose(alt, want, rtol=1e-13, atol=0.0)
     if case % 4 == 0 and comp == 0.0:
         assert np.array_equal(alt, want)
+
+
+# --------------------------------------------------------------------------- the authors' scripted competition strengths
+AUTHORS_STRENGTHS = (0.0, 100.0, 1e4, 1e8)      # scripts/run_pansim_benchmark.sh:235-278
+
+
+def _authors_like_population(rng, n, G, clones=0):
+    """an accessory matrix like the one the authors' flags produce after a generation (one compartment, every gene flipped
+    with p = 0.43 from a clonal start), optionally with `clones` exact copies of row 0"""
+    base = (rng.random(G) < 0.21).astype(np.uint8)
+    pop = np.where(rng.random((n, G)) < 0.4323, 1 - base, base).astype(np.uint8)
+    for k in range(1, clones + 1):
+        pop[k] = pop[0]
+    return pop
+
+
+@pytest.mark.parametrize("strength", AUTHORS_STRENGTHS)
+def test_authors_competition_strengths_against_the_second_restatement(orc, strength):
+    # population.rs:374-393 at the strengths the authors script: at 1e4 the softmax of strength * ln(avg) leaves one
+    # individual (or a tie) with all the weight, at 1e8 every other entry underflows to exactly 0
+    rng = np.random.default_rng(77)
+    n, G, cg = 48, 320, 140
+    pop = _authors_like_population(rng, n, G)
+    avg = orc.average_distance(pop, False, cg)
+    assert np.array_equal(avg, average_distance(pop, False, cg))
+    sel = np.zeros(G)                                                # --prop_positive -0.1: neutral genes (main.rs:287-292)
+    agn = int(round(0.2086 * G))
+    num, logw = orc.fitness_terms(pop, sel)
+    rc, got = orc.sample_weights(num, logw, G, agn, avg, False, 0.99, strength)
+    assert rc == 0
+    want, _ = sample_weights(pop, sel, agn, list(avg), False, 0.99, strength)
+    assert np.array_equal(got, want)
+    nz = int((got > 0.0).sum())
+    if strength >= 1e8:
+        assert nz == 1 and int(np.argmax(got)) == int(np.argmax(avg))         # winner takes all: the most distant individual
+    elif strength >= 1e4:
+        assert got.max() / got.sum() > 0.5 and np.sort(got)[n // 2] < 1e-12 * got.max()        # a handful of individuals hold the mass
+    else:
+        assert nz == n
+    # WeightedIndex over that vector (population.rs:440-443): the oracle's draws only ever name individuals with weight
+    rc, idx = orc.draw_parents(got, 5, 3)
+    assert rc == 0 and (got[idx] > 0.0).all()
+
+
+@pytest.mark.parametrize("strength", AUTHORS_STRENGTHS)
+def test_clonal_population_under_competition_is_uniform(orc, strength):
+    # all rows identical (the clonal start, or the generation after a single-parent sweep without a mutation): every
+    # distance is exactly 0, average_distance returns MIN_POSITIVE for everyone (population.rs:774-776), strength * ln of
+    # it is the same finite number for all (-7.08e10 at 1e8) and the competition softmax is exactly uniform
+    rng = np.random.default_rng(3)
+    n, G, cg = 33, 90, 10
+    pop = np.tile((rng.random(G) < 0.3).astype(np.uint8), (n, 1))
+    avg = orc.average_distance(pop, False, cg)
+    assert (avg == MIN_POSITIVE).all() and np.array_equal(avg, average_distance(pop, False, cg))
+    num, logw = orc.fitness_terms(pop, np.zeros(G))
+    rc, got = orc.sample_weights(num, logw, G, int(pop[0].sum()), avg, False, 0.99, strength)
+    want, _ = sample_weights(pop, np.zeros(G), int(pop[0].sum()), list(avg), False, 0.99, strength)
+    assert rc == 0 and np.array_equal(got, want)
+    assert (got == got[0]).all() and got[0] > 0.0
+
+
+def test_all_zero_weights_fall_back_to_uniform(orc):
+    # population.rs:403, :435-437: when every product underflows to 0 the weights become 1.0.  Reached when the one
+    # individual the saturated competition softmax keeps is one the genome-size softmax has already zeroed
+    # (--genome_size_penalty 1e-300: two genes more than the others costs exp(-1381))
+    G, cg = 40, 5
+    pop = np.zeros((6, G), np.uint8)
+    pop[:, :10] = 1
+    pop[5, 10:14] = 1            # the most distant individual AND the one with four extra genes
+    avg = orc.average_distance(pop, False, cg)
+    assert int(np.argmax(avg)) == 5
+    num, logw = orc.fitness_terms(pop, np.zeros(G))
+    rc, got = orc.sample_weights(num, logw, G, 10, avg, False, 1e-300, 1e8)
+    want, _ = sample_weights(pop, np.zeros(G), 10, list(avg), False, 1e-300, 1e8)
+    assert rc == 0 and np.array_equal(got, want) and (got == 1.0).all()
+    # one step away from the fallback: without the genome-size term the winner keeps its weight
+    rc, got = orc.sample_weights(num, logw, G, 10, avg, True, 1e-300, 1e8)
+    want, _ = sample_weights(pop, np.zeros(G), 10, list(avg), True, 1e-300, 1e8)
+    assert rc == 0 and np.array_equal(got, want) and (got > 0.0).sum() == 1 and got[5] > 0.0
