@@ -58,7 +58,16 @@ CONFIGS = {
                     "BASELINE configs[3], shard 0 of 8 emulated on one GPU"),
     "cfg4": (dict(pop_size=65536, core_size=1200000, pan_genes=6000, HR_rate=0.05, HGT_rate=0.05), 100000, 0, 5, 1,
              "BASELINE configs[3], all 1.2 M sites on one GPU (78.6 GB of core state)"),
+    # not a BASELINE configuration: the one workload the reference's AUTHORS script themselves
+    # (scripts/run_pansim_benchmark.sh:2-12, :235-278, the "weak competition" run: one accessory compartment, no
+    # recombination, D-avg + the competition softmax every generation, --threads 4)
+    "authors": (dict(pop_size=1000, core_size=1342000, pan_genes=4400, core_genes=1342, avg_gene_freq=0.45, core_mu=0.019,
+                     HR_rate=0.0, HGT_rate=0.0, rate_genes1=1.0, rate_genes2=1000.0, prop_genes2=0.0, pos_lambda=100.0,
+                     neg_lambda=100.0, competition_strength=100.0), 100000, 0, 40, 5,
+                "the reference authors' scripted run (scripts/run_pansim_benchmark.sh: --competition_strength 100)"),
 }
+ORACLE_PARAM_KEYS = ("pop_size", "core_size", "pan_genes", "core_genes", "avg_gene_freq", "HR_rate", "HGT_rate", "core_mu",
+                     "rate_genes1", "rate_genes2", "prop_genes2")
 
 
 def pmc_traffic(kernel, algorithmic_bytes):
@@ -106,13 +115,41 @@ def cpu_model():
     return "unknown"
 
 
-def cpu_baseline(kw, seed, pairs, budget_s=20.0):
+def cpu_baseline(kw, seed, pairs, budget_s=20.0, also_threads=None):
     """Reference algorithm (event-driven, rows in parallel like rayon) timed on the host cores:
     all cores (the figure `value` reports), one thread (the reference's --threads default), and the
-    sampled-pair distance phase on a bounded number of pairs."""
+    sampled-pair distance phase on a bounded number of pairs.  `also_threads`: one more generation at that thread count
+    (the authors' script runs --threads 4) instead of the one-thread run."""
     from oracle import oracle as o
     threads = host_cores()
-    sim = o.RefSim(o.make_params(**kw), seed=seed, threads=threads)
+    comp = float(kw.get("competition_strength", 0.0))
+    okw = {k: v for k, v in kw.items() if k in ORACLE_PARAM_KEYS}
+    if also_threads:
+        sim = o.RefSim(o.make_params(**okw), seed=seed, threads=threads, competition_strength=comp)
+        t0 = time.perf_counter()
+        sim.generation(0)
+        first = time.perf_counter() - t0
+        n = max(1, min(8, int((budget_s - first) / max(first, 1e-3))))
+        t0 = time.perf_counter()
+        for g in range(n):
+            sim.generation(1 + g)
+        dt = time.perf_counter() - t0
+        sim.close()
+        simk = o.RefSim(o.make_params(**okw), seed=seed, threads=int(also_threads), competition_strength=comp)
+        simk.generation(0)
+        t0 = time.perf_counter()
+        simk.generation(1)
+        dtk = time.perf_counter() - t0
+        simk.close()
+        what = "pop=%d core=%d pan=%d core_genes=%d, competition_strength %g" % (kw["pop_size"], kw["core_size"], kw["pan_genes"],
+                                                                                 kw.get("core_genes", 2000), comp)
+        return {"value": n / dt, "unit": "generations/s", "cores": threads, "kind": "port", "cpu_model": cpu_model(),
+                "sample": "%d generations of %s after 1 warm-up generation; event-driven reference algorithm incl. the row-parallel "
+                          "average_distance (oracle/pansim_oracle.c orc_ref_*), %d threads" % (n, what, threads),
+                "threads%d" % int(also_threads): {"value": 1.0 / dtk, "unit": "generations/s", "cores": int(also_threads),
+                                                  "sample": "1 generation after 1 warm-up generation with %d threads, the script's "
+                                                            "--threads value" % int(also_threads)}}
+    sim = o.RefSim(o.make_params(**okw), seed=seed, threads=threads, competition_strength=comp)
     t0 = time.perf_counter()
     sim.generation(0)                      # warm-up generation (page faults, first touch)
     first = time.perf_counter() - t0
@@ -130,7 +167,7 @@ def cpu_baseline(kw, seed, pairs, budget_s=20.0):
     dist_dt = time.perf_counter() - t0
     sim.close()
     # --threads 1 is the reference's default (main.rs:127-131): one generation, state already warm
-    sim1 = o.RefSim(o.make_params(**kw), seed=seed, threads=1)
+    sim1 = o.RefSim(o.make_params(**okw), seed=seed, threads=1, competition_strength=comp)
     t0 = time.perf_counter()
     sim1.generation(0)
     dt1 = time.perf_counter() - t0
@@ -690,6 +727,8 @@ def rank_main(args):
     for k in ("pop_size", "core_size", "pan_genes", "HR_rate", "HGT_rate"):
         if getattr(args, k) is not None:
             kw[k] = getattr(args, k)
+    if args.competition_strength == 0.0 and "competition_strength" in kw:
+        args.competition_strength = kw["competition_strength"]
     P = args.max_distances if args.max_distances is not None else base_P
     emu = args.emulate_shard if args.emulate_shard is not None else base_emu
     steps = args.steps if args.steps is not None else (d_steps or 100)
@@ -726,7 +765,7 @@ def rank_main(args):
         droof = None
         if r["dist_kernel_ms"] is not None:
             droof = distance_roofline(r["pair_form"], N, L_local, G_acc, P, *r["dist_kernel_ms"])
-        roof = sweep_roofline(r, default_wl or args.config in ("cfg3", "cfg4", "cfg4_shard8", "cfg5pop"))
+        roof = sweep_roofline(r, default_wl or args.config in ("cfg3", "cfg4", "cfg4_shard8", "cfg5pop", "authors"))
         rate = steps / r["dt"]
         out = {
             # `value` is the rate at which the simulation itself advances, at every world size (a sum of
@@ -769,7 +808,8 @@ def rank_main(args):
         if world > 1:
             out["sweep_avg_ms_over_ranks"] = {"min": r["sweep_avg_ms_min_over_ranks"], "max": r["sweep_avg_ms_max_over_ranks"]}
         if world == 1 and not args.no_cpu_baseline and not emu:
-            out["cpu_baseline"] = cpu_baseline(kw, 0, r["pairs"], budget_s=20.0 if kw["pop_size"] <= 1000 else 30.0)
+            out["cpu_baseline"] = cpu_baseline(kw, 0, r["pairs"], budget_s=20.0 if kw["pop_size"] <= 1000 else 30.0,
+                                               also_threads=4 if args.config == "authors" else None)
         if emu:
             out["emulated_shards"] = emu
             out["config"]["workload"] += "; THIS LINE: shard 0 of %d emulated on one GPU (%d sites)" % (emu, L_local)
@@ -777,7 +817,7 @@ def rank_main(args):
     # ---- the other BASELINE configurations, short runs on the same GPU (N = 1, default workload only)
     if default_wl and world == 1 and not args.no_other_configs:
         others = {}
-        for name in ("cfg3", "cfg5pop", "cfg4_shard8", "cfg4"):
+        for name in ("cfg3", "authors", "cfg5pop", "cfg4_shard8", "cfg4"):
             okw, oP, oemu, osteps, owarm, olabel = CONFIGS[name]
             try:
                 t0 = time.perf_counter()
@@ -785,6 +825,11 @@ def rank_main(args):
                 others[name] = summary(ro, olabel + ": --pop_size %d --core_size %d --pan_genes %d --HR_rate %g --HGT_rate %g, P = %d"
                                        % (okw["pop_size"], okw["core_size"], okw["pan_genes"], okw["HR_rate"], okw["HGT_rate"], oP),
                                        emu=oemu)
+                if name == "authors":
+                    others[name]["workload"] += ("; --core_genes 1342 --avg_gene_freq 0.45 --core_mu 0.019 --prop_genes2 0.0 "
+                                                 "--pos_lambda 100 --neg_lambda 100 --competition_strength 100")
+                    if not args.no_cpu_baseline:
+                        others[name]["cpu_baseline"] = cpu_baseline(dict(okw), 0, None, budget_s=8.0, also_threads=4)
                 others[name]["wall_s_incl_setup"] = time.perf_counter() - t0
             except Exception as e:      # (a configuration that does not fit this GPU must not void the contract line)
                 others[name] = {"error": str(e)[:300]}

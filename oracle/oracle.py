@@ -94,6 +94,7 @@ def lib():
         "orc_ref_create": (C.c_void_p, [C.POINTER(Params), u64, ci]),
         "orc_ref_destroy": (None, [C.c_void_p]),
         "orc_ref_generation": (ci, [C.c_void_p, u32]),
+        "orc_ref_set_competition": (None, [C.c_void_p, C.c_double]),
         "orc_ref_core": (C.c_void_p, [C.c_void_p]),
         "orc_ref_acc": (C.c_void_p, [C.c_void_p]),
         "orc_ref_pairwise": (None, [C.c_void_p, ci, u64, _u32p, _u32p, _f64p]),
@@ -306,10 +307,12 @@ def recombine_acc(pop, seed, gen, comp_begin, comp_end, lambdas):
 class RefSim:
     """Reference-algorithm (event-driven) CPU mode: the 'port' CPU baseline."""
 
-    def __init__(self, params, seed=0, threads=1):
+    def __init__(self, params, seed=0, threads=1, competition_strength=0.0):
         self.params = params
         self.d = derive(params)
         self.h = lib().orc_ref_create(C.byref(params), int(seed), int(threads))
+        if competition_strength:
+            lib().orc_ref_set_competition(self.h, float(competition_strength))
         self.N, self.L, self.G = params.pop_size, params.core_size, self.d.pan_size
 
     def generation(self, gen):

@@ -523,11 +523,19 @@ void orc_pairwise_hamming_counts(const uint8_t *pop, uint64_t N, uint64_t ncols,
 }
 
 /* population.rs:753-784 with get_distance :114-151 */
+/* one row of average_distance (the body of the `.map(|i| ...)` closure, population.rs:759-779) */
+static double average_distance_row(const uint8_t *pop, uint64_t N, uint64_t ncols, int core, uint64_t core_genes, uint64_t i);
+
 void orc_average_distance(const uint8_t *pop, uint64_t N, uint64_t ncols, int core,
                           uint64_t core_genes, double *out)
 {
+    for (uint64_t i = 0; i < N; i++) out[i] = average_distance_row(pop, N, ncols, core, core_genes, i);
+}
+
+static double average_distance_row(const uint8_t *pop, uint64_t N, uint64_t ncols, int core, uint64_t core_genes, uint64_t i)
+{
     double matches = 0.0;                                      /* population.rs:764 */
-    for (uint64_t i = 0; i < N; i++) {
+    {
         const uint8_t *row1 = pop + i * ncols;
         double sum = 0.0;
         uint64_t count = 0;
@@ -549,7 +557,7 @@ void orc_average_distance(const uint8_t *pop, uint64_t N, uint64_t ncols, int co
         }
         double fd = sum / (double)count;                       /* :771 */
         if (fd == 0.0) fd = DBL_MIN;                           /* :774-776 f64::MIN_POSITIVE */
-        out[i] = fd;
+        return fd;
     }
 }
 
@@ -906,6 +914,7 @@ struct orc_ref_sim {
     widx_f32 pan_w[2];
     float *pan_weights[2];
     uint64_t shuffle_ctr;
+    double competition;          /* --competition_strength (0: average_distance is never called) */
 };
 
 typedef void (*row_fn)(orc_ref_sim *, uint64_t row, void *ctx);
@@ -1090,14 +1099,23 @@ static void ref_recombine(orc_ref_sim *s, uint32_t gen, int core, int n_comp, co
 }
 
 /* main.rs:429-464 */
+/* --competition_strength of the run (main.rs:438-440: average_distance is only called when it is > 0) */
+void orc_ref_set_competition(orc_ref_sim *s, double strength) { s->competition = strength; }
+
+static void ref_avg_row(orc_ref_sim *s, uint64_t row, void *ctx_)
+{
+    ((double *)ctx_)[row] = average_distance_row(s->acc, s->N, s->G, 0, s->p.core_genes, row);
+}
+
 int orc_ref_generation(orc_ref_sim *s, uint32_t gen)
 {
     uint64_t N = s->N;
     double *avg = (double *)malloc(N * sizeof(double));
     for (uint64_t i = 0; i < N; i++) avg[i] = 1.0;                 /* main.rs:435 */
+    if (s->competition > 0.0) par_rows(s, N, ref_avg_row, avg);    /* main.rs:438-440; population.rs:757 into_par_iter */
     uint32_t *idx = (uint32_t *)malloc(N * sizeof(uint32_t));
     int rc = orc_sample_indices(s->acc, N, s->G, s->seed, gen, s->d.avg_gene_num, avg,
-                                s->sel_coeff, 0, 0.99, 0.0, idx);  /* main.rs:442-443 */
+                                s->sel_coeff, 0, 0.99, s->competition, idx);  /* main.rs:442-443 */
     free(avg);
     if (rc) { free(idx); return rc; }
     /* population.rs:450-465: fresh zeroed array + serial row copies */

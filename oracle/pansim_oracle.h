@@ -171,6 +171,7 @@ orc_ref_sim *orc_ref_create(const orc_params *p, uint64_t seed, int threads);
 void orc_ref_destroy(orc_ref_sim *s);
 /* one generation of main.rs:429-464 (select, gather x2, mutate x2, HR, HGT) */
 int orc_ref_generation(orc_ref_sim *s, uint32_t gen);
+void orc_ref_set_competition(orc_ref_sim *s, double strength);   /* main.rs:438-440 */
 const uint8_t *orc_ref_core(const orc_ref_sim *s);
 const uint8_t *orc_ref_acc(const orc_ref_sim *s);
 /* threaded pairwise distances (population.rs:797-799 is a par_iter) */
