@@ -916,6 +916,7 @@ __global__ void __launch_bounds__(256) acc_rows_pad_kernel(const uint64_t *accI,
 
 typedef int ps_da_v8i __attribute__((ext_vector_type(8)));
 typedef float ps_da_v16f __attribute__((ext_vector_type(16)));
+typedef uint32_t ps_da_u32x2 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ uint32_t ps_da_lut(uint32_t raw, uint32_t colofs, uint32_t b)
 {
@@ -938,6 +939,181 @@ __device__ __forceinline__ double ps_da_half_bcast(double s, bool upper)
     const auto r0 = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
     const auto r1 = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
     return upper ? __hiloint2double((int)r1[1], (int)r0[1]) : __hiloint2double((int)r1[0], (int)r0[0]);
+}
+
+// one Jaccard distance from its integer counts, bit for bit the value of `1.0 - ((n + 0.0 + core_genes) / (u + 0.0 +
+// core_genes))` (population.rs:144-145).  FAST = the lean form described in the epilogue of
+// acc_average_distance_mfma_kernel below (one integer add + one conversion per operand; the arithmetic core of the
+// compiler's own f64 division without the scale / fixup steps that only act at the ends of the exponent range).
+template <bool FAST>
+__device__ __forceinline__ double ps_da_distance(uint32_t in, uint32_t un, double core_genes, uint32_t cg_int)
+{
+    if (FAST) {
+        const double num = (double)(in + cg_int), den = (double)(un + cg_int);
+        double rc = __builtin_amdgcn_rcp(den);
+        double er = __builtin_fma(-den, rc, 1.0);
+        rc = __builtin_fma(rc, er, rc);
+        er = __builtin_fma(-den, rc, 1.0);
+        rc = __builtin_fma(rc, er, rc);
+        const double q0 = num * rc;
+        const double rem = __builtin_fma(-den, q0, num);
+        return 1.0 - __builtin_fma(rem, rc, q0);
+    }
+    return 1.0 - (((double)in + 0.0 + core_genes) / ((double)un + 0.0 + core_genes));
+}
+
+// ---------------------------------------------------------------------------
+// D-avg in TWO PHASES (round 5): the one-kernel form below keeps a wave on its 32 NB individuals for the whole ordered
+// fold -- 256 waves for 1024 SIMDs when a rank of 8 folds its 8192 rows, and a serial f64 epilogue between the MFMA
+// bursts (0.31 of the FP4 peak).  Split by what each part needs:
+//   phase 1, acc_intersections_mfma_kernel<NB>: ONLY the {0, 1} contraction, on every SIMD.  2-D grid: x = groups of four
+//     waves x 32 NB individuals i, y = segments of `jsteps` x 128 individuals j; the same operands, table and K order as
+//     the one-kernel form.  The exact f32 counts (<= G <= 65535) leave as u16 into In[i - i_lo][j] (row pitch `ld`): a
+//     lane holds column i and four consecutive j per accumulator group, one 8-byte store each.  2 bytes per pair instead
+//     of an f64 distance: 8.6 GB for N = 65536 against 34 GB, and the division moves to phase 2 where it costs nothing.
+//   phase 2, acc_average_from_counts_kernel<FAST>: the reference's fold (population.rs:770: one running f64 sum per
+//     individual, ascending j).  Workgroup = 16 individuals; all 256 threads turn a chunk of 64 j x 16 i counts into f64
+//     distances (the unions from the row counts, the division exactly as get_distance writes it) and park them in LDS
+//     while 16 threads add the previous chunk in ascending j -- the chain of dependent additions never waits for memory
+//     or for a division.
+// Bit-equal to the one-kernel form and to the oracle: the counts are integers, the distance expression and the order of
+// the additions are unchanged.
+// ---------------------------------------------------------------------------
+template <uint32_t NB>
+__global__ void __launch_bounds__(256, NB == 2u ? 2 : 1) acc_intersections_mfma_kernel(const uint32_t *rowsP, uint32_t WP, uint32_t Npad,
+                                                                                      uint32_t i_lo, uint32_t i_cnt, uint32_t jsteps,
+                                                                                      uint16_t *In, uint32_t ld)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t lut[];      // 256 entries x 64 copies x 4 bytes, at LDS offset 0
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    for (uint32_t x = tid; x < 256u * 64u; x += 256u) {
+        const uint32_t e = x >> 6;
+        uint32_t v = 0;
+#pragma unroll
+        for (uint32_t k = 0; k < 8u; k++) v |= ((e >> k) & 1u) ? (2u << (4u * k)) : 0u;       // gene k of the byte -> nibble k = E2M1 1.0
+        *(uint32_t *)(lut + (size_t)x * 4u) = v;         // x = e * 64 + copy
+    }
+    __syncthreads();
+    const uint32_t colofs = lane << 2;
+    const uint32_t r = lane & 31u, h = lane >> 5;
+    const uint32_t i_rel = (blockIdx.x * 4u + wave) * 32u * NB;       // first row of this wave inside the shard
+    if (i_rel >= i_cnt) return;                          // (wave-uniform; no barrier follows)
+    const uint32_t *srcB[NB];
+#pragma unroll
+    for (uint32_t b = 0; b < NB; b++) srcB[b] = rowsP + (size_t)min(i_lo + i_rel + 32u * b + r, Npad - 1u) * WP + h * 4u;
+    const uint32_t nch = WP / 8u;
+    const int one = 0x7f7f7f7f;          // E8M0 block scale 2^0 in every byte
+    const uint32_t j_begin = blockIdx.y * jsteps * 128u, j_end = min(Npad, j_begin + jsteps * 128u);
+    for (uint32_t j0 = j_begin; j0 < j_end; j0 += 128u) {
+        const uint32_t *srcA[4];
+#pragma unroll
+        for (uint32_t a = 0; a < 4u; a++) srcA[a] = rowsP + (size_t)(j0 + 32u * a + r) * WP + h * 4u;
+        ps_da_v16f acc[4][NB];
+#pragma unroll
+        for (uint32_t a = 0; a < 4u; a++)
+#pragma unroll
+            for (uint32_t b = 0; b < NB; b++)
+#pragma unroll
+                for (int v = 0; v < 16; v++) acc[a][b][v] = 0.0f;
+        uint4 cur[4 + NB], nxt[4 + NB];
+#pragma unroll
+        for (uint32_t f = 0; f < 4u + NB; f++) cur[f] = *(const uint4 *)((f < 4u ? srcA[f] : srcB[f - 4u]));
+        for (uint32_t c = 0; c < nch; c++) {
+            const uint32_t cn = min(c + 1u, nch - 1u);
+#pragma unroll
+            for (uint32_t f = 0; f < 4u + NB; f++) nxt[f] = *(const uint4 *)((f < 4u ? srcA[f] : srcB[f - 4u]) + (size_t)cn * 8u);
+#pragma unroll
+            for (uint32_t t = 0; t < 4u; t++) {
+                ps_da_v8i op[4 + NB];
+#pragma unroll
+                for (uint32_t f = 0; f < 4u + NB; f++) {
+                    const uint32_t raw = t == 0u ? cur[f].x : t == 1u ? cur[f].y : t == 2u ? cur[f].z : cur[f].w;
+                    op[f] = ps_da_v8i{ (int)ps_da_lut(raw, colofs, 0u), (int)ps_da_lut(raw, colofs, 1u), (int)ps_da_lut(raw, colofs, 2u),
+                                       (int)ps_da_lut(raw, colofs, 3u), 0, 0, 0, 0 };
+                }
+#pragma unroll
+                for (uint32_t a = 0; a < 4u; a++)
+#pragma unroll
+                    for (uint32_t b = 0; b < NB; b++)
+                        acc[a][b] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(op[a], op[4u + b], acc[a][b], 4, 4, 0, one, 0, one);
+            }
+#pragma unroll
+            for (uint32_t f = 0; f < 4u + NB; f++) cur[f] = nxt[f];
+        }
+        // block (a, b): column i = i_rel + 32 b + r, rows j0 + 32 a + 8 g + 4 h + q (q = 0..3): four consecutive j per group
+#pragma unroll
+        for (uint32_t b = 0; b < NB; b++) {
+            uint16_t *row = In + (size_t)(i_rel + 32u * b + r) * ld + j0 + 4u * h;
+#pragma unroll
+            for (uint32_t a = 0; a < 4u; a++)
+#pragma unroll
+                for (uint32_t g = 0; g < 4u; g++) {
+                    const uint32_t c0 = (uint32_t)acc[a][b][4 * g], c1 = (uint32_t)acc[a][b][4 * g + 1];
+                    const uint32_t c2 = (uint32_t)acc[a][b][4 * g + 2], c3 = (uint32_t)acc[a][b][4 * g + 3];
+                    __builtin_nontemporal_store(ps_da_u32x2{ c0 | (c1 << 16), c2 | (c3 << 16) }, (ps_da_u32x2 *)(row + 32u * a + 8u * g));
+                }
+        }
+    }
+}
+
+// phase 2 (see above).  Counts of rows [i_lo, i_lo + i_cnt) against all N columns; out[i] for those rows only.
+#define PS_AC_IB 16u
+#define PS_AC_JB 64u
+template <bool FAST>
+__global__ void __launch_bounds__(256, 8) acc_average_from_counts_kernel(const uint16_t *In, uint32_t ld, const uint32_t *rowcnt, uint32_t N,
+                                                                         uint32_t i_lo, uint32_t i_cnt, double core_genes, uint32_t cg_int,
+                                                                         double *out)
+{
+    __shared__ double S[2][PS_AC_JB * (PS_AC_IB + 1u)];
+    const uint32_t tid = threadIdx.x, i0 = blockIdx.x * PS_AC_IB;       // (relative to the shard)
+    const uint32_t ii = tid >> 4, jq = tid & 15u;                       // this thread turns 4 consecutive j of individual i0 + ii into distances
+    const uint32_t nch = (N + PS_AC_JB - 1u) / PS_AC_JB;
+    const bool live = i0 + ii < i_cnt;
+    const uint32_t ci = live ? rowcnt[i_lo + i0 + ii] : 0u;
+    const uint16_t *src = In + (size_t)(i0 + ii) * ld + 4u * jq;
+    ps_da_u32x2 raw;
+    uint4 cj;
+    auto load = [&](uint32_t c) {
+        // (In has ld >= Npad columns and rowcnt Npad entries: no edge in the loads; rows past N are skipped by the fold)
+        raw = live ? __builtin_nontemporal_load((const ps_da_u32x2 *)(src + c * PS_AC_JB)) : ps_da_u32x2{ 0u, 0u };
+        cj = *(const uint4 *)(rowcnt + c * PS_AC_JB + 4u * jq);
+    };
+    auto park = [&](uint32_t buf) {
+        const uint32_t in[4] = { raw.x & 0xffffu, raw.x >> 16, raw.y & 0xffffu, raw.y >> 16 };
+        const uint32_t cjv[4] = { cj.x, cj.y, cj.z, cj.w };
+#pragma unroll
+        for (uint32_t q = 0; q < 4u; q++)
+            S[buf][(4u * jq + q) * (PS_AC_IB + 1u) + ii] = ps_da_distance<FAST>(in[q], ci + cjv[q] - in[q], core_genes, cg_int);
+    };
+    load(0u);
+    park(0u);
+    __syncthreads();
+    double sum = 0.0;
+    const uint32_t i = i_lo + i0 + tid;          // (threads 0..15 fold)
+    for (uint32_t c = 0; c < nch; c++) {
+        const uint32_t buf = c & 1u;
+        if (c + 1u < nch) load(c + 1u);
+        if (tid < PS_AC_IB) {
+            // 16 LDS reads ahead of their 16 dependent additions (the j == i term is skipped, population.rs:126-128)
+            for (uint32_t jj = 0; jj < PS_AC_JB; jj += 16u) {
+                double w[16];
+#pragma unroll
+                for (uint32_t u = 0; u < 16u; u++) w[u] = S[buf][(jj + u) * (PS_AC_IB + 1u) + tid];
+#pragma unroll
+                for (uint32_t u = 0; u < 16u; u++) {
+                    const uint32_t j = c * PS_AC_JB + jj + u;
+                    if (j < N && j != i) sum = sum + w[u];
+                }
+            }
+        }
+        if (c + 1u < nch) park(buf ^ 1u);
+        __syncthreads();
+    }
+    if (tid < PS_AC_IB && i0 + tid < i_cnt && i < N) {
+        double fd = sum / (double)(N - 1u);
+        if (fd == 0.0) fd = 2.2250738585072014e-308;    // f64::MIN_POSITIVE, population.rs:774-776
+        out[i] = fd;
+    }
 }
 
 template <uint32_t NB, bool FAST>

@@ -4,8 +4,10 @@
 //
 // RCCL has no OR reduction, so the exchange is the same three steps as pansim_amd/distributed.py::or_all_reduce:
 //   1. all-to-all of the K row slices (ncclSend / ncclRecv to every peer inside one group: slice k of every rank's
-//      delta arrives at rank k), 2. a local OR of the K received slices, 3. ncclAllGather of the merged slices.
-// Per rank and call 2 (K - 1) / K x the buffer is sent and as much received, point to point over xGMI.
+//      delta arrives at rank k), 2. a local OR of the K received slices, 3. the merged slices to everyone: a second
+//      group of direct sends (round 5; PANSIM_RCCL_GATHER=ring selects ncclAllGather instead).
+// Per rank and call 2 (K - 1) / K x the buffer is sent and as much received, point to point over xGMI: both steps put one
+// slice on each of the K - 1 links of a fully connected node at the same time.
 // librccl.so is opened with dlopen at the first use: libpansim_hip.so itself links no RCCL and includes no RCCL header
 // (the few ABI types the calls need are declared below), so a box without RCCL builds the library unchanged and gets
 // PS_ERR_NO_DEVICE from ps_rccl_* and nothing else.  Failures of RCCL calls themselves are PS_ERR_STATE.
@@ -110,6 +112,7 @@ struct ps_rccl_exchange {
     // --competition_strength run): one scratch set per length, so that alternating calls never reallocate
     ps_rccl_scratch scratch[4];
     uint64_t calls = 0, bytes = 0;
+    bool ring_gather = false;       // PANSIM_RCCL_GATHER=ring: ncclAllGather instead of the direct sends (A/B on real links)
 };
 
 #define NCCLCHK(x, expr)                                                                                         \
@@ -177,6 +180,7 @@ extern "C" int ps_rccl_exchange_create(const uint8_t *id, int rank, int world, i
     x->rank = rank;
     x->world = world;
     x->device = device;
+    if (const char *e = getenv("PANSIM_RCCL_GATHER")) x->ring_gather = strcmp(e, "ring") == 0;
     ncclUniqueId uid;
     memcpy(&uid, id, sizeof(uid));
     ncclResult_t r = a->CommInitRank(&x->comm, world, uid, rank);       // (collective: every rank of the run is inside it)
@@ -244,7 +248,27 @@ extern "C" int ps_exchange_rccl(void *ctx, void *d_words, uint64_t n_words, void
         return ps_fail(PS_ERR_STATE, "ncclGroupEnd failed: %s", a->GetErrorString(closed));
     rccl_or_slices_kernel<<<(uint32_t)((part + 255) / 256), 256, 0, st>>>(sc->mine, sc->recv, part, (uint32_t)K);
     HIPCHK(hipGetLastError());
-    NCCLCHK(a, a->AllGather(sc->mine, sc->send, part, ncclUint64, x->comm, st));
+    if (x->ring_gather) {
+        NCCLCHK(a, a->AllGather(sc->mine, sc->send, part, ncclUint64, x->comm, st));
+    } else {
+        // the all-gather as a second DIRECT all-to-all: this rank's merged slice goes to every peer over that peer's own
+        // xGMI link, all links at once (slice / link rate), where ncclAllGather's ring passes every slice through K - 1
+        // hops and is bound by ONE link ((K - 1) / K x buffer / link rate: 7 x longer at K = 8)
+        NCCLCHK(a, a->GroupStart());
+        first = ncclSuccess;
+        for (uint64_t k = 0; k < K && first == ncclSuccess; k++) {
+            first = a->Send(sc->mine, part, ncclUint64, (int)k, x->comm, st);
+            what = "ncclSend";
+            if (first != ncclSuccess) break;
+            first = a->Recv(sc->send + k * part, part, ncclUint64, (int)k, x->comm, st);
+            what = "ncclRecv";
+        }
+        const ncclResult_t closed2 = a->GroupEnd();
+        if (first != ncclSuccess)
+            return ps_fail(PS_ERR_STATE, "%s failed inside the gather group: %s", what, a->GetErrorString(first));
+        if (closed2 != ncclSuccess)
+            return ps_fail(PS_ERR_STATE, "ncclGroupEnd failed: %s", a->GetErrorString(closed2));
+    }
     HIPCHK(hipMemcpyAsync(d_words, sc->send, n_words * 8, hipMemcpyDeviceToDevice, st));
     x->calls++;
     x->bytes += 2 * part * 8 * (K - 1);

@@ -236,7 +236,9 @@ struct ps_population {
     double *d_Dt = nullptr;          // all-pairs Jaccard distances (D-avg), N x N
     void *d_davg = nullptr;          // matrix-core D-avg: the padded bit rows + row counts
     uint64_t davg_cap = 0;
-    int davg_form = 0;               // 0 = choose, 1 = LDS-tile popcount kernels, 2 = matrix cores
+    int davg_form = 0;               // 0 = choose, 1 = LDS-tile popcount kernels, 2 = matrix cores (one kernel), 3 = matrix cores, two phases
+    void *d_davg_in = nullptr;       // two-phase D-avg: u16 intersection counts of one band of rows
+    uint64_t davg_in_cap = 0;
     uint32_t davg_nb = 0;            // matrix-core D-avg: B fragments per wave (0 = choose, 1 or 2)
     bool davg_plain_division = false; // matrix-core D-avg: the compiler's f64 division in the epilogue ("davg_plain_division": A/B, tests)
     uint64_t H_cap = 0;
@@ -280,7 +282,7 @@ extern "C" void ps_population_destroy(ps_population *p)
     (void)hipSetDevice(p->device);
     if (p->stream) (void)hipStreamSynchronize(p->stream);
     void *ptrs[] = { p->state, p->state2, p->d_delta, p->hgt_ovf_img, p->G[0], p->G[1], p->I[0], p->I[1], p->I_snap, p->d_ptab[0], p->d_ptab[1], p->hgt_scratch, p->cnt, p->d_idx, p->d_idxT, p->d_work,
-                     p->d_log1p, p->d_num_genes, p->d_logw, p->d_pairs, p->d_H, p->d_Dt, p->d_davg, p->d_pack2, p->d_pair_part };
+                     p->d_log1p, p->d_num_genes, p->d_logw, p->d_pairs, p->d_H, p->d_Dt, p->d_davg, p->d_davg_in, p->d_pack2, p->d_pair_part };
     for (void *q : ptrs)
         if (q) (void)hipFree(q);
     if (p->h_flag) (void)hipHostFree(p->h_flag);
@@ -464,7 +466,8 @@ extern "C" int ps_set_tuning(ps_population *p, const char *key, int64_t value)
         if (value < 0 || value > 8) return ps_fail(PS_ERR_INVALID, "window_blocks_per_cu must be 0 (choose) or 1..8");
         p->window_blocks_per_cu = (uint32_t)value;
     } else if (k == "davg_form") {
-        if (value < 0 || value > 2) return ps_fail(PS_ERR_INVALID, "davg_form must be 0 (choose), 1 (LDS-tile popcount kernels) or 2 (matrix cores)");
+        if (value < 0 || value > 3)
+            return ps_fail(PS_ERR_INVALID, "davg_form must be 0 (choose), 1 (LDS-tile popcount kernels), 2 (matrix cores, one kernel) or 3 (matrix cores, two phases)");
         p->davg_form = (int)value;
     } else if (k == "davg_plain_division") {
         p->davg_plain_division = value != 0;
@@ -1532,9 +1535,11 @@ static int average_distance_device(ps_population *p, double *d_out, hipStream_t 
     const uint64_t N = p->cfg.pop_size;
     if (i_cnt == ~0ull) i_cnt = N - i_lo;
     // wide populations (and every row shard): intersections on the matrix cores, ordered f64 fold in the accumulator layout
-    // (acc_kernels.h); "davg_form": 0 = choose, 1 = LDS-tile popcount kernels, 2 = matrix cores
+    // (acc_kernels.h); "davg_form": 0 = choose, 1 = LDS-tile popcount kernels, 2 = matrix cores in one kernel (round 4),
+    // 3 = matrix cores in two phases (round 5: contraction on every SIMD -> u16 counts -> division + ordered fold)
     const bool whole = i_lo == 0 && i_cnt == N;
-    const bool mfma = p->d.G > 0 && N >= 2 && (p->davg_form == 2 || !whole || (p->davg_form == 0 && N > 8192));
+    const bool mfma = p->d.G > 0 && N >= 2 && (p->davg_form >= 2 || !whole || (p->davg_form == 0 && N > 8192));
+    const bool two_phase = mfma && p->davg_form != 2 && p->d.G <= 65535;      // (u16 counts)
     if (mfma) {
         const uint32_t WP = (2u * p->d.GW + 7u) & ~7u, Npad = (uint32_t)((N + 127) & ~127ull);
         const uint64_t need = (uint64_t)Npad * WP * 4 + (uint64_t)Npad * 4 + 64;
@@ -1547,13 +1552,48 @@ static int average_distance_device(ps_population *p, double *d_out, hipStream_t 
         }
         uint32_t *rowsP = (uint32_t *)p->d_davg, *rowcnt = rowsP + (uint64_t)Npad * WP;
         acc_rows_pad_kernel<<<(Npad + 3u) / 4u, 256, 0, st>>>(p->I[p->cur], rowsP, rowcnt, p->d, WP, Npad);
+        const uint32_t lds = 256u * 64u * 4u;
+        // (the lean division needs core_genes + the largest union below 2^32: always, short of an absurd --core_genes)
+        const bool fast = p->cfg.core_genes < (1ull << 31) && !p->davg_plain_division;
+        const uint32_t cgi = fast ? (uint32_t)p->cfg.core_genes : 0u;
+        if (two_phase) {
+            // phase 1 (contraction, every SIMD) -> u16 counts In[row][j]; phase 2 (division + the ordered fold).  Rows in
+            // bands so that the scratch stays below ~9 GB (N = 65536 whole: one band of 8.6 GB)
+            const uint32_t nb = p->davg_nb ? p->davg_nb : 2u, ld = Npad;
+            uint64_t band = std::min<uint64_t>((i_cnt + 63) & ~63ull, std::max<uint64_t>(256, ((9ull << 30) / ((uint64_t)ld * 2)) & ~255ull));
+            const uint64_t need_in = band * ld * 2;
+            if (p->davg_in_cap < need_in) {
+                if (p->d_davg_in) HIPCHK(hipFree(p->d_davg_in));
+                p->d_davg_in = nullptr;
+                p->davg_in_cap = 0;
+                HIPCHK(hipMalloc(&p->d_davg_in, need_in));
+                p->davg_in_cap = need_in;
+            }
+            uint16_t *In = (uint16_t *)p->d_davg_in;
+            const uint32_t steps = Npad / 128u;
+            for (uint64_t b0 = 0; b0 < i_cnt; b0 += band) {
+                const uint32_t rows = (uint32_t)std::min<uint64_t>(band, i_cnt - b0), lo = (uint32_t)(i_lo + b0);
+                const uint32_t gx = (rows + 128u * nb - 1u) / (128u * nb);
+                uint32_t jsteps = 8u;
+                while (jsteps > 1u && (uint64_t)gx * ((steps + jsteps - 1u) / jsteps) < 2048u) jsteps >>= 1;
+                const dim3 grid(gx, (steps + jsteps - 1u) / jsteps);
+                if (nb == 2u) {
+                    HIPCHK(hipFuncSetAttribute((const void *)acc_intersections_mfma_kernel<2u>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                    acc_intersections_mfma_kernel<2u><<<grid, 256, lds, st>>>(rowsP, WP, Npad, lo, rows, jsteps, In, ld);
+                } else {
+                    HIPCHK(hipFuncSetAttribute((const void *)acc_intersections_mfma_kernel<1u>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                    acc_intersections_mfma_kernel<1u><<<grid, 256, lds, st>>>(rowsP, WP, Npad, lo, rows, jsteps, In, ld);
+                }
+                const uint32_t g2 = (rows + PS_AC_IB - 1u) / PS_AC_IB;
+                if (fast)
+                    acc_average_from_counts_kernel<true><<<g2, 256, 0, st>>>(In, ld, rowcnt, (uint32_t)N, lo, rows, (double)p->cfg.core_genes, cgi, d_out);
+                else
+                    acc_average_from_counts_kernel<false><<<g2, 256, 0, st>>>(In, ld, rowcnt, (uint32_t)N, lo, rows, (double)p->cfg.core_genes, cgi, d_out);
+            }
+        } else {
         // 64 individuals per wave (two B fragments: fewer table reads per MFMA) when that still gives every SIMD a wave
         const uint32_t nb = p->davg_nb ? p->davg_nb : (i_cnt >= 64u * 1024u ? 2u : 1u);
         const uint32_t waves = (uint32_t)((i_cnt + 32u * nb - 1) / (32u * nb)), grid = (waves + 3u) / 4u;
-        const uint32_t lds = 256u * 64u * 4u;
-        // (the lean epilogue needs core_genes + the largest union below 2^32: always, short of an absurd --core_genes)
-        const bool fast = p->cfg.core_genes < (1ull << 31) && !p->davg_plain_division;
-        const uint32_t cgi = fast ? (uint32_t)p->cfg.core_genes : 0u;
 #define PS_DAVG_LAUNCH(NB_, FAST_)                                                                                                    \
         {                                                                                                                             \
             HIPCHK(hipFuncSetAttribute((const void *)acc_average_distance_mfma_kernel<NB_, FAST_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
@@ -1563,6 +1603,7 @@ static int average_distance_device(ps_population *p, double *d_out, hipStream_t 
         if (nb == 2u) { if (fast) PS_DAVG_LAUNCH(2u, true) else PS_DAVG_LAUNCH(2u, false) }
         else { if (fast) PS_DAVG_LAUNCH(1u, true) else PS_DAVG_LAUNCH(1u, false) }
 #undef PS_DAVG_LAUNCH
+        }
     } else if (N <= 8192) {
         if (!p->d_Dt) HIPCHK(hipMalloc(&p->d_Dt, N * N * sizeof(double)));
         const uint32_t nt = (uint32_t)((N + 63) / 64);

@@ -40,10 +40,10 @@ class OrScratch:
         return self.n == buf.numel() and self.K == K and self.send.device == buf.device and self.send.dtype == buf.dtype
 
 
-def or_all_reduce(buf, group=None, force_a2a=False, scratch=None):
+def or_all_reduce(buf, group=None, force_a2a=False, scratch=None, ring_gather=False):
     """in-place bitwise OR of the int64 tensor `buf` over the ranks of `group`.  NCCL / RCCL has no OR reduction: an
-    all-to-all of the K slices (slice k of every rank's buffer arrives at rank k), a local OR, and an all-gather of the
-    merged slices.  gloo has ReduceOp.BOR and takes it on CPU tensors unless `force_a2a` -- which runs the very same
+    all-to-all of the K slices (slice k of every rank's buffer arrives at rank k), a local OR, and the merged slices
+    sent to everyone (a second direct all-to-all; `ring_gather`: all_gather_into_tensor instead).  gloo has ReduceOp.BOR and takes it on CPU tensors unless `force_a2a` -- which runs the very same
     slice / pad / OR / all-gather logic over gloo, so that the RCCL branch is covered by CPU tests.  `scratch`
     (an OrScratch) keeps the three work buffers between calls.  Returns the bytes this rank sent + received."""
     import torch.distributed as dist
@@ -66,7 +66,13 @@ def or_all_reduce(buf, group=None, force_a2a=False, scratch=None):
     mine.copy_(recv[:part])
     for k in range(1, K):
         mine |= recv[k * part:(k + 1) * part]
-    dist.all_gather_into_tensor(send, mine, group=group)        # the merged slices, everywhere
+    if ring_gather:
+        dist.all_gather_into_tensor(send, mine, group=group)    # the merged slices, everywhere (RCCL: a ring, one link's rate)
+    else:
+        # the same as a second DIRECT all-to-all: this rank's merged slice to every peer over that peer's own xGMI link,
+        # all links at once (recv is free after the OR: it carries K copies of `mine`)
+        recv.view(K, part).copy_(mine)
+        dist.all_to_all_single(send, recv, group=group)
     buf.copy_(send[:n])
     return 2 * part * 8 * (K - 1)
 

@@ -21,7 +21,10 @@ pop.load_matrix(m)
 del m
 out = {"N": N, "G": G}
 ref = None
-for name, form, nb in (("popcount_tiles", 1, 0), ("matrix_cores_nb1", 2, 1), ("matrix_cores_nb2", 2, 2)):
+FORMS = (("popcount_tiles", 1, 0), ("matrix_cores_nb1", 2, 1), ("matrix_cores_nb2", 2, 2), ("two_phase_nb2", 3, 2), ("two_phase_nb1", 3, 1))
+if len(sys.argv) > 3:
+    FORMS = tuple(f for f in FORMS if f[0] in sys.argv[3].split(","))
+for name, form, nb in FORMS:
     pop.set_tuning("davg_form", form)
     pop.set_tuning("davg_nb", nb)
     v = pop.average_distance()
@@ -32,7 +35,7 @@ for name, form, nb in (("popcount_tiles", 1, 0), ("matrix_cores_nb1", 2, 1), ("m
         v = pop.average_distance()
     out[name + "_ms"] = (time.perf_counter() - t0) / 3 * 1e3
     out[name + "_equal"] = bool(np.array_equal(v, ref))
-    if form == 2:
+    if form >= 2:
         t0 = time.perf_counter()
         for _ in range(3):
             r = pop.average_distance_rows(0, N // 8)

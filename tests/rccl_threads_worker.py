@@ -2,7 +2,7 @@
 tests/libfake_rccl.so (PANSIM_RCCL_LIBRARY) -- test infrastructure, started as a subprocess by tests/test_gpu_rccl_fake.py
 (the pytest process itself keeps the real librccl: a process resolves the RCCL symbols once).
 
-    python tests/rccl_threads_worker.py raw K            ps_exchange_rccl on raw device buffers against the numpy OR
+    python tests/rccl_threads_worker.py raw K [ring]     ps_exchange_rccl on raw device buffers against the numpy OR
     python tests/rccl_threads_worker.py sim K COMP       K site shards with sharded HGT donors inside ps_sim_run against
                                                          the UNSHARDED oracle run (COMP = --competition_strength)
     python tests/rccl_threads_worker.py fail WHAT        one injected RCCL failure (PANSIM_FAKE_RCCL_FAIL) inside the exchange
@@ -145,6 +145,8 @@ def fail(what):
     """an RCCL call fails once inside the exchange: the library returns PS_ERR_STATE with the call's name, the group is
     closed (the NEXT exchange on the same thread works), nothing hangs"""
     os.environ["PANSIM_FAKE_RCCL_FAIL"] = what
+    if what == "allgather":
+        os.environ["PANSIM_RCCL_GATHER"] = "ring"          # (the default gathers with direct sends: no ncclAllGather call)
     lib, hs = handles(1)
     torch.cuda.set_device(0)
     host = np.arange(1000, dtype=np.int64)
@@ -165,6 +167,8 @@ def fail(what):
 if __name__ == "__main__":
     mode = sys.argv[1]
     if mode == "raw":
+        if len(sys.argv) > 3:
+            os.environ["PANSIM_RCCL_GATHER"] = sys.argv[3]      # "ring": ncclAllGather instead of the direct sends
         out = raw(int(sys.argv[2]))
     elif mode == "sim":
         out = sim(int(sys.argv[2]), float(sys.argv[3]))

@@ -132,7 +132,7 @@ def run(trials, seed=1, log=print):
             want = o.average_distance(a, False, cg)
             acc = pa.Population(N, G, 2, False, 0.3, 0, cg)
             acc.load_matrix(a)
-            acc.set_tuning("davg_form", int(rng.integers(0, 3)))
+            acc.set_tuning("davg_form", int(rng.integers(0, 4)))
             acc.set_tuning("davg_nb", int(rng.integers(0, 3)))
             got = acc.average_distance()
             K = int(rng.integers(1, min(N, 5) + 1))

@@ -127,7 +127,8 @@ def _or_worker(rank, world, port, out, force_a2a):
         buf = mine.clone()
         if force_a2a and (scratch is None or not scratch.fits(buf, world)):
             scratch = OrScratch(n, world, buf)
-        sent = or_all_reduce(buf, force_a2a=force_a2a, scratch=scratch)
+        # (both forms of the last step: the direct all-to-all of the merged slices, and the ring all-gather)
+        sent = or_all_reduce(buf, force_a2a=force_a2a, scratch=scratch, ring_gather=(rep % 2 == 1))
         np.save(os.path.join(out, "or_%d_%d.npy" % (rep, rank)), buf.numpy())
         np.save(os.path.join(out, "in_%d_%d.npy" % (rep, rank)), mine.numpy())
         part = (n + world - 1) // world

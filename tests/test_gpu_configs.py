@@ -163,17 +163,25 @@ def test_average_distance_on_the_matrix_cores(pa, orc, N, G, cg, nb):
     want = orc.average_distance(m, False, cg)
     pop = pa.Population(N, G, 2, False, 0.3, 0, cg)
     pop.load_matrix(m)
-    pop.set_tuning("davg_form", 2)
-    pop.set_tuning("davg_nb", nb)
-    assert np.array_equal(pop.average_distance(), want, equal_nan=True)
     K = 3 if N >= 3 else 2
-    got = np.concatenate([pop.average_distance_rows(N * r // K, N * (r + 1) // K - N * r // K) for r in range(K)])
-    assert np.array_equal(got, want, equal_nan=True)
-    # the lean epilogue's quotient (rcp + Newton + residual: the arithmetic core of the IEEE division) against the compiler's
-    # own f64 division inside the same kernel
-    pop.set_tuning("davg_plain_division", 1)
-    assert np.array_equal(pop.average_distance(), want, equal_nan=True)
-    pop.set_tuning("davg_plain_division", 0)
+    # form 2: contraction + fold in one kernel (round 4); form 3: two phases (round 5: contraction on every SIMD -> u16
+    # counts, then division + ordered fold, acc_intersections_mfma_kernel / acc_average_from_counts_kernel); 0 = the
+    # library's choice for row shards and wide populations (= 3)
+    for form in (2, 3, 0):
+        pop.set_tuning("davg_form", form)
+        pop.set_tuning("davg_nb", nb)
+        if form:
+            assert np.array_equal(pop.average_distance(), want, equal_nan=True), form
+        got = np.concatenate([pop.average_distance_rows(N * r // K, N * (r + 1) // K - N * r // K) for r in range(K)])
+        assert np.array_equal(got, want, equal_nan=True), form
+        # the lean quotient (rcp + Newton + residual: the arithmetic core of the IEEE division) against the compiler's
+        # own f64 division inside the same kernel
+        pop.set_tuning("davg_plain_division", 1)
+        if form:
+            assert np.array_equal(pop.average_distance(), want, equal_nan=True), form
+        assert np.array_equal(pop.average_distance_rows(1, N - 1), want[1:], equal_nan=True), form
+        pop.set_tuning("davg_plain_division", 0)
+    pop.set_tuning("davg_form", 3)
     if N == 20000:
         pop.set_tuning("davg_form", 1)                # the LDS-tile popcount kernel agrees
         assert np.array_equal(pop.average_distance(), want, equal_nan=True)

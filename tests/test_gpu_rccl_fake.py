@@ -27,9 +27,10 @@ def _worker(*args, timeout=600):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("K", [2, 3, 8])
-def test_exchange_rccl_raw_buffers(K):
-    out = _worker("raw", K)
+@pytest.mark.parametrize("K,gather", [(2, "direct"), (3, "direct"), (8, "direct"), (3, "ring"), (8, "ring")])
+def test_exchange_rccl_raw_buffers(K, gather):
+    # gather: the last step as direct sends to every peer (default) or as ncclAllGather (PANSIM_RCCL_GATHER=ring)
+    out = _worker("raw", K, gather)
     assert out["K"] == K and out["exchanges_checked"] == len(out["lengths"]) == 8
     assert min(out["lengths"]) < K or K == 2
 
