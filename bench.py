@@ -361,7 +361,12 @@ def distance_roofline(form, N, L_local, G_acc, P, core_ms, acc_ms):
         out.update({"regime": ("all pairs, one-hot X X^T on v_mfma_i32_32x32x32_i8 (exact i32 counts), then lookup" if form == 6 else
                                "all pairs, one-hot X X^T on v_mfma_scale_f32_32x32x64_f8f6f4 (E2M1 {0, 1}, scales 2^0; exact f32 counts), then lookup"),
                     "bound": "mfma-i8" if form == 6 else "mfma-fp4", "achieved": ach, "peak": peak, "unit": "TOP/s", "frac": ach / peak,
-                    "pair_sites_per_s": float(N) * (N - 1) / 2.0 * L_local / kms})
+                    "pair_sites_per_s": float(N) * (N - 1) / 2.0 * L_local / kms,
+                    # the same time priced three ways: `frac` counts the N (N - 1) / 2 distinct pairs; the kernel computes whole
+                    # 256 x 256 tiles of the upper triangle (diagonal tiles in both orders, the last tile padded); the run asked
+                    # for P sampled pairs
+                    "frac_on_computed_tile_pairs": (lambda nt: nt * (nt + 1) / 2.0 * 65536.0 * L_local * 8.0 / kms / 1e12 / peak)((N + 255) // 256),
+                    "frac_on_requested_pairs": float(P) * L_local * 8.0 / kms / 1e12 / peak})
     elif form == 2:
         # all pairs, xor + popcount on nibble strings: 2 VALU wave-instructions per 8 sites of a pair
         ach = float(N) * (N - 1) / 2.0 * L_local / kms
@@ -495,10 +500,14 @@ def measure(ctx, kw, P, steps, warmup, shard_rank, shard_count, seed=0, want_pai
     _with_chain(r, exchange, chain)
     if exchange == "emulate":
         r["exchange"]["modelled_link_ms_per_generation"] = link_us / 1e3 / max(steps, 1)
-        r["exchange"]["link_model"] = ("two collectives per generation (all-to-all + all-gather), each charged %.0f us + (K - 1) / K x "
-                                       "buffer / %.0f GB/s (one xGMI link: a ring is bound by a single point-to-point link) as a "
-                                       "kernel that holds the accessory stream, beside device-local copies of the same volume"
-                                       % (link_lat_us, link_gbps))
+        ring = os.environ.get("PANSIM_EMU_RING", "0") not in ("", "0")
+        r["exchange"]["link_model"] = (
+            "two collectives per generation, both DIRECT all-to-alls (slice k of every rank to rank k; the merged slice to every "
+            "peer): one slice of buffer / K on each of the K - 1 point-to-point xGMI links at once, so each is charged %.0f us + "
+            "(buffer / K) / %.0f GB/s%s, as a kernel of RCCL's own footprint (256 threads, 264 registers, 19.7 KB LDS) that "
+            "holds the accessory stream, beside device-local copies of the same volume"
+            % (link_lat_us, link_gbps, "; PANSIM_EMU_RING=1: the second one priced as a ring all-gather, (K - 1) / K x buffer through "
+                                       "ONE link (round 4's figure)" if ring else ""))
     if want_pairs:
         r["pairs"] = (sim.range1, sim.range2)
     sim.close()

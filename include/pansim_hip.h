@@ -294,9 +294,13 @@ void ps_sim_destroy(ps_sim *s);
  * mutate x2, HR, HGT.  Asynchronous on the device; ps_sim_sync() waits.
  * The loop stores the children of a generation in ASCENDING PARENT ORDER: the N draws of sample_indices
  * (population.rs:440-443) are sorted before both gathers.  The individuals of a Wright-Fisher generation
- * are exchangeable, so this is a relabeling no output statistic of the reference can see; it is what lets populations wider
+ * are exchangeable, so every MARGINAL the reference's outputs carry is unchanged -- but two things are not exchangeable any
+ * more: the ROW ORDER of _core_genome.csv / _pangenome.csv encodes ancestry (neighbouring rows are siblings), and with
+ * --print_dist the fixed pair list (main.rs:413-427) re-samples the same close-kin slot pairs every generation, so the
+ * sampling noise of _per_gen.tsv is autocorrelated between generations when P << N^2.  It is what lets populations wider
  * than one wavefront gather from a ~1 KB window of the parent row.  The Population-level calls (ps_sample_indices,
- * ps_next_generation, ps_step) take and return any order, like the reference's methods. */
+ * ps_next_generation, ps_step) take and return any order, like the reference's methods: a host that needs the
+ * reference's slot order drives those instead of ps_sim_run. */
 int ps_sim_run(ps_sim *s, uint32_t first_generation, uint32_t count);
 int ps_sim_sync(ps_sim *s);
 /* Shard the HGT donors over the site shards of this run (shard_rank / shard_count of the parameters) and exchange the

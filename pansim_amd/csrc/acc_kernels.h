@@ -177,6 +177,7 @@ struct acc_hgt_args {
     // donor shard: this launch serves the donors [dn_lo, dn_lo + dn_cnt) only (all of them: 0, N).  Events are keyed per
     // donor and the recipient's bit is ORed, so the union over any partition of the donors is the unsharded result.
     uint32_t dn_lo, dn_cnt;
+    uint32_t bin_prio;             // bin pass: wave priority (s_setprio) while it runs beside a sweep (0 = leave it)
 };
 
 // k_d for every (compartment, donor): kmin + number of thresholds <= u (ps_poisson_table).
@@ -295,6 +296,11 @@ __global__ void __launch_bounds__(256) acc_hgt_donor_bin_kernel(acc_hgt_args a)
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
     const uint32_t items = a.n_comp * a.dn_cnt;
     const uint32_t cap = a.bin_cap;
+    // (cfg3: the pass is the longest link of the chain that has to fit beside the sweep -- it has one wave slot per SIMD
+    // against the sweep's seven, and what it loses in issue slots the whole next generation waits for)
+    if (a.bin_prio >= 3u) __builtin_amdgcn_s_setprio(3);
+    else if (a.bin_prio == 2u) __builtin_amdgcn_s_setprio(2);
+    else if (a.bin_prio == 1u) __builtin_amdgcn_s_setprio(1);
     uint32_t *mybins = a.bins + (uint64_t)blockIdx.x * a.parts * cap;
     for (uint32_t q = tid; q < a.parts; q += blockDim.x) fill[q] = 0u;
     for (uint32_t item = blockIdx.x; item < items; item += gridDim.x) {

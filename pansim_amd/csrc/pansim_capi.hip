@@ -212,6 +212,7 @@ struct ps_population {
     uint32_t hgt_events_per_thread = 0;  // light HGT kernel: 0 = whole chip, else narrow launch (set by ps_sim)
     bool hgt_list_in_global = false;     // light HGT kernel: donor lists in global scratch (no LDS beside the block sweep)
     bool hgt_bin_list_in_global = false; // binned HGT, bin pass: the same (tests)
+    uint32_t hgt_bin_prio = 0;           // binned HGT, bin pass: s_setprio level beside the sweep (PANSIM_HGT_BIN_PRIO)
     uint32_t *cnt = nullptr;
     int cur = 0;
     ps_acc_plan aplan{};
@@ -263,6 +264,7 @@ struct ps_population {
     uint32_t sweep_queue_cap = 0;       // tests: the sweeps treat their candidate queues / HR lists as this short (0 = real size)
     uint32_t hgt_apply_threads = 1024;  // binned HGT, LDS-image pass: threads per workgroup (256 / 512 / 1024; "hgt_apply_threads")
     uint32_t window_blocks_per_cu = 0;  // window sweep: workgroups per CU (0 = PS_WBPC)
+    uint32_t free_cus_per_xcd = 0;      // core stream created with a CU mask that leaves this many CUs per XCD to other streams
     bool exchange_beside_sweep = false; // donor-sharded HGT: the next sweep waits for the LDS-image pass only (ps_sim sets it)
     int last_sweep_form = 0;            // PS_SWEEP_FORM_* of the last core sweep launch (ps_last_sweep_form)
     int window_sweep = -1;              // window sweep for N > 1024 when the parents are sorted: -1 = choose, 0 = never, 1 = whenever possible
@@ -307,6 +309,23 @@ static int pop_create_impl(const ps_config *cfg, const uint8_t *init_vec, ps_pop
         HIPCHK(hipGetDevice(&p->device));
     }
     PSCHK(use_device(p));
+    // PANSIM_SWEEP_FREE_CUS=n (experiment, round 5): the core stream is created with a CU mask that leaves n CUs of every
+    // XCD to the other streams -- kernels that cannot share a SIMD with resident sweep waves (RCCL's 264-register
+    // rcclGenericKernel) then start beside the sweep instead of behind it.  KFD deals mask bits round-robin over the XCCs
+    // (bit b -> XCC b % 8): clearing the first 8 n bits takes n CUs from each (scripts/ubench/cu_mask.hip).
+    if (cfg->core)
+        if (const char *e = getenv("PANSIM_SWEEP_FREE_CUS")) p->free_cus_per_xcd = (uint32_t)std::max(0, std::min(8, atoi(e)));
+    if (p->free_cus_per_xcd) {
+        hipDeviceProp_t prop;
+        HIPCHK(hipGetDeviceProperties(&prop, p->device));
+        std::vector<uint32_t> mask((size_t)(prop.multiProcessorCount + 31) / 32, 0xFFFFFFFFu);
+        for (uint32_t b = 0; b < 8u * p->free_cus_per_xcd && b < (uint32_t)prop.multiProcessorCount; b++) mask[b / 32u] &= ~(1u << (b % 32u));
+        if (hipExtStreamCreateWithCUMask(&p->stream, (uint32_t)mask.size(), mask.data()) != hipSuccess) {
+            (void)hipGetLastError();
+            p->free_cus_per_xcd = 0;            // (not permitted on this box: an ordinary stream, all CUs)
+            HIPCHK(hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking));
+        }
+    } else
     HIPCHK(hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking));
     if (const char *e = getenv("PANSIM_SWEEP_BLOCKS_PER_CU")) {
         const int v = atoi(e);
@@ -322,6 +341,7 @@ static int pop_create_impl(const ps_config *cfg, const uint8_t *init_vec, ps_pop
     if (const char *e = getenv("PANSIM_BLOCK_WAVES")) p->block_waves = (uint32_t)atoi(e);
     if (const char *e = getenv("PANSIM_HGT_SLICES")) p->hgt_slices = (uint32_t)atoi(e);
     if (const char *e = getenv("PANSIM_HGT_BIN_LIST_GLOBAL")) p->hgt_bin_list_in_global = atoi(e) != 0;
+    if (const char *e = getenv("PANSIM_HGT_BIN_PRIO")) p->hgt_bin_prio = (uint32_t)std::max(0, std::min(3, atoi(e)));
     if (const char *e = getenv("PANSIM_SWEEP_ROWS")) {
         const int v = atoi(e);
         if (v >= 2 && v <= 4) p->sweep_rows = (uint32_t)v;
@@ -810,7 +830,7 @@ static int launch_core_sweep_window(ps_population *p, const core_sweep_args &a, 
     const uint32_t bpc = std::max(1u, std::min(p->window_blocks_per_cu ? p->window_blocks_per_cu : (uint32_t)PS_WBPC, p->lds_limit / lds));
     const uint32_t segs = (a.N + 1023u) / 1024u;
     // at least one wave per (XCD group, segment); a multiple of the 8 groups
-    const uint32_t grid = (std::max(8u * ((segs + 3u) / 4u), 256u * bpc) + 7u) & ~7u;
+    const uint32_t grid = (std::max(8u * ((segs + 3u) / 4u), (256u - 8u * p->free_cus_per_xcd) * bpc) + 7u) & ~7u;
     const bool stash = a.plan.bC <= 15u && p->nibble_safe;
     // two launches: the segments whose parent window fits the row buffer, then the others (usually none: its waves
     // leave at once); they alternate the counter sets like any two consecutive launches
@@ -1105,6 +1125,7 @@ static int launch_acc_hgt(ps_population *p, uint32_t gen, hipStream_t st, hipEve
         a.bin_cap = cap;
         a.srcI = p->I[p->cur];          // not edited before the reduce pass: it IS the snapshot
         a.dstI = p->I[p->cur];
+        a.bin_prio = p->hgt_bin_prio;
         if (list_bytes) {
             // the co-running block sweep owns the CU's LDS: donor lists in global scratch, the bin pass then fits
             // beside it with its fill counters only
@@ -2965,7 +2986,8 @@ static void sim_exchange_schedule(ps_sim *s)
     const char *e = getenv("PANSIM_EXCHANGE_BESIDE_SWEEP");
     const bool on = e && atoi(e) != 0 && s->acc->exchange != nullptr;
     s->acc->exchange_beside_sweep = on;
-    if (on && s->core->window_blocks_per_cu == 0) s->core->window_blocks_per_cu = 6;
+    // (room for the exchange: a sixth of every CU, or -- PANSIM_SWEEP_FREE_CUS -- whole CUs the sweep's stream cannot use)
+    if (on && s->core->window_blocks_per_cu == 0 && s->core->free_cus_per_xcd == 0) s->core->window_blocks_per_cu = 6;
 }
 
 extern "C" int ps_sim_set_exchange(ps_sim *s, ps_exchange_fn fn, void *ctx)
@@ -2978,16 +3000,25 @@ extern "C" int ps_sim_set_exchange(ps_sim *s, ps_exchange_fn fn, void *ctx)
 }
 
 // bench.py --emulate-shard K: this process plays shard 0 of K.  Its HGT serves donors [0, N / K) and the exchange is
-// stood in for by (i) device-local copies of the volume a K-rank all-to-all + all-gather of the delta moves per rank
-// (2 x (K - 1) / K of the buffer: the pack / unpack traffic in HBM) and (ii) a one-wave kernel that holds the stream for
-// the time the two collectives would take on the links: per collective a launch latency + (K - 1) / K x bytes / the
-// rate of ONE xGMI link (the links are point to point, a ring is bound by a single link: 153 GB/s, 20 us; the
-// environment variables PANSIM_EMU_XGMI_GBPS / PANSIM_EMU_COLL_LATENCY_US override).  A timing stand-in only: the
-// other shards' events never arrive.
-__global__ void emu_hold_kernel(unsigned long long ticks)
+// stood in for by (i) device-local copies of the volume a K-rank all-to-all + gather of the delta moves per rank
+// (2 x (K - 1) / K of the buffer: the pack / unpack traffic in HBM) and (ii) a kernel of RCCL's shape that holds the stream
+// for the time the two collectives would take on the links.  Both steps of the providers are DIRECT all-to-alls (round 5):
+// one slice of buffer / K on each of the K - 1 point-to-point links at the same time, so a collective is charged a launch
+// latency + (buffer / K) / the rate of one xGMI link (153 GB/s, 20 us; PANSIM_EMU_XGMI_GBPS / PANSIM_EMU_COLL_LATENCY_US
+// override).  PANSIM_EMU_RING=1 prices round 4's ring all-gather instead ((K - 1) / K x buffer through ONE link).  A timing
+// stand-in only: the other shards' events never arrive.
+// The hold kernel has the FOOTPRINT of the kernel a real exchange runs: librccl's rcclGenericKernel on gfx950 is 256
+// threads, 261-280 unified registers per lane and 19744 bytes of LDS (read from the code object of torch's librccl,
+// RCCL 2.26.6) -- one wave per SIMD, and only on a SIMD that holds no sweep wave.  With a lighter stand-in the
+// exchange-beside-the-sweep schedule (PANSIM_EXCHANGE_BESIDE_SWEEP) measured what RCCL's kernels cannot do.
+__global__ void __launch_bounds__(256) emu_hold_kernel(unsigned long long ticks)
 {
+    __shared__ uint32_t pad[19744 / 4];
+    pad[threadIdx.x] = threadIdx.x;
+    asm volatile("v_mov_b32 v255, 0\n\tv_accvgpr_write_b32 a7, 0" ::: "v255", "a7");
     const unsigned long long t0 = wall_clock64();
     while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(64);
+    if (pad[(threadIdx.x + 1u) & 255u] == 0xFFFFFFFFu) __builtin_trap();
 }
 
 static int emulated_exchange(void *ctx, void *d_words, uint64_t n_words, void *hip_stream)
@@ -3012,14 +3043,18 @@ static int emulated_exchange(void *ctx, void *d_words, uint64_t n_words, void *h
         if (e && atof(e) >= 0.0) s->emu_latency_us = atof(e);
     }
     const uint64_t part = bytes / (uint64_t)s->emu_shards * (uint64_t)(s->emu_shards - 1);
-    const double coll_us = s->emu_latency_us + (double)part / (s->emu_link_gbps * 1e3);     // one collective
-    const unsigned long long ticks = (unsigned long long)(coll_us * 1e-6 * (double)s->emu_clock_khz * 1e3);
+    static const bool ring = getenv("PANSIM_EMU_RING") && atoi(getenv("PANSIM_EMU_RING")) != 0;
+    const double slice = (double)bytes / (double)s->emu_shards;
+    const double a2a_us = s->emu_latency_us + slice / (s->emu_link_gbps * 1e3);             // direct: one slice per link, all links at once
+    const double gather_us = ring ? s->emu_latency_us + (double)part / (s->emu_link_gbps * 1e3) : a2a_us;
+    const unsigned long long ticks = (unsigned long long)(a2a_us * 1e-6 * (double)s->emu_clock_khz * 1e3);
+    const unsigned long long ticks2 = (unsigned long long)(gather_us * 1e-6 * (double)s->emu_clock_khz * 1e3);
     hipStream_t st = (hipStream_t)hip_stream;
     HIPCHK(hipMemcpyAsync(s->emu_buf, d_words, part, hipMemcpyDeviceToDevice, st));                        // "all-to-all"
-    emu_hold_kernel<<<1, 64, 0, st>>>(ticks);
+    emu_hold_kernel<<<8, 256, 0, st>>>(ticks);
     HIPCHK(hipMemcpyAsync((uint8_t *)s->emu_buf + (bytes - part), (uint8_t *)d_words + (bytes - part), part,
                           hipMemcpyDeviceToDevice, st));                                                   // "all-gather"
-    emu_hold_kernel<<<1, 64, 0, st>>>(ticks);
+    emu_hold_kernel<<<8, 256, 0, st>>>(ticks2);
     HIPCHK(hipGetLastError());
     if (d_words == (void *)s->d_avg) {       // (told apart by the buffer itself: an HGT delta of N words exists, pan_genes <= 64)
         // the row-sharded D-avg vector (sim_average_distance): the other shards' slices never arrive, and zeros there would
@@ -3031,7 +3066,7 @@ static int emulated_exchange(void *ctx, void *d_words, uint64_t n_words, void *h
     }
     s->exchange_calls++;
     s->exchange_bytes += 2 * part;
-    s->emu_modelled_us += 2.0 * coll_us;
+    s->emu_modelled_us += a2a_us + gather_us;
     return PS_OK;
 }
 

@@ -310,7 +310,18 @@ def test_config4_full_size_properties(pa):
     import torch
     free, _total = torch.cuda.mem_get_info()
     if free < 170e9:
-        pytest.skip("needs 2 x 78.6 GB of HBM")
+        # LOUD: a skipped full-size cfg4 test must not read as coverage -- the reason goes to
+        # stderr (pytest -rs / -s show it), into gpurun_out/ for the builder, and PANSIM_REQUIRE_FULL_SIZE=1 turns it into a failure
+        msg = "test_config4_full_size_properties SKIPPED: needs 2 x 78.6 GB of HBM, only %.1f GB free" % (free / 1e9)
+        import sys
+        print("\n*** " + msg + " ***", file=sys.stderr, flush=True)
+        try:
+            os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+            open(os.path.join(ROOT, "gpurun_out", "SKIPPED_full_size_cfg4.txt"), "w").write(msg + "\n")
+        except OSError:
+            pass
+        assert not os.environ.get("PANSIM_REQUIRE_FULL_SIZE"), msg
+        pytest.skip(msg)
     kw = dict(pop_size=65536, core_size=1200000, pan_genes=6000, core_genes=2000)
     P, gens = 100000, 2
     runs = []
