@@ -1,7 +1,8 @@
 #!/bin/bash
 # Round 5, VERDICT item 6: what does HR cost the window sweep?  PMC passes of the generation loop at N = 65536 x 150000 sites
 # (one rank of 8 at cfg4) with HR on (0.05) and off (0), separate passes per counter group (MI355X_MICROARCH.md, HBM section),
-# plus GRBM_GUI_ACTIVE for the clock.  usage: scripts/pmc_hr_study.sh OUTDIR [n_generations]
+# plus GRBM_GUI_ACTIVE for the clock.  (A pass with TA_BUSY_avr / TA_*_STALLED_BY_TC_CYCLES / TCC_TAG_STALL never returned on
+# this pool -- 37 minutes until the call's limit -- and is left out; every pass runs under `timeout`.)  usage: scripts/pmc_hr_study.sh OUTDIR [n_generations]
 OUT=$1; n=${2:-6}
 REPO=$(pwd)
 mkdir -p $OUT
@@ -13,16 +14,15 @@ for hr in 0.05 0; do
            "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_INSTS_VMEM_RD SQ_INSTS_VALU SQ_ACTIVE_INST_VMEM" \
            "SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_INSTS_SALU SQ_ACTIVE_INST_VALU" \
            "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_128B_sum" \
-           "TA_BUSY_avr TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_DATA_STALLED_BY_TC_CYCLES_sum TCC_TAG_STALL_sum" \
            "GRBM_GUI_ACTIVE" "FETCH_SIZE" "WRITE_SIZE"; do
     i=$((i+1))
-    rocprofv3 --pmc $c --kernel-trace --output-format csv -d $REPO/$OUT/hr${hr}/pmc_$i -- python3 $REPO/scripts/loop_only.py $n 0 65536 150000 $hr 0.05 > $REPO/$OUT/hr${hr}_pmc_$i.log 2>&1
+    timeout 240 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $REPO/$OUT/hr${hr}/pmc_$i -- python3 $REPO/scripts/loop_only.py $n 0 65536 150000 $hr 0.05 > $REPO/$OUT/hr${hr}_pmc_$i.log 2>&1
   done
   python3 $REPO/scripts/collect_pmc.py $REPO/$OUT/hr${hr} $REPO/$OUT/hr${hr}_summary.json core_sweep_window_kernel "N=65536 L=150000 lam_hr=${hr}x lam_mut (loop_only.py)" > /dev/null
 done
 # the wave sweep's two clock states (weak #3): GRBM_GUI_ACTIVE / 8 / kernel time over several PROCESSES (a process keeps its state)
 for k in 1 2 3 4 5 6 7 8; do
-  rocprofv3 --pmc GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $REPO/$OUT/wave/pmc_$k -- python3 $REPO/scripts/sweep_only.py 30 > $REPO/$OUT/wave_$k.log 2>&1
+  timeout 240 rocprofv3 --pmc GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $REPO/$OUT/wave/pmc_$k -- python3 $REPO/scripts/sweep_only.py 30 > $REPO/$OUT/wave_$k.log 2>&1
 done
 cd $REPO
 python3 - $OUT <<'PY'
