@@ -30,6 +30,8 @@ struct core_sweep_args {
     uint32_t launch_parity;    // which counter set this launch uses
     uint32_t nt;               // out-of-place form: nontemporal row loads / stores (every byte is touched once per launch)
     uint32_t qcap_limit;       // tests: pretend the candidate queues / HR lists hold only this many entries (0 = their real size)
+    uint32_t gate_chunks;      // window sweep, experiment (PANSIM_WINDOW_GATE): a wave waits while its chunk is more than this many
+                               // chunks ahead of the slowest segment of its XCD group (0 = no gate)
 };
 
 typedef uint32_t ps_u32x4 __attribute__((ext_vector_type(4)));
@@ -691,10 +693,29 @@ __global__ void __launch_bounds__(256, PS_WLB) core_sweep_window_kernel(core_swe
     if (wide != WIDE) return;                               // the segment belongs to the other launch (no workgroup barriers here)
     uint32_t next_chunk = 0;
     if (lane == 0) next_chunk = __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#ifdef PS_WINDOW_GATE
+    uint32_t gate_budget = 4096u;      // (bounded: a gate that cannot open -- a segment whose waves are not resident -- is abandoned)
+#endif
     for (;;) {
         const uint32_t chk = __builtin_amdgcn_readfirstlane(next_chunk);
         if (b_lo + chk * PS_CHUNK >= b_hi) break;
         if (lane == 0) next_chunk = __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#ifdef PS_WINDOW_GATE      // (A/B builds only -- make variant NAME=gate VFLAGS=-DPS_WINDOW_GATE=1: the code costs the default kernel 3 spilled registers)
+        if (a.gate_chunks) {
+            // soft progress gate: the chunk counters of the group's segments ARE their frontiers (read past L1, no
+            // atomics): stay within gate_chunks of the slowest, so that the row an HR donor byte is read from is still
+            // in the group's L2
+            const uint32_t *cbase = a.work_ctr + (a.launch_parity * 8u + grp) * segs * 32u;
+            while (gate_budget) {
+                uint32_t c = lane < segs ? __hip_atomic_load(cbase + lane * 32u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0xFFFFFFFFu;
+#pragma unroll
+                for (int off = 32; off >= 1; off >>= 1) c = min(c, (uint32_t)__shfl_xor((int)c, off));
+                if (chk <= c + a.gate_chunks) break;
+                __builtin_amdgcn_s_sleep(64);
+                gate_budget--;
+            }
+        }
+#endif
     for (uint32_t cb = 0; cb < PS_CHUNK; cb++) {
         const uint32_t batch = b_lo + chk * PS_CHUNK + cb;
         if (batch >= b_hi) break;

@@ -836,6 +836,10 @@ static int launch_core_sweep_window(ps_population *p, const core_sweep_args &a, 
     // leave at once); they alternate the counter sets like any two consecutive launches
     // (the counter sets alternate among the launches that use them: a parity of their own)
     core_sweep_args a0 = a, b = a;
+    // (experiment, round 5: PANSIM_WINDOW_GATE = rows a segment may run ahead of the slowest one of its XCD group; only
+    // where every segment of a group has resident waves: at most 64 segments, the grid one round of workgroups)
+    static const int gate_rows = getenv("PANSIM_WINDOW_GATE") ? atoi(getenv("PANSIM_WINDOW_GATE")) : 0;
+    if (gate_rows > 0 && segs <= 64u && grid <= (256u - 8u * p->free_cus_per_xcd) * bpc) a0.gate_chunks = std::max(1u, (uint32_t)gate_rows / (4u * ROWS));
     a0.launch_parity = (uint32_t)(p->window_launches++ & 1u);
     b.launch_parity = (uint32_t)(p->window_launches++ & 1u);
 #define PS_WLAUNCH(ST_, NT_)                                                                                                           \
@@ -911,6 +915,7 @@ static int launch_core_sweep(ps_population *p, const uint32_t *d_idx, uint32_t g
     }
     a.overflow_flag = p->d_flag;
     a.qcap_limit = p->sweep_queue_cap;
+    a.gate_chunks = 0;
     a.stamps = p->d_stamps;
     a.work_ctr = p->d_work;
     a.launch_parity = (uint32_t)(p->sweep_launches++ & 1u);
@@ -3281,6 +3286,14 @@ struct ps_multi {
     bool peers_ok = true;               // every shard's device can read every other's memory
     std::vector<uint64_t *> delta;
     std::vector<hipEvent_t> ev_ready, ev_read;
+    // sliced form of the exchange (round 5; PANSIM_MULTI_EXCHANGE=or keeps the reading kernels): per shard a copy stream,
+    // a landing buffer for the K - 1 slices it merges, and events "my slices have arrived" / "my slice is merged" / "my
+    // gather copies are done"
+    bool sliced = true;
+    std::vector<hipStream_t> copy_stream;
+    std::vector<uint64_t *> landing;
+    std::vector<uint64_t> landing_cap;
+    std::vector<hipEvent_t> ev_a2a, ev_merged, ev_done;
     std::vector<multi_ctx> ctx;
     // the host half of a generation (three softmaxes over N individuals) is computed by shard 0 and shared: the shards'
     // replicas of the accessory matrix are bit-identical, and K shards x up to 16 threads each oversubscribe the host
@@ -3311,14 +3324,86 @@ static int multi_barrier(ps_multi *m)
     return PS_OK;
 }
 
-// ps_exchange_fn of the shards of one process.  OR is idempotent and the buffers only ever gain bits that belong to the
-// union, so a shard may OR into its buffer while its peers read it (aligned 8-byte accesses): in place, no staging.
+// dst[w] |= OR over j of land[j * part + w]   (the K - 1 slices that arrived for this shard, into its own slice in place)
+__global__ void __launch_bounds__(256) multi_or_slices_kernel(uint64_t *dst, const uint64_t *land, uint64_t len, uint64_t part, uint32_t n_land)
+{
+    const uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= len) return;
+    uint64_t v = dst[w];
+    for (uint32_t j = 0; j < n_land; j++) v |= land[(uint64_t)j * part + w];
+    dst[w] = v;
+}
+
+// ps_exchange_fn of the shards of one process, SLICED form (round 5): the same three steps as the RCCL provider, with the
+// copy engines doing the moving -- hipMemcpyPeerAsync on a copy stream of its own needs no wave slot, so the exchange
+// runs whatever the CUs are busy with, and 2 (K - 1) / K x the buffer crosses the links per shard instead of the K - 1
+// whole buffers the reading kernels pulled:
+//   1. slice k of every peer's buffer is copied into shard k's landing buffer (K - 1 peer copies, one per link),
+//   2. one small kernel ORs them into slice k of shard k's own buffer, in place (peers only ever read the OTHER slices),
+//   3. the merged slice j of every peer j is copied over slice j of shard k's buffer (K - 1 peer copies).
+static int multi_exchange_sliced(multi_ctx *c, void *d_words, uint64_t n_words, hipStream_t st)
+{
+    ps_multi *m = c->m;
+    const size_t k = c->k, K = m->shard.size();
+    const uint64_t part = (n_words + K - 1) / K;
+    auto lo = [&](size_t j) { return std::min<uint64_t>(n_words, (uint64_t)j * part); };
+    auto len = [&](size_t j) { return std::min<uint64_t>(n_words, (uint64_t)(j + 1) * part) - lo(j); };
+    const int dev_k = m->shard[k]->core->device;
+    hipStream_t cs = m->copy_stream[k];
+    if (m->landing_cap[k] < (K - 1) * part) {
+        HIPCHK(hipStreamSynchronize(cs));
+        if (m->landing[k]) HIPCHK(hipFree(m->landing[k]));
+        m->landing[k] = nullptr;
+        m->landing_cap[k] = 0;
+        HIPCHK(hipMalloc(&m->landing[k], (K - 1) * part * 8));
+        m->landing_cap[k] = (K - 1) * part;
+    }
+    m->delta[k] = (uint64_t *)d_words;
+    HIPCHK(hipEventRecord(m->ev_ready[k], st));
+    PSCHK(multi_barrier(m));                     // every shard's buffer is published and its "complete" event recorded
+    uint32_t slot = 0;
+    for (size_t j = 0; j < K; j++) {
+        if (j == k) continue;
+        HIPCHK(hipStreamWaitEvent(cs, m->ev_ready[j], 0));
+        if (len(k))
+            HIPCHK(hipMemcpyPeerAsync(m->landing[k] + (uint64_t)slot * part, dev_k, m->delta[j] + lo(k), m->shard[j]->core->device, len(k) * 8, cs));
+        slot++;
+    }
+    HIPCHK(hipEventRecord(m->ev_a2a[k], cs));
+    HIPCHK(hipStreamWaitEvent(st, m->ev_a2a[k], 0));
+    if (len(k)) {
+        multi_or_slices_kernel<<<(uint32_t)((len(k) + 255) / 256), 256, 0, st>>>((uint64_t *)d_words + lo(k), m->landing[k], len(k), part, (uint32_t)(K - 1));
+        HIPCHK(hipGetLastError());
+    }
+    HIPCHK(hipEventRecord(m->ev_merged[k], st));
+    PSCHK(multi_barrier(m));                     // every shard has recorded "my slice is merged" (and, before it, "my slices have arrived")
+    for (size_t j = 0; j < K; j++) {
+        if (j == k) continue;
+        // (ev_merged[j] also says that shard j has finished READING slice j of this buffer: its step 1 precedes its merge)
+        HIPCHK(hipStreamWaitEvent(cs, m->ev_merged[j], 0));
+        if (len(j))
+            HIPCHK(hipMemcpyPeerAsync((uint64_t *)d_words + lo(j), dev_k, m->delta[j] + lo(j), m->shard[j]->core->device, len(j) * 8, cs));
+    }
+    HIPCHK(hipEventRecord(m->ev_done[k], cs));
+    HIPCHK(hipStreamWaitEvent(st, m->ev_done[k], 0));
+    PSCHK(multi_barrier(m));                     // every shard has queued its gather copies
+    for (size_t j = 0; j < K; j++)               // nobody rewrites its buffer (next generation) before its peers have copied its slice
+        if (j != k) HIPCHK(hipStreamWaitEvent(st, m->ev_done[j], 0));
+    m->shard[k]->exchange_calls++;
+    m->shard[k]->exchange_bytes += 2 * (uint64_t)(K - 1) * part * 8;
+    return PS_OK;
+}
+
+// ps_exchange_fn of the shards of one process.  Reading-kernel form (PANSIM_MULTI_EXCHANGE=or): OR is idempotent and the
+// buffers only ever gain bits that belong to the union, so a shard may OR into its buffer while its peers read it (aligned
+// 8-byte accesses): in place, no staging -- but K - 1 whole buffers cross the links per shard, pulled by kernels on the CUs.
 static int multi_exchange(void *vctx, void *d_words, uint64_t n_words, void *hip_stream)
 {
     multi_ctx *c = (multi_ctx *)vctx;
     ps_multi *m = c->m;
     const size_t k = c->k, K = m->shard.size();
     hipStream_t st = (hipStream_t)hip_stream;
+    if (m->sliced) return multi_exchange_sliced(c, d_words, n_words, st);
     m->delta[k] = (uint64_t *)d_words;
     HIPCHK(hipEventRecord(m->ev_ready[k], st));
     PSCHK(multi_barrier(m));                     // every shard's buffer is published and its "complete" event recorded
@@ -3407,6 +3492,11 @@ extern "C" void ps_multi_destroy(ps_multi *m)
         if (k == 0 && m->d_tmp) (void)hipFree(m->d_tmp);
         if (k < m->ev_ready.size() && m->ev_ready[k]) (void)hipEventDestroy(m->ev_ready[k]);
         if (k < m->ev_read.size() && m->ev_read[k]) (void)hipEventDestroy(m->ev_read[k]);
+        if (k < m->ev_a2a.size() && m->ev_a2a[k]) (void)hipEventDestroy(m->ev_a2a[k]);
+        if (k < m->ev_merged.size() && m->ev_merged[k]) (void)hipEventDestroy(m->ev_merged[k]);
+        if (k < m->ev_done.size() && m->ev_done[k]) (void)hipEventDestroy(m->ev_done[k]);
+        if (k < m->copy_stream.size() && m->copy_stream[k]) { (void)hipStreamSynchronize(m->copy_stream[k]); (void)hipStreamDestroy(m->copy_stream[k]); }
+        if (k < m->landing.size() && m->landing[k]) (void)hipFree(m->landing[k]);
         ps_sim_destroy(m->shard[k]);
     }
     delete m;
@@ -3463,12 +3553,23 @@ extern "C" int ps_multi_create(const ps_sim_params *p, int n_shards, const int *
         m->delta.assign((size_t)n_shards, nullptr);
         m->ev_ready.assign((size_t)n_shards, nullptr);
         m->ev_read.assign((size_t)n_shards, nullptr);
+        m->ev_a2a.assign((size_t)n_shards, nullptr);
+        m->ev_merged.assign((size_t)n_shards, nullptr);
+        m->ev_done.assign((size_t)n_shards, nullptr);
+        m->copy_stream.assign((size_t)n_shards, nullptr);
+        m->landing.assign((size_t)n_shards, nullptr);
+        m->landing_cap.assign((size_t)n_shards, 0);
+        if (const char *e = getenv("PANSIM_MULTI_EXCHANGE")) m->sliced = strcmp(e, "or") != 0;
         m->ctx.resize((size_t)n_shards);
         int rc = PS_OK;
         for (int k = 0; k < n_shards && rc == PS_OK; k++) {
             m->ctx[(size_t)k] = multi_ctx{ m, (size_t)k };
             if (hipSetDevice(m->shard[(size_t)k]->core->device) != hipSuccess
                 || hipEventCreateWithFlags(&m->ev_ready[(size_t)k], hipEventDisableTiming) != hipSuccess
+                || hipEventCreateWithFlags(&m->ev_a2a[(size_t)k], hipEventDisableTiming) != hipSuccess
+                || hipEventCreateWithFlags(&m->ev_merged[(size_t)k], hipEventDisableTiming) != hipSuccess
+                || hipEventCreateWithFlags(&m->ev_done[(size_t)k], hipEventDisableTiming) != hipSuccess
+                || hipStreamCreateWithFlags(&m->copy_stream[(size_t)k], hipStreamNonBlocking) != hipSuccess
                 || hipEventCreateWithFlags(&m->ev_read[(size_t)k], hipEventDisableTiming) != hipSuccess)
                 rc = ps_fail(PS_ERR_NO_DEVICE, "cannot create the exchange events of shard %d", k);
             else

@@ -28,3 +28,5 @@ import json,sys
 d=json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
 print("comp10 gen/s %.1f period %.4f sweep %.4f" % (d["value"], d["ms_per_step"], d["roofline"]["avg_launch_ms"]))
 PY
+# soft progress gate in the window sweep (variant build), same library with the gate off as the control
+for g in 0 24 48 96 192; do run_s8 gate$g PANSIM_HIP_LIBRARY=pansim_amd/libpansim_hip_gate.so PANSIM_WINDOW_GATE=$g; done

@@ -193,13 +193,15 @@ def test_hgt_donor_shards_union_is_the_unsharded_result(pa, orc, N, G, K, mode):
 
 
 @pytest.mark.parametrize("env", [{}, {"PANSIM_MULTI_REPLICATED_HGT": "1"}, {"PANSIM_HEAVY_HGT": "1", "PANSIM_HGT_MODE": "2"},
-                                 {"PANSIM_HEAVY_HGT": "1", "PANSIM_HGT_MODE": "1"}])
+                                 {"PANSIM_HEAVY_HGT": "1", "PANSIM_HGT_MODE": "1"}, {"PANSIM_MULTI_EXCHANGE": "or"},
+                                 {"PANSIM_MULTI_EXCHANGE": "or", "PANSIM_HEAVY_HGT": "1", "PANSIM_HGT_MODE": "2"}])
 def test_multi_donor_sharded_hgt_forms(pa, orc, env):
     # ps_multi with the HGT donors sharded over the shards and the deltas ORed between them (default), against the
-    # replicated form and in both HGT kernel forms / schedules: always the unsharded oracle run
+    # replicated form and in both HGT kernel forms / schedules: always the unsharded oracle run.  The exchange itself in both
+    # forms: sliced peer copies on copy streams + one merge kernel (default, round 5) and the reading kernels ("or")
     from orc_sim import OracleSim
     kw = dict(pop_size=300, core_size=900, pan_genes=700, core_genes=100, HR_rate=0.2, HGT_rate=0.6)
-    old = {k: os.environ.get(k) for k in ("PANSIM_MULTI_REPLICATED_HGT", "PANSIM_HEAVY_HGT", "PANSIM_HGT_MODE")}
+    old = {k: os.environ.get(k) for k in ("PANSIM_MULTI_REPLICATED_HGT", "PANSIM_HEAVY_HGT", "PANSIM_HGT_MODE", "PANSIM_MULTI_EXCHANGE")}
     try:
         for k in old:
             os.environ.pop(k, None)
