@@ -982,7 +982,7 @@ __device__ __forceinline__ double ps_da_distance(uint32_t in, uint32_t un, doubl
 //     distances (the unions from the row counts, the division exactly as get_distance writes it) and park them in LDS
 //     while 16 threads add the previous chunk in ascending j -- the chain of dependent additions never waits for memory
 //     or for a division.
-// Bit-equal to the one-kernel form and to the oracle: the counts are integers, the distance expression and the order of
+// Bit-equal to the one-kernel form (and to the CPU restatement the tests compare with): the counts are integers, the distance expression and the order of
 // the additions are unchanged.
 // ---------------------------------------------------------------------------
 template <uint32_t NB>
