@@ -1585,7 +1585,9 @@ static int average_distance_device(ps_population *p, double *d_out, hipStream_t 
         if (two_phase) {
             // phase 1 (contraction, every SIMD) -> u16 counts In[row][j]; phase 2 (division + the ordered fold).  Rows in
             // bands so that the scratch stays below ~9 GB (N = 65536 whole: one band of 8.6 GB)
-            const uint32_t nb = p->davg_nb ? p->davg_nb : 2u, ld = Npad;
+            // (row pitch of the counts: Npad u16 + 256 bytes -- with a power-of-two pitch the 32 rows one store instruction
+            // touches, and the 16 rows a phase-2 workgroup reads, fall on ONE memory channel: 33.7 ms instead of TODO at N = 65536)
+            const uint32_t nb = p->davg_nb ? p->davg_nb : 2u, ld = Npad + 128u;
             uint64_t band = std::min<uint64_t>((i_cnt + 63) & ~63ull, std::max<uint64_t>(256, ((9ull << 30) / ((uint64_t)ld * 2)) & ~255ull));
             const uint64_t need_in = band * ld * 2;
             if (p->davg_in_cap < need_in) {
