@@ -826,6 +826,90 @@ __global__ void __launch_bounds__(256) acc_average_distance_tiled_kernel(const u
 // threads add the current one), so a thread's chain of additions never waits for memory.  (One thread per individual
 // reading its own column, 16 loads in flight: a thousand rows = 62 memory latencies in a row, 43 us at N = 1000 whether
 // beside the sweep or not; deeper register prefetch changed nothing.)
+// workgroup barrier that orders LDS traffic only: __syncthreads() also drains vmcnt, i.e. waits for the counts that were
+// requested a moment ago for two chunks ahead -- a memory latency per chunk (2.0 us; 2.07 ms for the 1024 chunks of a row
+// shard at N = 65536, whatever the prefetch depth)
+__device__ __forceinline__ void ps_acc_sync_lds()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+// The ordered fold of one chunk: sum = (((sum + d[0]) + d[1]) + ...) over the chunk's JB distances of individual `tid`, in
+// ascending j (population.rs:770).  The chain of dependent f64 additions is the one serial thing in D-avg -- N - 1 of them
+// per individual -- so nothing else may sit on it: the terms that are skipped (j == i, population.rs:126-128; j >= N) are
+// replaced by +0.0 BEFORE they meet the sum (sum + 0.0 == sum for the sums that occur: they start at +0.0 and only ever
+// add distances >= +0.0 or NaN), and only in the chunks that contain such a j (workgroup-uniform).  (First form: `if (j <
+// N && j != i) sum = sum + w` -- the compiler selected on the RESULT, an add, a compare and two levels of v_cndmask per
+// element on the chain: 65 cycles per element, 2.07 ms for a row shard at N = 65536.)
+// the same fold for a kernel that must stay within 64 VGPRs beside a sweep: 16 reads, then their 16 additions
+template <uint32_t JB, uint32_t STRIDE>
+__device__ __forceinline__ double ps_da_fold_chunk_lean(const double *S, uint32_t tid, double sum, uint32_t j_base, uint32_t N, uint32_t i, bool need_mask)
+{
+#pragma unroll 1
+    for (uint32_t jj = 0; jj < JB; jj += 16u) {
+        double w[16];
+#pragma unroll
+        for (uint32_t u = 0; u < 16u; u++) w[u] = S[(jj + u) * STRIDE + tid];
+        if (need_mask) {
+#pragma unroll
+            for (uint32_t u = 0; u < 16u; u++) {
+                const uint32_t j = j_base + jj + u;
+                w[u] = (j < N && j != i) ? w[u] : 0.0;
+            }
+        }
+#pragma unroll
+        for (uint32_t u = 0; u < 16u; u++) sum = sum + w[u];
+    }
+    return sum;
+}
+
+template <uint32_t JB, uint32_t STRIDE, bool need_mask>
+__device__ __forceinline__ double ps_da_fold_chunk_impl(const double *S, uint32_t tid, double sum, uint32_t j_base, uint32_t N, uint32_t i)
+{
+    // eight distances are read from LDS while the eight before them are added (two sets of 8 doubles, ping-pong; the loop
+    // is kept rolled: unrolled, the compiler hoists all JB reads to the top and spills -- the kernels that call this are
+    // built for 64 VGPRs, 8 waves per SIMD, so that they fit beside a sweep)
+    static_assert(JB % 16u == 0u, "chunks of a multiple of 16 distances");
+    double w[8], x[8];
+#pragma unroll
+    for (uint32_t u = 0; u < 8u; u++) w[u] = S[u * STRIDE + tid];
+#pragma unroll 1
+    for (uint32_t jj = 0; jj < JB; jj += 16u) {
+#pragma unroll
+        for (uint32_t u = 0; u < 8u; u++) x[u] = S[(jj + 8u + u) * STRIDE + tid];
+        if (need_mask) {
+#pragma unroll
+            for (uint32_t u = 0; u < 8u; u++) {
+                const uint32_t j = j_base + jj + u;
+                w[u] = (j < N && j != i) ? w[u] : 0.0;
+            }
+        }
+#pragma unroll
+        for (uint32_t u = 0; u < 8u; u++) sum = sum + w[u];
+        if (jj + 16u < JB) {
+#pragma unroll
+            for (uint32_t u = 0; u < 8u; u++) w[u] = S[(jj + 16u + u) * STRIDE + tid];
+        }
+        if (need_mask) {
+#pragma unroll
+            for (uint32_t u = 0; u < 8u; u++) {
+                const uint32_t j = j_base + jj + 8u + u;
+                x[u] = (j < N && j != i) ? x[u] : 0.0;
+            }
+        }
+#pragma unroll
+        for (uint32_t u = 0; u < 8u; u++) sum = sum + x[u];
+    }
+    return sum;
+}
+
+template <uint32_t JB, uint32_t STRIDE>
+__device__ __forceinline__ double ps_da_fold_chunk(const double *S, uint32_t tid, double sum, uint32_t j_base, uint32_t N, uint32_t i, bool need_mask)
+{
+    return need_mask ? ps_da_fold_chunk_impl<JB, STRIDE, true>(S, tid, sum, j_base, N, i)
+                     : ps_da_fold_chunk_impl<JB, STRIDE, false>(S, tid, sum, j_base, N, i);
+}
+
 #define PS_AV_IB 16u
 #define PS_AV_JB 64u
 __global__ void __launch_bounds__(256, 8) acc_average_from_matrix_kernel(const double *Dt, double *out, acc_dims d)
@@ -857,17 +941,10 @@ __global__ void __launch_bounds__(256, 8) acc_average_from_matrix_kernel(const d
         const uint32_t buf = c & 1u;
         if (c + 1u < nch) load(c + 1u);
         if (tid < PS_AV_IB) {
-            // 16 LDS reads ahead of their 16 dependent additions (rows past N hold zeros and are skipped like j == i)
-            for (uint32_t jj = 0; jj < PS_AV_JB; jj += 16u) {
-                double w[16];
-#pragma unroll
-                for (uint32_t u = 0; u < 16u; u++) w[u] = S[buf][(jj + u) * (PS_AV_IB + 1u) + tid];
-#pragma unroll
-                for (uint32_t u = 0; u < 16u; u++) {
-                    const uint32_t j = c * PS_AV_JB + jj + u;
-                    if (j < d.N && j != i) sum = sum + w[u];
-                }
-            }
+            // (rows past N hold zeros; the j == i term is replaced by +0.0 before it meets the sum: see ps_da_fold_chunk)
+            const uint32_t jb = c * PS_AV_JB;
+            const bool need_mask = jb < i0 + PS_AV_IB && jb + PS_AV_JB > i0;
+            sum = ps_da_fold_chunk_lean<PS_AV_JB, PS_AV_IB + 1u>(S[buf], tid, sum, jb, d.N, i, need_mask);
         }
         if (c + 1u < nch) park(buf ^ 1u);
         __syncthreads();
@@ -923,6 +1000,7 @@ __global__ void __launch_bounds__(256) acc_rows_pad_kernel(const uint64_t *accI,
 typedef int ps_da_v8i __attribute__((ext_vector_type(8)));
 typedef float ps_da_v16f __attribute__((ext_vector_type(16)));
 typedef uint32_t ps_da_u32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t ps_u32x4_acc __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ uint32_t ps_da_lut(uint32_t raw, uint32_t colofs, uint32_t b)
 {
@@ -1056,66 +1134,93 @@ __global__ void __launch_bounds__(256, NB == 2u ? 2 : 1) acc_intersections_mfma_
                 for (uint32_t g = 0; g < 4u; g++) {
                     const uint32_t c0 = (uint32_t)acc[a][b][4 * g], c1 = (uint32_t)acc[a][b][4 * g + 1];
                     const uint32_t c2 = (uint32_t)acc[a][b][4 * g + 2], c3 = (uint32_t)acc[a][b][4 * g + 3];
-                    __builtin_nontemporal_store(ps_da_u32x2{ c0 | (c1 << 16), c2 | (c3 << 16) }, (ps_da_u32x2 *)(row + 32u * a + 8u * g));
+                    // (plain stores: a 128-byte line of In is made of 16 such 8-byte pieces from 8 store instructions of this
+                    // wave, and only the L2 merges them -- as nontemporal stores every piece went to memory on its own: 29.6 ms
+                    // for the whole population against 9.5)
+                    *(ps_da_u32x2 *)(row + 32u * a + 8u * g) = ps_da_u32x2{ c0 | (c1 << 16), c2 | (c3 << 16) };
                 }
         }
     }
 }
 
 // phase 2 (see above).  Counts of rows [i_lo, i_lo + i_cnt) against all N columns; out[i] for those rows only.
-#define PS_AC_IB 16u
+// Workgroup = 32 individuals, FIVE waves: waves 0..3 stage (every thread turns 8 consecutive j of one individual into
+// distances per chunk: one 16-byte load of counts), wave 4 does nothing but the fold (32 lanes: one running sum each), so that
+// the chain of dependent additions -- the one serial thing here -- shares its wave with no division.  Two chunks of counts
+// are in flight.  (Built for 128 VGPRs: this kernel runs with phase 1, ahead of the sweep, not beside it.)
+#define PS_AC_IB 32u
 #define PS_AC_JB 64u
+#define PS_AC_THREADS 320u
 template <bool FAST>
-__global__ void __launch_bounds__(256, 8) acc_average_from_counts_kernel(const uint16_t *In, uint32_t ld, const uint32_t *rowcnt, uint32_t N,
-                                                                         uint32_t i_lo, uint32_t i_cnt, double core_genes, uint32_t cg_int,
-                                                                         double *out)
+__global__ void __launch_bounds__(PS_AC_THREADS, 2) acc_average_from_counts_kernel(const uint16_t *In, uint32_t ld, const uint32_t *rowcnt, uint32_t N,
+                                                                                   uint32_t i_lo, uint32_t i_cnt, double core_genes, uint32_t cg_int,
+                                                                                   double *out)
 {
     __shared__ double S[2][PS_AC_JB * (PS_AC_IB + 1u)];
     const uint32_t tid = threadIdx.x, i0 = blockIdx.x * PS_AC_IB;       // (relative to the shard)
-    const uint32_t ii = tid >> 4, jq = tid & 15u;                       // this thread turns 4 consecutive j of individual i0 + ii into distances
     const uint32_t nch = (N + PS_AC_JB - 1u) / PS_AC_JB;
-    const bool live = i0 + ii < i_cnt;
-    const uint32_t ci = live ? rowcnt[i_lo + i0 + ii] : 0u;
-    const uint16_t *src = In + (size_t)(i0 + ii) * ld + 4u * jq;
-    ps_da_u32x2 raw;
-    uint4 cj;
-    auto load = [&](uint32_t c) {
-        // (In has ld >= Npad columns and rowcnt Npad entries: no edge in the loads; rows past N are skipped by the fold)
-        raw = live ? __builtin_nontemporal_load((const ps_da_u32x2 *)(src + c * PS_AC_JB)) : ps_da_u32x2{ 0u, 0u };
-        cj = *(const uint4 *)(rowcnt + c * PS_AC_JB + 4u * jq);
-    };
-    auto park = [&](uint32_t buf) {
-        const uint32_t in[4] = { raw.x & 0xffffu, raw.x >> 16, raw.y & 0xffffu, raw.y >> 16 };
-        const uint32_t cjv[4] = { cj.x, cj.y, cj.z, cj.w };
-#pragma unroll
-        for (uint32_t q = 0; q < 4u; q++)
-            S[buf][(4u * jq + q) * (PS_AC_IB + 1u) + ii] = ps_da_distance<FAST>(in[q], ci + cjv[q] - in[q], core_genes, cg_int);
-    };
-    load(0u);
-    park(0u);
-    __syncthreads();
-    double sum = 0.0;
-    const uint32_t i = i_lo + i0 + tid;          // (threads 0..15 fold)
-    for (uint32_t c = 0; c < nch; c++) {
-        const uint32_t buf = c & 1u;
-        if (c + 1u < nch) load(c + 1u);
-        if (tid < PS_AC_IB) {
-            // 16 LDS reads ahead of their 16 dependent additions (the j == i term is skipped, population.rs:126-128)
-            for (uint32_t jj = 0; jj < PS_AC_JB; jj += 16u) {
-                double w[16];
-#pragma unroll
-                for (uint32_t u = 0; u < 16u; u++) w[u] = S[buf][(jj + u) * (PS_AC_IB + 1u) + tid];
-#pragma unroll
-                for (uint32_t u = 0; u < 16u; u++) {
-                    const uint32_t j = c * PS_AC_JB + jj + u;
-                    if (j < N && j != i) sum = sum + w[u];
-                }
+    const bool folder = tid >= 256u;                                    // (wave-uniform)
+    if (!folder) {
+        const uint32_t ii = tid >> 3, jq = tid & 7u;                    // 8 consecutive j of individual i0 + ii per chunk
+        const bool live = i0 + ii < i_cnt;
+        const uint32_t ci = live ? rowcnt[i_lo + i0 + ii] : 0u;
+        const uint16_t *src = In + (size_t)(i0 + ii) * ld + 8u * jq;
+        uint4 raw0, raw1, cja0, cjb0, cja1, cjb1;
+        auto load = [&](uint32_t c, uint4 &raw, uint4 &cja, uint4 &cjb) {
+            // (In has ld >= Npad columns and rowcnt Npad entries: no edge in the loads; rows past N are skipped by the fold)
+            if (live) {
+                const ps_u32x4_acc v = __builtin_nontemporal_load((const ps_u32x4_acc *)(src + c * PS_AC_JB));
+                raw = make_uint4(v.x, v.y, v.z, v.w);
+            } else {
+                raw = make_uint4(0u, 0u, 0u, 0u);
             }
+            cja = *(const uint4 *)(rowcnt + c * PS_AC_JB + 8u * jq);
+            cjb = *(const uint4 *)(rowcnt + c * PS_AC_JB + 8u * jq + 4u);
+        };
+        auto park = [&](double *Sb, const uint4 &raw, const uint4 &cja, const uint4 &cjb) {
+            const uint32_t in[8] = { raw.x & 0xffffu, raw.x >> 16, raw.y & 0xffffu, raw.y >> 16, raw.z & 0xffffu, raw.z >> 16, raw.w & 0xffffu, raw.w >> 16 };
+            const uint32_t cjv[8] = { cja.x, cja.y, cja.z, cja.w, cjb.x, cjb.y, cjb.z, cjb.w };
+#pragma unroll
+            for (uint32_t q = 0; q < 8u; q++)
+                Sb[(8u * jq + q) * (PS_AC_IB + 1u) + ii] = ps_da_distance<FAST>(in[q], ci + cjv[q] - in[q], core_genes, cg_int);
+        };
+        load(0u, raw0, cja0, cjb0);
+        if (nch > 1u) load(1u, raw1, cja1, cjb1);
+        park(S[0], raw0, cja0, cjb0);
+        if (nch > 2u) load(2u, raw0, cja0, cjb0);                   // (set 0 is free again)
+        ps_acc_sync_lds();
+        // chunk c sits in S[c & 1]; the counts of chunk c + 1 are in set (c + 1) & 1, which then takes chunk c + 3
+        uint32_t c = 0;
+        for (; c + 1u < nch; c += 2u) {
+            park(S[1], raw1, cja1, cjb1);
+            if (c + 3u < nch) load(c + 3u, raw1, cja1, cjb1);
+            ps_acc_sync_lds();
+            if (c + 2u < nch) park(S[0], raw0, cja0, cjb0);
+            if (c + 4u < nch) load(c + 4u, raw0, cja0, cjb0);
+            ps_acc_sync_lds();
         }
-        if (c + 1u < nch) park(buf ^ 1u);
-        __syncthreads();
+        return;
     }
-    if (tid < PS_AC_IB && i0 + tid < i_cnt && i < N) {
+    const uint32_t lane = tid - 256u;            // the fold wave: lanes 0..31 hold one running sum each
+    const uint32_t i = i_lo + i0 + lane, ib = i_lo + i0;
+    double sum = 0.0;
+    auto fold = [&](uint32_t c, const double *Sb) {
+        if (lane < PS_AC_IB) {
+            const uint32_t jb = c * PS_AC_JB;
+            const bool need_mask = jb + PS_AC_JB > N || (jb < ib + PS_AC_IB && jb + PS_AC_JB > ib);
+            sum = ps_da_fold_chunk<PS_AC_JB, PS_AC_IB + 1u>(Sb, lane, sum, jb, N, i, need_mask);
+        }
+    };
+    ps_acc_sync_lds();                           // (chunk 0 is parked)
+    uint32_t c = 0;
+    for (; c + 1u < nch; c += 2u) {
+        fold(c, S[0]);
+        ps_acc_sync_lds();
+        fold(c + 1u, S[1]);
+        ps_acc_sync_lds();
+    }
+    if (c < nch) fold(c, S[0]);
+    if (lane < PS_AC_IB && i0 + lane < i_cnt && i < N) {
         double fd = sum / (double)(N - 1u);
         if (fd == 0.0) fd = 2.2250738585072014e-308;    // f64::MIN_POSITIVE, population.rs:774-776
         out[i] = fd;

@@ -199,6 +199,7 @@ struct ps_population {
     int32_t *fuse_counts_out = nullptr;
     double *fuse_logw_out = nullptr;
     bool counts_fresh = false;
+    uint64_t edit_epoch = 0;         // bumped by every edit of the matrix (load, generation step, HGT): what a cached result was computed from
     uint64_t *I[2] = { nullptr, nullptr };
     uint32_t *d_ptab[PS_MAX_COMP] = {};  // Poisson threshold tables of the HGT event counts (ps_set_rates)
     uint32_t ptab_kmin[PS_MAX_COMP] = {}, ptab_len[PS_MAX_COMP] = {};
@@ -576,6 +577,7 @@ extern "C" int ps_load_matrix(ps_population *p, const uint8_t *rows)
                                                                               p->d);
         p->g_valid = false;
         p->counts_fresh = false;
+        p->edit_epoch++;
     }
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(p->stream));
@@ -979,6 +981,7 @@ static int launch_acc_step(ps_population *p, const uint32_t *d_idx, uint32_t gen
     p->cur = 1 - p->cur;
     p->g_valid = false;
     p->counts_fresh = false;
+    p->edit_epoch++;
     return PS_OK;
 }
 
@@ -1216,6 +1219,7 @@ static int launch_acc_hgt(ps_population *p, uint32_t gen, hipStream_t st, hipEve
     if (record_after_apply) HIPCHK(hipEventRecord(record_after_apply, st));      // (light form under a forced turn-taking schedule; sharded runs)
     p->g_valid = false;       // only the individual-major view is edited (ensure_gene_major)
     p->counts_fresh = counts_left;
+    p->edit_epoch++;
     return PS_OK;
 }
 
@@ -1565,7 +1569,11 @@ static int average_distance_device(ps_population *p, double *d_out, hipStream_t 
     // 3 = matrix cores in two phases (round 5: contraction on every SIMD -> u16 counts -> division + ordered fold)
     const bool whole = i_lo == 0 && i_cnt == N;
     const bool mfma = p->d.G > 0 && N >= 2 && (p->davg_form >= 2 || !whole || (p->davg_form == 0 && N > 8192));
-    const bool two_phase = mfma && p->davg_form != 2 && p->d.G <= 65535;      // (u16 counts)
+    // Choice between the two matrix-core forms (davg_form 0): the one-kernel form needs 32 NB rows per wave for the whole
+    // fold, so below ~48 K rows it leaves SIMDs idle (a rank of 8 at N = 65536: 7.6 ms for 8192 rows) and the two-phase form
+    // wins (2.3 ms there; N = 16384 whole: 1.1 against 1.96 ms); with 65536 rows in one launch the one-kernel form's fused
+    // epilogue is cheaper than 8.6 GB of counts written and read back (11.1 against 12-15 ms)
+    const bool two_phase = mfma && p->davg_form != 2 && p->d.G <= 65535 && (p->davg_form == 3 || i_cnt < 49152);      // (u16 counts)
     if (mfma) {
         const uint32_t WP = (2u * p->d.GW + 7u) & ~7u, Npad = (uint32_t)((N + 127) & ~127ull);
         const uint64_t need = (uint64_t)Npad * WP * 4 + (uint64_t)Npad * 4 + 64;
@@ -1586,7 +1594,7 @@ static int average_distance_device(ps_population *p, double *d_out, hipStream_t 
             // phase 1 (contraction, every SIMD) -> u16 counts In[row][j]; phase 2 (division + the ordered fold).  Rows in
             // bands so that the scratch stays below ~9 GB (N = 65536 whole: one band of 8.6 GB)
             // (row pitch of the counts: Npad u16 + 256 bytes -- with a power-of-two pitch the 32 rows one store instruction
-            // touches, and the 16 rows a phase-2 workgroup reads, fall on ONE memory channel: 33.7 ms instead of TODO at N = 65536)
+            // touches, and the 16 rows a phase-2 workgroup reads, fall on ONE memory channel)
             const uint32_t nb = p->davg_nb ? p->davg_nb : 2u, ld = Npad + 128u;
             uint64_t band = std::min<uint64_t>((i_cnt + 63) & ~63ull, std::max<uint64_t>(256, ((9ull << 30) / ((uint64_t)ld * 2)) & ~255ull));
             const uint64_t need_in = band * ld * 2;
@@ -1614,9 +1622,9 @@ static int average_distance_device(ps_population *p, double *d_out, hipStream_t 
                 }
                 const uint32_t g2 = (rows + PS_AC_IB - 1u) / PS_AC_IB;
                 if (fast)
-                    acc_average_from_counts_kernel<true><<<g2, 256, 0, st>>>(In, ld, rowcnt, (uint32_t)N, lo, rows, (double)p->cfg.core_genes, cgi, d_out);
+                    acc_average_from_counts_kernel<true><<<g2, PS_AC_THREADS, 0, st>>>(In, ld, rowcnt, (uint32_t)N, lo, rows, (double)p->cfg.core_genes, cgi, d_out);
                 else
-                    acc_average_from_counts_kernel<false><<<g2, 256, 0, st>>>(In, ld, rowcnt, (uint32_t)N, lo, rows, (double)p->cfg.core_genes, cgi, d_out);
+                    acc_average_from_counts_kernel<false><<<g2, PS_AC_THREADS, 0, st>>>(In, ld, rowcnt, (uint32_t)N, lo, rows, (double)p->cfg.core_genes, cgi, d_out);
             }
         } else {
         // 64 individuals per wave (two B fragments: fewer table reads per MFMA) when that still gives every SIMD a wave
@@ -2592,6 +2600,11 @@ struct ps_sim {
     int32_t *h_num_genes = nullptr, *m_num_genes = nullptr;   // pinned + its device alias
     double *h_logw = nullptr, *m_logw = nullptr, *h_avg = nullptr;
     double *d_avg = nullptr;
+    // D-avg of the NEXT generation computed ahead of the sweep (sim_one_generation): valid while the accessory matrix is the
+    // one it was computed from
+    bool avg_prefetched = false;
+    uint64_t avg_epoch = 0;
+    hipEvent_t ev_avg = nullptr;
     double *d_log1p = nullptr;          // ln(1 + s_g) of THIS run (the accessory handle's own table belongs to its Population API)
     uint64_t step_count = 0;
     bool need_logw = false;
@@ -2638,6 +2651,7 @@ extern "C" void ps_sim_destroy(ps_sim *s)
         if (s->ev_idx[k]) (void)hipEventDestroy(s->ev_idx[k]);
         if (s->ev_core[k]) (void)hipEventDestroy(s->ev_core[k]);
         if (k == 0 && s->ev_hgt) (void)hipEventDestroy(s->ev_hgt);
+        if (k == 0 && s->ev_avg) (void)hipEventDestroy(s->ev_avg);
         for (int j = 0; j < 2; j++) if (s->ev_gap[k][j]) (void)hipEventDestroy(s->ev_gap[k][j]);
     }
     if (s->h_num_genes) (void)hipHostFree(s->h_num_genes);
@@ -2847,7 +2861,9 @@ static int sim_host_weights(ps_sim *s, uint32_t gen, double *w, bool avg_ready =
     auto ms_since = [](clk::time_point t0) { return std::chrono::duration<double, std::milli>(clk::now() - t0).count(); };
     for (uint64_t i = 0; i < N; i++) s->h_avg[i] = 1.0;                 // main.rs:435
     if (p.competition_strength > 0.0) {                                  // :438-440
-        if (!avg_ready) PSCHK(sim_average_distance(s));
+        const bool ahead = s->avg_prefetched && s->avg_epoch == acc->edit_epoch;       // (computed before the previous sweep was launched)
+        if (!avg_ready && !ahead) PSCHK(sim_average_distance(s));
+        s->avg_prefetched = false;
         HIPCHK(hipMemcpyAsync(s->h_avg, s->d_avg, N * sizeof(double), hipMemcpyDeviceToHost, sa));
     }
     if (s->need_logw)
@@ -2945,6 +2961,25 @@ static int sim_one_generation(ps_sim *s, uint32_t gen)
         HIPCHK(hipEventRecord(s->ev_hgt, sa));       // (recorded again after the LDS-image pass; this one covers an HGT that launches nothing)
         PSCHK(launch_acc_hgt(acc, gen, sa, s->slot_used[prev] ? s->ev_core[prev] : nullptr, s->ev_hgt));
         HIPCHK(hipStreamWaitEvent(sc, s->ev_hgt, 0));
+    }
+
+    // --competition_strength with a D-avg that cannot share a CU with the sweep (the matrix-core forms: wide populations and
+    // every row shard): D-avg of generation g + 1 needs the accessory matrix after HGT(g) and nothing of sweep(g), and its
+    // kernels would wait for sweep(g)'s END and head the whole chain of g + 1 behind it.  Run it NOW, ahead of sweep(g): the
+    // two take turns (D-avg is matrix-core work, the sweep HBM traffic) and the host half, the draw, the gather and the bin
+    // pass of g + 1 hide beside the sweep again (round 5: one rank of 8 at cfg4 + competition 10: 114 -> 141 generations/s; 41 in round 4).
+    {
+        const bool sharded_rows = acc->exchange && acc->donor_cnt != 0;
+        const bool big_davg = acc->d.G > 0 && N >= 2 && (sharded_rows || N > 8192 || acc->davg_form >= 2) && acc->davg_form != 1;
+        static const bool off = getenv("PANSIM_DAVG_AHEAD") && atoi(getenv("PANSIM_DAVG_AHEAD")) == 0;
+        if (!off && p.competition_strength > 0.0 && big_davg && (heavy_hgt || p.HGT_rate <= 0.0) && (int64_t)gen + 1 != (int64_t)p.n_gen) {      // (not behind the run's last generation)
+            PSCHK(sim_average_distance(s));
+            s->avg_prefetched = true;
+            s->avg_epoch = acc->edit_epoch;
+            if (!s->ev_avg) HIPCHK(hipEventCreateWithFlags(&s->ev_avg, hipEventDisableTiming));
+            HIPCHK(hipEventRecord(s->ev_avg, sa));
+            HIPCHK(hipStreamWaitEvent(sc, s->ev_avg, 0));
+        }
     }
 
     // main.rs:445, :452, :459-461 on the core stream, one fused pass
@@ -3432,7 +3467,8 @@ static int multi_weights(void *vctx, ps_sim *s, uint32_t gen, double *w)
     // D-avg sharded by rows over the shards like the HGT donors: every shard computes its rows and takes part in the exchange
     bool avg_ready = false;
     if (m->prm.competition_strength > 0.0 && s->acc->exchange && s->acc->donor_cnt != 0 && s->acc->d.G > 0) {
-        PSCHK(sim_average_distance(s));
+        // (every shard takes the same branch: the flags are set in lockstep by sim_one_generation)
+        if (!(s->avg_prefetched && s->avg_epoch == s->acc->edit_epoch)) PSCHK(sim_average_distance(s));
         avg_ready = true;
     }
     if (c->k == 0) {

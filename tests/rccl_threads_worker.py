@@ -3,7 +3,7 @@ tests/libfake_rccl.so (PANSIM_RCCL_LIBRARY) -- test infrastructure, started as a
 (the pytest process itself keeps the real librccl: a process resolves the RCCL symbols once).
 
     python tests/rccl_threads_worker.py raw K [ring]     ps_exchange_rccl on raw device buffers against the numpy OR
-    python tests/rccl_threads_worker.py sim K COMP       K site shards with sharded HGT donors inside ps_sim_run against
+    python tests/rccl_threads_worker.py sim K COMP [heavy]  K site shards with sharded HGT donors inside ps_sim_run against
                                                          the UNSHARDED oracle run (COMP = --competition_strength)
     python tests/rccl_threads_worker.py fail WHAT        one injected RCCL failure (PANSIM_FAKE_RCCL_FAIL) inside the exchange
 Prints one JSON line; exit code 0 iff everything matched."""
@@ -133,6 +133,7 @@ def sim(K, comp):
     for r in range(K):
         calls = C.c_uint64()
         _lib.check(lib.ps_rccl_exchange_stats(hs[r], 0, C.byref(calls), None))
+        # (D-avg computed ahead of the sweep: generation 0's at its own start, then one per generation but the run's last)
         assert calls.value == per_gen * gens, calls.value
     for s in sims:
         s.close()
@@ -171,6 +172,11 @@ if __name__ == "__main__":
             os.environ["PANSIM_RCCL_GATHER"] = sys.argv[3]      # "ring": ncclAllGather instead of the direct sends
         out = raw(int(sys.argv[2]))
     elif mode == "sim":
+        if len(sys.argv) > 4 and sys.argv[4] == "heavy":
+            # the binned HGT in its turn-taking schedule: with competition on, D-avg of generation g + 1 (row-sharded, its
+            # all-gather through the exchange) is computed AHEAD of sweep(g) -- two exchanges per generation in another order
+            os.environ["PANSIM_HEAVY_HGT"] = "1"
+            os.environ["PANSIM_HGT_MODE"] = "2"
         out = sim(int(sys.argv[2]), float(sys.argv[3]))
     else:
         out = fail(sys.argv[2])

@@ -374,3 +374,47 @@ def test_config5_full_size_distance_forms_agree(pa):
     assert np.array_equal(sim.last_parents(), parents)
     sim.close()
     assert np.array_equal(_shard_counts_sum(pa, kw, gens, 1 << 20, 8), got[0][:1 << 20].astype(np.uint64))
+
+
+@pytest.mark.parametrize("hgt,env", [(0.0, {}), (0.4, {"PANSIM_HEAVY_HGT": "1", "PANSIM_HGT_MODE": "2"})])
+def test_average_distance_ahead_of_the_sweep(pa, orc, monkeypatch, hgt, env):
+    # --competition_strength with a matrix-core D-avg (forced here with davg_form 3; the library's own choice for N > 8192 and
+    # for row shards): D-avg of generation g + 1 is computed right behind HGT(g) and AHEAD of sweep(g).  Same parents and
+    # matrices as the oracle whether the generations run in one call or one by one; and a matrix loaded between two calls
+    # must not be served the distances of the old one (the result carries the matrix's edit epoch)
+    from orc_sim import OracleSim
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    kw = dict(pop_size=700, core_size=900, pan_genes=420, core_genes=120, HR_rate=0.1, HGT_rate=hgt)
+    extra = dict(competition_strength=6.0, prop_positive=0.2)
+    gens = 7
+    ref = OracleSim(seed=12, **kw, **extra)
+    a = pa.Simulation(pa.make_params(seed=12, n_gen=gens, max_distances=100, **kw, **extra))
+    b = pa.Simulation(pa.make_params(seed=12, n_gen=gens, max_distances=100, **kw, **extra))
+    for s in (a, b):
+        s.pan_genome.set_tuning("davg_form", 3)
+    a.run(4)
+    a.sync()
+    for g in range(4):
+        b.run(1)
+        b.sync()
+        ref.generation(g)
+        assert np.array_equal(b.last_parents(), ref.last_idx), "generation %d" % g
+    assert np.array_equal(a.last_parents(), ref.last_idx)
+    assert np.array_equal(a.pan_genome.read_matrix(), ref.acc) and np.array_equal(b.pan_genome.read_matrix(), ref.acc)
+    # another matrix arrives between two generations: the distances computed ahead belong to the old one
+    rng = np.random.default_rng(5)
+    m = (rng.random(ref.acc.shape) < 0.4).astype(np.uint8)
+    for s in (a, b):
+        s.pan_genome.load_matrix(m)
+    ref.acc = m.copy()
+    for g in range(4, gens):
+        a.run(1)
+        b.run(1)
+        ref.generation(g)
+        assert np.array_equal(a.last_parents(), ref.last_idx), "generation %d" % g
+        assert np.array_equal(b.last_parents(), ref.last_idx), "generation %d" % g
+    assert np.array_equal(a.pan_genome.read_matrix(), ref.acc)
+    assert np.array_equal(a.core_genome.read_matrix(), ref.core)
+    a.close()
+    b.close()

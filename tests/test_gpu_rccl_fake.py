@@ -36,11 +36,12 @@ def test_exchange_rccl_raw_buffers(K, gather):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("K,comp", [(2, 0.0), (3, 0.0), (8, 0.0), (3, 4.0), (8, 2.5)])
-def test_exchange_rccl_inside_the_generation_loop(K, comp):
+@pytest.mark.parametrize("K,comp,hgt", [(2, 0.0, ""), (3, 0.0, ""), (8, 0.0, ""), (3, 4.0, ""), (8, 2.5, ""), (3, 4.0, "heavy"), (2, 0.0, "heavy")])
+def test_exchange_rccl_inside_the_generation_loop(K, comp, hgt):
     # K site shards, HGT donors sharded K ways, (comp > 0: D-avg sharded by rows too): core shards, accessory matrix and
-    # parents of every rank equal the unsharded oracle run
-    out = _worker("sim", K, comp)
+    # parents of every rank equal the unsharded oracle run.  "heavy": the binned HGT taking turns with the sweep, and with
+    # competition D-avg of the next generation computed ahead of the sweep
+    out = _worker("sim", K, comp, *([hgt] if hgt else []))
     assert out["K"] == K and out["generations"] == 3
 
 
