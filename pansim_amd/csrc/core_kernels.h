@@ -30,6 +30,7 @@ struct core_sweep_args {
     uint32_t launch_parity;    // which counter set this launch uses
     uint32_t nt;               // out-of-place form: nontemporal row loads / stores (every byte is touched once per launch)
     uint32_t qcap_limit;       // tests: pretend the candidate queues / HR lists hold only this many entries (0 = their real size)
+    uint32_t *wide_flags;      // window sweep: [(generation & 1) * 32] != 0 iff the first launch met a segment for the second one
     uint32_t gate_chunks;      // window sweep, experiment (PANSIM_WINDOW_GATE): a wave waits while its chunk is more than this many
                                // chunks ahead of the slowest segment of its XCD group (0 = no gate)
 };
@@ -654,6 +655,16 @@ __global__ void __launch_bounds__(256, PS_WLB) core_sweep_window_kernel(core_swe
     const uint32_t grp = blockIdx.x & 7u;
     const uint32_t wg = __builtin_amdgcn_readfirstlane((blockIdx.x >> 3) * 4u + wave);     // wave index inside its group
     const uint32_t sg = wg % segs;
+    // this launch zeroes the chunk counters of the next one (two sets alternate by launch parity) ...
+    if (wg < segs && lane == 0) a.work_ctr[(((a.launch_parity ^ 1u) * 8u + grp) * segs + wg) * 32u] = 0u;
+    // ... and the second launch (WIDE) leaves here unless the first one met a segment for it (one flag per generation
+    // parity, cleared a generation ahead): under drift there is none, and 7168 waves each reading their window bounds and 16
+    // parent indices just to find that out cost 31 us between two sweeps
+    if (WIDE) {
+        if (__builtin_amdgcn_readfirstlane(a.wide_flags[(a.gen & 1u) * 32u]) == 0u) return;
+    } else if (blockIdx.x == 0 && threadIdx.x == 0) {
+        a.wide_flags[((a.gen + 1u) & 1u) * 32u] = 0u;
+    }
     const uint32_t c_first = sg * 1024u, c_last = min(c_first + 1023u, a.N - 1u);
     const uint32_t chunk = sg * 64u + lane;                 // the lane's 16-cell chunk of the row (Philox counter word)
     const bool has_chunk = chunk < a.cpr;
@@ -689,8 +700,10 @@ __global__ void __launch_bounds__(256, PS_WLB) core_sweep_window_kernel(core_swe
     const uint32_t batches = (a.rows + PS_ROWS - 1u) / PS_ROWS;
     const uint32_t b_lo = (uint32_t)((uint64_t)batches * grp / 8u), b_hi = (uint32_t)((uint64_t)batches * (grp + 1u) / 8u);
     uint32_t *ctr = a.work_ctr + ((a.launch_parity * 8u + grp) * segs + sg) * 32u;
-    if (wg < segs && lane == 0) a.work_ctr[(((a.launch_parity ^ 1u) * 8u + grp) * segs + wg) * 32u] = 0u;
-    if (wide != WIDE) return;                               // the segment belongs to the other launch (no workgroup barriers here)
+    if (wide != WIDE) {                                     // the segment belongs to the other launch (no workgroup barriers here)
+        if (!WIDE && lane == 0) a.wide_flags[(a.gen & 1u) * 32u] = 1u;
+        return;
+    }
     uint32_t next_chunk = 0;
     if (lane == 0) next_chunk = __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #ifdef PS_WINDOW_GATE

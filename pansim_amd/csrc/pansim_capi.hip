@@ -199,6 +199,7 @@ struct ps_population {
     int32_t *fuse_counts_out = nullptr;
     double *fuse_logw_out = nullptr;
     bool counts_fresh = false;
+    hipStream_t stream_of_call = nullptr;   // launch_acc_hgt: its caller's stream
     uint64_t edit_epoch = 0;         // bumped by every edit of the matrix (load, generation step, HGT): what a cached result was computed from
     uint64_t *I[2] = { nullptr, nullptr };
     uint32_t *d_ptab[PS_MAX_COMP] = {};  // Poisson threshold tables of the HGT event counts (ps_set_rates)
@@ -229,6 +230,7 @@ struct ps_population {
     uint32_t *d_idx = nullptr;       // N parents
     uint32_t *d_idxT = nullptr;      // transposed parents for the block sweep (16 x cpr)
     uint32_t *d_work = nullptr;      // wave sweep: chunk counters (2 sets x 8 x 128 bytes)
+    uint32_t work_flags_ofs = 0;     // dword offset of the window sweep's two wide-segment flags behind the counters
     uint64_t sweep_launches = 0;     // parity selects the counter set
     uint64_t window_launches = 0;    // the same for the window sweep's per-segment counters
     double *d_log1p = nullptr;       // G
@@ -367,8 +369,10 @@ static int pop_create_impl(const ps_config *cfg, const uint8_t *init_vec, ps_pop
             // chunk counters of the dynamic row assignment: 2 sets (alternating by launch) x 8 groups (wave sweep) or
             // x one per 1024-child segment (window sweep), 128 bytes apart
             const uint64_t nctr = 8 * std::max<uint64_t>(1, std::min<uint64_t>((N + 1023) / 1024, 4096));      // (window sweep: N <= 2^22)
-            HIPCHK(hipMalloc(&p->d_work, 2 * nctr * 128));
-            HIPCHK(hipMemsetAsync(p->d_work, 0, 2 * nctr * 128, p->stream));
+            // (+ 256 bytes: the window sweep's two "a segment needs the second launch" flags)
+            HIPCHK(hipMalloc(&p->d_work, 2 * nctr * 128 + 256));
+            HIPCHK(hipMemsetAsync(p->d_work, 0, 2 * nctr * 128 + 256, p->stream));
+            p->work_flags_ofs = (uint32_t)(2 * nctr * 32);
         }
         if (C) {
             const uint64_t total = C * p->cpr;
@@ -920,6 +924,7 @@ static int launch_core_sweep(ps_population *p, const uint32_t *d_idx, uint32_t g
     a.gate_chunks = 0;
     a.stamps = p->d_stamps;
     a.work_ctr = p->d_work;
+    a.wide_flags = p->d_work + p->work_flags_ofs;
     a.launch_parity = (uint32_t)(p->sweep_launches++ & 1u);
     a.idxT = p->d_idxT;
     p->last_sweep_form = window ? PS_SWEEP_FORM_WINDOW
@@ -1027,10 +1032,17 @@ static bool hgt_takes_binned_form(const ps_population *p)
 // wait_before_apply / record_after_apply: the turn-taking of a heavy HGT with the core sweep (ps_sim) -- the LDS-image pass
 // waits for the previous sweep, and the next sweep waits for it: not for the reduce pass behind it, a small streaming
 // kernel that fits beside a sweep (nor, in a donor-sharded run, for the exchange and the merge that follow)
+// st_gap / ev_bin (round 5, ps_sim's turn-taking schedule): the passes that sit BETWEEN two sweeps -- the LDS-image pass, and in
+// a donor-sharded run the reduce pass, the exchange and the merge as well -- are launched on the sweep's own stream, in order
+// with the sweeps, instead of being tied to them by two cross-stream events (a stream that waits for another stream's event
+// starts 20 - 50 us after it fired: twice per generation, 22 + 6 of cfg3's 92 us between sweeps, 54 + 7 of 577 at one rank of 8
+// at cfg4).  Only the bin pass, which runs beside the sweep, stays on `st`; st_gap waits for it (ev_bin), and `st` waits for
+// record_after_apply, recorded on st_gap behind the last of them.
 static int launch_acc_hgt(ps_population *p, uint32_t gen, hipStream_t st, hipEvent_t wait_before_apply = nullptr,
-                          hipEvent_t record_after_apply = nullptr)
+                          hipEvent_t record_after_apply = nullptr, hipStream_t st_gap = nullptr, hipEvent_t ev_bin = nullptr)
 {
     if (p->d.G == 0 || p->d.N < 2) return PS_OK;
+    p->stream_of_call = st;          // (the stream the accessory chain continues on, whatever stream the gap passes take)
     bool counts_left = false;
     acc_hgt_args a{};
     a.n_comp = (uint32_t)p->aplan.n_comp;
@@ -1144,18 +1156,27 @@ static int launch_acc_hgt(ps_population *p, uint32_t gen, hipStream_t st, hipEve
         if (dlds > 64 * 1024)
             HIPCHK(hipFuncSetAttribute((const void *)acc_hgt_donor_bin_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dlds));
         hipLaunchKernelGGL(acc_hgt_donor_bin_kernel, dim3(donor_blocks), dim3(256), dlds, st, a);
-        if (wait_before_apply) HIPCHK(hipStreamWaitEvent(st, wait_before_apply, 0));
+        const bool in_gap = st_gap && ev_bin && record_after_apply && !p->exchange_beside_sweep;
+        hipStream_t run = st;            // where the passes between two sweeps go
+        if (in_gap) {
+            HIPCHK(hipEventRecord(ev_bin, st));
+            HIPCHK(hipStreamWaitEvent(st_gap, ev_bin, 0));
+            run = st_gap;                // (in order behind the previous sweep: no wait_before_apply)
+        } else if (wait_before_apply) HIPCHK(hipStreamWaitEvent(st, wait_before_apply, 0));
         auto kern = acc_hgt_apply_kernel;
         if (lds > 64 * 1024)
             HIPCHK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(kern, dim3(parts * n_slices), dim3(p->hgt_apply_threads), lds, st, a, donor_blocks, n_slices);
-        // (a donor-sharded run keeps the sweep behind the exchange and the merge as well: the copies / collective kernels of
-        // an exchange do not fit beside the sweep's 7 workgroups per CU -- they would wait for its END, and with them the
-        // whole chain of the next generation: measured with the emulated exchange, 0.9 -> 1.6 ms exposed per generation)
+        hipLaunchKernelGGL(kern, dim3(parts * n_slices), dim3(p->hgt_apply_threads), lds, run, a, donor_blocks, n_slices);
+        // (a donor-sharded run keeps the sweep behind the exchange and the merge as well: the kernels of an exchange do not
+        // fit beside the sweep's 7 workgroups per CU -- RCCL's need 264 registers per lane -- they would wait for its END, and
+        // with them the whole chain of the next generation)
         if (record_after_apply && (!sharded || p->exchange_beside_sweep)) {
-            HIPCHK(hipEventRecord(record_after_apply, st));
+            HIPCHK(hipEventRecord(record_after_apply, run));
+            if (in_gap) HIPCHK(hipStreamWaitEvent(st, record_after_apply, 0));      // the reduce pass, beside the next sweep, on st
             record_after_apply = nullptr;
+            run = st;
         }
+        st = run;                        // (sharded: reduce, exchange and merge follow the LDS-image pass on its stream)
         if (!sharded && p->fuse_counts_out) {
             // (ps_sim, neutral selection: the reduce pass also leaves the gene counts the next generation's host half reads)
             acc_hgt_reduce_rows_kernel<<<(uint32_t)((p->d.N + 3) / 4), 256, 0, st>>>((const uint64_t *)p->hgt_scratch, p->I[p->cur], p->d,
@@ -1216,7 +1237,10 @@ static int launch_acc_hgt(ps_population *p, uint32_t gen, hipStream_t st, hipEve
         acc_or_kernel<<<(uint32_t)((mat_words + 255) / 256), 256, 0, st>>>(p->I[p->cur], p->d_delta, mat_words);
         HIPCHK(hipGetLastError());
     }
-    if (record_after_apply) HIPCHK(hipEventRecord(record_after_apply, st));      // (light form under a forced turn-taking schedule; sharded runs)
+    if (record_after_apply) {        // (light form under a forced turn-taking schedule; sharded runs)
+        HIPCHK(hipEventRecord(record_after_apply, st));
+        if (st != p->stream_of_call) HIPCHK(hipStreamWaitEvent(p->stream_of_call, record_after_apply, 0));     // (the gap stream carried the merge)
+    }
     p->g_valid = false;       // only the individual-major view is edited (ensure_gene_major)
     p->counts_fresh = counts_left;
     p->edit_epoch++;
@@ -1419,7 +1443,8 @@ static void softmax_norm(double *v, uint64_t n, std::vector<double> &scratch)
     // exp arguments of the streaming form: they depend on the running maximum only
     scratch.resize(n);
     double *arg = scratch.data();
-    std::vector<uint8_t> upd(n);
+    static thread_local std::vector<uint8_t> upd;
+    upd.resize(n);
     double alpha = -INFINITY;
     for (uint64_t i = 0; i < n; i++) {
         if (v[i] <= alpha) { arg[i] = v[i] - alpha; upd[i] = 0; }
@@ -1445,7 +1470,11 @@ extern "C" int ps_sample_weights(const int32_t *num_genes, const double *logw, u
 {
     if (!num_genes || !logw || !avg_pairwise_dists || !weights || n == 0)
         return ps_fail(PS_ERR_INVALID, "null argument");
-    std::vector<double> sel(n, 1.0), tmp(n), scratch;              // population.rs:293
+    // (work vectors kept per thread: four 512 KB allocations per call at N = 65536 were page-faulted in every generation, on
+    // the chain that has to fit beside the sweep)
+    static thread_local std::vector<double> sel, tmp, scratch;
+    sel.assign(n, 1.0);                                            // population.rs:293
+    tmp.resize(n);
     if (n_genes > 0) {                                             // :296
         for (uint64_t i = 0; i < n; i++) sel[i] = logw[i];
         softmax_norm(sel.data(), n, scratch);                      // :325-340
@@ -1466,8 +1495,9 @@ extern "C" int ps_sample_weights(const int32_t *num_genes, const double *logw, u
             const double t = competition_strength * std::log(avg_pairwise_dists[0]);
             for (uint64_t i = 0; i < n; i++) tmp[i] = t;
         } else {
-            par_for(n, [&](uint64_t a, uint64_t b) {
-                for (uint64_t i = a; i < b; i++) tmp[i] = competition_strength * std::log(avg_pairwise_dists[i]);
+            double *tp = tmp.data();          // (tmp is thread local: the workers must not name it)
+            par_for(n, [&, tp](uint64_t a, uint64_t b) {
+                for (uint64_t i = a; i < b; i++) tp[i] = competition_strength * std::log(avg_pairwise_dists[i]);
             });
         }
     }
@@ -2605,6 +2635,8 @@ struct ps_sim {
     bool avg_prefetched = false;
     uint64_t avg_epoch = 0;
     hipEvent_t ev_avg = nullptr;
+    std::vector<double> h_w;         // the weights of the generation being drawn (kept: no allocation per generation)
+    hipEvent_t ev_bin = nullptr;     // the bin pass of the binned HGT is complete (the LDS-image pass on the core stream waits for it)
     double *d_log1p = nullptr;          // ln(1 + s_g) of THIS run (the accessory handle's own table belongs to its Population API)
     uint64_t step_count = 0;
     bool need_logw = false;
@@ -2652,6 +2684,7 @@ extern "C" void ps_sim_destroy(ps_sim *s)
         if (s->ev_core[k]) (void)hipEventDestroy(s->ev_core[k]);
         if (k == 0 && s->ev_hgt) (void)hipEventDestroy(s->ev_hgt);
         if (k == 0 && s->ev_avg) (void)hipEventDestroy(s->ev_avg);
+        if (k == 0 && s->ev_bin) (void)hipEventDestroy(s->ev_bin);
         for (int j = 0; j < 2; j++) if (s->ev_gap[k][j]) (void)hipEventDestroy(s->ev_gap[k][j]);
     }
     if (s->h_num_genes) (void)hipHostFree(s->h_num_genes);
@@ -2898,7 +2931,8 @@ static int sim_one_generation(ps_sim *s, uint32_t gen)
     s->host_wait_ms += ms_since(th0);
     // main.rs:435-443: the weights of sample_indices -- from this shard's own replica of the accessory matrix, or (several
     // shards in one process) computed once by shard 0 and handed to the others, whose replicas are bit-identical
-    std::vector<double> w(N);
+    std::vector<double> &w = s->h_w;
+    w.resize(N);
     if (s->weights_hook) PSCHK(s->weights_hook(s->weights_ctx, s, gen, w.data()));
     else PSCHK(sim_host_weights(s, gen, w.data()));
     th0 = clk::now();
@@ -2959,8 +2993,12 @@ static int sim_one_generation(ps_sim *s, uint32_t gen)
         // only the LDS-image passes (apply, reduce) wait for the previous sweep: the bin pass -- LDS-local
         // gathers, streaming appends -- runs beside its tail (cfg3: 1359 -> 1411 generations/s)
         HIPCHK(hipEventRecord(s->ev_hgt, sa));       // (recorded again after the LDS-image pass; this one covers an HGT that launches nothing)
-        PSCHK(launch_acc_hgt(acc, gen, sa, s->slot_used[prev] ? s->ev_core[prev] : nullptr, s->ev_hgt));
-        HIPCHK(hipStreamWaitEvent(sc, s->ev_hgt, 0));
+        // (measured, not kept as the default: cfg3 exposed 0.092 / 0.094 against 0.087 / 0.092 ms, one rank of 8 at cfg4 0.69 / 0.63 against
+        // 0.66 / 0.66 -- what sits between two sweeps is the bin pass finishing late, not the event latency; profiles/r05_sweep_experiments.md 8)
+        static const bool gap_on_core = getenv("PANSIM_GAP_ON_CORE_STREAM") && atoi(getenv("PANSIM_GAP_ON_CORE_STREAM")) != 0;
+        if (gap_on_core && !s->ev_bin) HIPCHK(hipEventCreateWithFlags(&s->ev_bin, hipEventDisableTiming));
+        PSCHK(launch_acc_hgt(acc, gen, sa, s->slot_used[prev] ? s->ev_core[prev] : nullptr, s->ev_hgt, gap_on_core ? sc : nullptr, s->ev_bin));
+        HIPCHK(hipStreamWaitEvent(sc, s->ev_hgt, 0));      // (a no-op when the event was recorded on sc itself)
     }
 
     // --competition_strength with a D-avg that cannot share a CU with the sweep (the matrix-core forms: wide populations and

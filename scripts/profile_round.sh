@@ -20,8 +20,10 @@ run cfg4 python3 $REPO/bench.py --config cfg4 --no-cpu-baseline --steps 10 --war
 run cfg4_shard8 python3 $REPO/bench.py --config cfg4_shard8 --no-cpu-baseline --steps 20 --warmup 2
 run cfg5pop python3 $REPO/bench.py --config cfg5pop --no-cpu-baseline --steps 10 --warmup 2
 run competition python3 $REPO/bench.py --no-cpu-baseline --no-other-configs --competition_strength 10 --steps 100 --warmup 10
+run authors python3 $REPO/bench.py --config authors --no-cpu-baseline --steps 100 --warmup 10
+run cfg4_shard8_comp10 python3 $REPO/bench.py --config cfg4_shard8 --no-cpu-baseline --competition_strength 10 --steps 20 --warmup 2
 run cfg5cli $REPO/pansim_amd/pansim --pop_size 8192 --max_distances 33554432 --n_gen 3 --outpref /tmp/cfg5_prof
 rm -f /tmp/cfg5_prof*
 cd $REPO
-for n in cfg2 cfg3 cfg4 cfg4_shard8 cfg5pop competition; do tail -1 $OUT/$n.out > $OUT/${n}_bench.json; done
+for n in cfg2 cfg3 cfg4 cfg4_shard8 cfg5pop competition authors cfg4_shard8_comp10; do tail -1 $OUT/$n.out > $OUT/${n}_bench.json; done
 ls -la $OUT | head -40
