@@ -283,6 +283,9 @@ __global__ void __launch_bounds__(64) acc_hgt_donor_wave_kernel(acc_hgt_args a)
 // bins[(b * parts + part) * cap ...]; the position comes from a per-lane LDS atomic on the
 // workgroup's fill counters (parts * 4 bytes of LDS).  (Wave-aggregated appends -- one ballot per
 // partition -- were slower than one LDS atomic per lane even with 4 partitions.)
+#ifndef PS_HGT_BIN_BLOCKS
+#define PS_HGT_BIN_BLOCKS 2u
+#endif
 __global__ void __launch_bounds__(256) acc_hgt_donor_bin_kernel(acc_hgt_args a)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t sc_lds[];
@@ -318,21 +321,40 @@ __global__ void __launch_bounds__(256) acc_hgt_donor_bin_kernel(acc_hgt_args a)
         if (n == 0u) continue;                             // population.rs:672
         const uint32_t stream = PS_STREAM_HGT | (c << 8);
         // one Philox block serves two events: (x, y) = (recipient, gene) words of event 2 jp, (z, w) of event 2 jp + 1
-        for (uint32_t jp = tid; 2u * jp < k; jp += blockDim.x) {
-            const ps_u4 r = ps_philox(jp, dn, a.gen, stream, a.k0, a.k1);
+        // (beside a sweep the pass has ONE wave per SIMD: nothing hides the chain Philox -> list read -> LDS atomic -> store
+        // of an event but the thread's own next events, so two blocks = four events are taken per trip: all four list reads,
+        // then all four appends)
+        auto place = [&](uint32_t rc, uint32_t gene, uint32_t part, uint32_t pos) {
+            if (pos < cap) mybins[(uint64_t)part * cap + pos] = ((rc - part * a.rows_per_part) << 16) | gene;
+            // a full bin (sized for mean + 10 sigma) drops nothing: the event goes to the overflow image, which the
+            // reduce pass ORs in like one more slice image and clears again
+            else atomicOr(&a.ovf_img[(uint64_t)rc * d.GW + (gene >> 6)], 1ull << (gene & 63u));
+        };
+        constexpr uint32_t NBK = PS_HGT_BIN_BLOCKS;          // Philox blocks (= pairs of events) per trip
+        for (uint32_t jp = tid; 2u * jp < k; jp += NBK * blockDim.x) {
+            uint32_t wr[2u * NBK], wg[2u * NBK];
+            bool ok[2u * NBK];
 #pragma unroll
-            for (uint32_t h = 0; h < 2u; h++) {
-                if (2u * jp + h >= k) break;
-                uint32_t rc = ps_mulhi(h ? r.z : r.x, d.N - 1u);
-                rc += (rc >= dn) ? 1u : 0u;                             // population.rs:618
-                const uint32_t gene = glist[ps_mulhi(h ? r.w : r.y, n)];
-                const uint32_t part = ps_mulhi(rc, a.part_magic);       // rc / rows_per_part
-                const uint32_t pos = atomicAdd(&fill[part], 1u);
-                if (pos < cap) mybins[(uint64_t)part * cap + pos] = ((rc - part * a.rows_per_part) << 16) | gene;
-                // a full bin (sized for mean + 10 sigma) drops nothing: the event goes to the overflow image, which the
-                // reduce pass ORs in like one more slice image and clears again
-                else atomicOr(&a.ovf_img[(uint64_t)rc * d.GW + (gene >> 6)], 1ull << (gene & 63u));
+            for (uint32_t b = 0; b < NBK; b++) {
+                const uint32_t jb = jp + b * blockDim.x;
+                const ps_u4 r = ps_philox(jb, dn, a.gen, stream, a.k0, a.k1);
+                wr[2u * b] = r.x; wg[2u * b] = r.y; wr[2u * b + 1u] = r.z; wg[2u * b + 1u] = r.w;
+                ok[2u * b] = 2u * jb < k;
+                ok[2u * b + 1u] = 2u * jb + 1u < k;
             }
+            uint32_t rc[2u * NBK], gene[2u * NBK], part[2u * NBK], pos[2u * NBK];
+#pragma unroll
+            for (uint32_t e = 0; e < 2u * NBK; e++) {
+                rc[e] = ps_mulhi(wr[e], d.N - 1u);
+                rc[e] += (rc[e] >= dn) ? 1u : 0u;                       // population.rs:618
+                gene[e] = glist[ps_mulhi(wg[e], n)];
+                part[e] = ps_mulhi(rc[e], a.part_magic);                // rc / rows_per_part
+            }
+#pragma unroll
+            for (uint32_t e = 0; e < 2u * NBK; e++) pos[e] = ok[e] ? atomicAdd(&fill[part[e]], 1u) : 0u;
+#pragma unroll
+            for (uint32_t e = 0; e < 2u * NBK; e++)
+                if (ok[e]) place(rc[e], gene[e], part[e], pos[e]);
         }
     }
     __syncthreads();
