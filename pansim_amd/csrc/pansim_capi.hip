@@ -1432,11 +1432,24 @@ static void softmax_norm(double *v, uint64_t n, std::vector<double> &scratch)
     for (uint64_t i = 1; equal && i < n; i++) equal = (v[i] == v[0]);
     if (equal) {
         // streaming form on N equal values x: r = 0 * exp(-inf - x) + 1 = 1, then N - 1 times r += exp(0) = 1
-        const double lse = std::log((double)n) + v[0];
-        const double e = std::exp(v[0] - lse);
-        double sum = 0.0;
-        for (uint64_t i = 0; i < n; i++) sum += e;
-        const double q = (e != -INFINITY) ? e / sum : 0.0;
+        // (the result is a function of (N, x) alone, and under neutral selection without competition two of the three
+        // softmaxes of EVERY generation are this one with the same x: the N sequential additions -- 0.08 ms of dependent adds
+        // at N = 65536, on the chain beside the sweep -- are done once per (N, x) and thread)
+        static thread_local uint64_t memo_n = 0, memo_x = 0;
+        static thread_local double memo_q = 0.0;
+        uint64_t xbits;
+        memcpy(&xbits, &v[0], 8);
+        double q;
+        if (memo_n == n && memo_x == xbits) {
+            q = memo_q;
+        } else {
+            const double lse = std::log((double)n) + v[0];
+            const double e = std::exp(v[0] - lse);
+            double sum = 0.0;
+            for (uint64_t i = 0; i < n; i++) sum += e;
+            q = (e != -INFINITY) ? e / sum : 0.0;
+            memo_n = n; memo_x = xbits; memo_q = q;
+        }
         for (uint64_t i = 0; i < n; i++) v[i] = q;
         return;
     }
@@ -1463,6 +1476,56 @@ static void softmax_norm(double *v, uint64_t n, std::vector<double> &scratch)
     for (uint64_t i = 0; i < n; i++) v[i] = (v[i] != -INFINITY) ? v[i] / sum : 0.0;
 }
 
+// The genome-size softmax (population.rs:346-361) on its integer structure: v_i = (double)(count_i - average) * ln(penalty) takes
+// one value per distinct gene count (a few hundred among N), so every exp and every division of softmax_norm is done once per
+// distinct count and looked up by the count itself -- the same libm calls on the same operands, the sequential sums in the same
+// order, hence the same doubles as softmax_norm(v) (tests/test_host_logic.py compares with the plain loops of the CPU
+// restatement).  The exp arguments of the streaming ln_sum_exp depend on the running maximum: the table is stamped with the
+// maximum's epoch and starts over when it moves (expected O(log N) times).
+static bool softmax_size(const int32_t *cnt, int32_t avg, double lp, uint64_t n, double *v)
+{
+    int32_t lo = cnt[0], hi = cnt[0];
+    for (uint64_t i = 1; i < n; i++) { lo = std::min(lo, cnt[i]); hi = std::max(hi, cnt[i]); }
+    const uint64_t span = (uint64_t)((int64_t)hi - (int64_t)lo) + 1;
+    if (lo == hi || span > (1u << 20)) return false;          // (equal vector: softmax_norm's own path; absurd spans: the generic code)
+    static thread_local std::vector<double> val, tab;
+    static thread_local std::vector<uint32_t> stamp;
+    static thread_local std::vector<uint8_t> upd;
+    val.resize(span);
+    tab.resize(span);
+    stamp.assign(span, 0u);
+    upd.resize(n);
+    for (uint64_t k = 0; k < span; k++) val[k] = (double)((int32_t)((int64_t)lo + (int64_t)k) - avg) * lp;      // :350-355
+    // streaming ln_sum_exp: r over exp(v - alpha) / exp(alpha - v), alpha the running maximum
+    uint32_t epoch = 1;
+    double alpha = -INFINITY, r = 0.0;
+    for (uint64_t i = 0; i < n; i++) {
+        const uint32_t k = (uint32_t)(cnt[i] - lo);
+        const double x = val[k];
+        if (x <= alpha) {
+            if (stamp[k] != epoch) { tab[k] = std::exp(x - alpha); stamp[k] = epoch; }
+            r += tab[k];
+        } else {
+            r *= std::exp(alpha - x);
+            r += 1.0;
+            alpha = x;
+            epoch++;
+        }
+    }
+    const double lse = std::log(r) + alpha;
+    epoch++;
+    double sum = 0.0;
+    for (uint64_t i = 0; i < n; i++) {
+        const uint32_t k = (uint32_t)(cnt[i] - lo);
+        if (stamp[k] != epoch) { tab[k] = std::exp(val[k] - lse); stamp[k] = epoch; }
+        sum += tab[k];
+    }
+    for (uint64_t k = 0; k < span; k++)
+        if (stamp[k] == epoch) tab[k] = (tab[k] != -INFINITY) ? tab[k] / sum : 0.0;
+    for (uint64_t i = 0; i < n; i++) v[i] = tab[(uint32_t)(cnt[i] - lo)];
+    return true;
+}
+
 extern "C" int ps_sample_weights(const int32_t *num_genes, const double *logw, uint64_t n, uint64_t n_genes,
                                  int32_t avg_gene_num, const double *avg_pairwise_dists,
                                  int no_control_genome_size, double genome_size_penalty,
@@ -1481,8 +1544,10 @@ extern "C" int ps_sample_weights(const int32_t *num_genes, const double *logw, u
     }
     if (!no_control_genome_size) {                                 // :346
         const double lp = std::log(genome_size_penalty);
-        for (uint64_t i = 0; i < n; i++) tmp[i] = (double)(num_genes[i] - avg_gene_num) * lp; // :350-355
-        softmax_norm(tmp.data(), n, scratch);                      // :356-361
+        if (n < 4096 || !std::isfinite(lp) || !softmax_size(num_genes, avg_gene_num, lp, n, tmp.data())) {
+            for (uint64_t i = 0; i < n; i++) tmp[i] = (double)(num_genes[i] - avg_gene_num) * lp; // :350-355
+            softmax_norm(tmp.data(), n, scratch);                  // :356-361
+        }
         for (uint64_t i = 0; i < n; i++) weights[i] = tmp[i] * sel[i]; // :368
     } else {
         for (uint64_t i = 0; i < n; i++) weights[i] = sel[i];      // :371

@@ -239,3 +239,21 @@ def test_poisson_table_matches_oracle_and_poisson(pa, orc):
         assert orc.poisson_from_table(0, kmin_o, thr_o) == kmin_o + int(np.argmax(thr_o > 0))
         assert orc.poisson_from_table(2**32 - 1, kmin_o, thr_o) == kmin_o + len(thr_o) - 1
     assert _lib.load().ps_poisson_table(0.0, np.zeros(1, np.uint32), np.zeros(8, np.uint32), 8) == 0
+
+
+@pytest.mark.parametrize("penalty", [0.99, 1.0, 1.03, 1e-300, 0.5])
+def test_size_softmax_by_gene_count_matches_the_plain_loops(pa, orc, penalty):
+    # round 5: for N >= 4096 the genome-size softmax (population.rs:346-361) does every exp and division once per DISTINCT gene
+    # count and looks it up by the count (ps_sample_weights / softmax_size); the oracle runs the plain loops over all N.  Same
+    # doubles: penalties on both sides of 1 (the running maximum of the streaming ln_sum_exp moves up or down the counts),
+    # exactly 1 (all arguments 0), one that underflows every weight but the lightest genome's; narrow and wide count ranges;
+    # a count range too wide for the table (generic path); N just above and below the switch
+    rng = np.random.default_rng(int(penalty * 1000) % 9973)
+    for N, lo, hi in ((4096, 990, 1010), (4095, 990, 1010), (20000, 0, 4000), (9000, 5, 6), (5000, -3000000, 3000000)):
+        ng = rng.integers(lo, hi + 1, N).astype(np.int32)
+        ng[0], ng[-1] = hi, lo
+        lw = np.where(rng.random(N) < 0.5, 0.0, rng.normal(0, 2, N))
+        for avg_num in (1000, 0):
+            w = pa.sample_weights(ng, lw, 4000, avg_num, np.ones(N), False, penalty, 0.0)
+            rc, ow = orc.sample_weights(ng, lw, 4000, avg_num, np.ones(N), False, penalty, 0.0)
+            assert rc == 0 and np.array_equal(w, ow), (N, lo, hi, avg_num)
