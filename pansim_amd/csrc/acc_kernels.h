@@ -378,23 +378,30 @@ __global__ void __launch_bounds__(1024) acc_hgt_apply_kernel(acc_hgt_args a, uin
     for (uint32_t w = threadIdx.x; w < a.rows_per_part * W32; w += blockDim.x) lrow[w] = 0u;
     __syncthreads();
     const uint32_t cap = a.bin_cap;
-    const uint32_t quarter = threadIdx.x >> 8, qt = threadIdx.x & 255u;
-    const uint32_t nq = blockDim.x >> 8;           // 256-thread quarters of the workgroup (4; 1 or 2 for a workgroup that fits beside a sweep)
-    for (uint32_t bb = slice + quarter * n_slices; bb < donor_blocks; bb += nq * n_slices) {
-        const uint32_t n = a.counts[(uint64_t)bb * a.parts + part];
+    // a WAVE walks its own bins (round 5; the four 256-thread quarters of round 3 walked four): a bin is a dependent pair of
+    // reads (its count, then its events), and with the donors sharded over the ranks a bin holds ~120 events -- the pass was
+    // a chain of 51 such pairs per quarter, 58 us per workgroup, 0.23 ms between two sweeps at one rank of 8.  Sixteen bins
+    // in flight per workgroup instead of four; the next bin's count is requested before this bin's events are applied.
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u, nw = blockDim.x >> 6;
+    uint32_t bb = slice + wave * n_slices;
+    uint32_t n = bb < donor_blocks ? a.counts[(uint64_t)bb * a.parts + part] : 0u;
+    for (; bb < donor_blocks; bb += nw * n_slices) {
+        const uint32_t bn = bb + nw * n_slices;
+        const uint32_t n_next = bn < donor_blocks ? a.counts[(uint64_t)bn * a.parts + part] : 0u;
         const uint32_t *src = a.bins + ((uint64_t)bb * a.parts + part) * cap;
-        for (uint32_t k = qt; k < n; k += 1024u) {
+        for (uint32_t k = lane; k < n; k += 256u) {
             uint32_t v[4];
 #pragma unroll
-            for (uint32_t u = 0; u < 4u; u++) v[u] = (k + 256u * u < n) ? src[k + 256u * u] : 0xFFFFFFFFu;
+            for (uint32_t u = 0; u < 4u; u++) v[u] = (k + 64u * u < n) ? src[k + 64u * u] : 0xFFFFFFFFu;
 #pragma unroll
             for (uint32_t u = 0; u < 4u; u++) {
-                if (k + 256u * u < n) {
+                if (k + 64u * u < n) {
                     const uint32_t gene = v[u] & 0xFFFFu;
                     atomicOr(&lrow[(v[u] >> 16) * W32 + (gene >> 5)], 1u << (gene & 31u));
                 }
             }
         }
+        n = n_next;
     }
     __syncthreads();
     uint32_t *img = a.scratch + ((uint64_t)slice * d.N + r_lo) * W32;
