@@ -445,6 +445,25 @@ __global__ void __launch_bounds__(256) acc_hgt_reduce_rows_kernel(const uint64_t
     if (lane == 0) { num_genes[i] = (int32_t)n; logw[i] = 0.0; }
 }
 
+// The merge of a donor-sharded HGT (matrix |= exchanged delta) with one wave per individual, which also leaves the row's gene
+// count -- the device half of the NEXT generation's sample_indices under neutral selection (population.rs:282-291; log_sum =
+// 0.0), like acc_hgt_reduce_rows_kernel in an unsharded run: the count kernel of the next host half (a full-chip launch that
+// ran between two sweeps: 36 us at N = 65536) goes away and the host half starts that much earlier
+__global__ void __launch_bounds__(256) acc_or_rows_kernel(uint64_t *dstI, const uint64_t *delta, acc_dims d, int32_t *num_genes, double *logw)
+{
+    const uint32_t i = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
+    if (i >= d.N) return;
+    uint32_t n = 0;
+    for (uint32_t gw = lane; gw < d.GW; gw += 64u) {
+        const uint64_t w = (uint64_t)i * d.GW + gw;
+        const uint64_t old = dstI[w], now = old | delta[w];
+        if (now != old) dstI[w] = now;
+        n += __popcll(now);
+    }
+    for (int off = 32; off > 0; off >>= 1) n += __shfl_down(n, off, 64);
+    if (lane == 0) { num_genes[i] = (int32_t)n; logw[i] = 0.0; }
+}
+
 // dst |= src (a donor shard's exchanged HGT delta into the matrix; a peer shard's delta into this shard's)
 __global__ void __launch_bounds__(256) acc_or_kernel(uint64_t *dst, const uint64_t *src, uint64_t words)
 {

@@ -1234,6 +1234,11 @@ static int launch_acc_hgt(ps_population *p, uint32_t gen, hipStream_t st, hipEve
             }
             g_err = prev;
         }
+        if (p->fuse_counts_out) {
+            // (ps_sim, neutral selection: the merge also leaves the gene counts the next generation's host half reads)
+            acc_or_rows_kernel<<<(uint32_t)((p->d.N + 3) / 4), 256, 0, st>>>(p->I[p->cur], p->d_delta, p->d, p->fuse_counts_out, p->fuse_logw_out);
+            counts_left = true;
+        } else
         acc_or_kernel<<<(uint32_t)((mat_words + 255) / 256), 256, 0, st>>>(p->I[p->cur], p->d_delta, mat_words);
         HIPCHK(hipGetLastError());
     }
