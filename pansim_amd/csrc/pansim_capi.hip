@@ -1106,7 +1106,11 @@ static int launch_acc_hgt(ps_population *p, uint32_t gen, hipStream_t st, hipEve
         uint32_t donor_blocks = std::min(items, 1024u);
         if (const char *e = getenv("PANSIM_HGT_DONOR_BLOCKS")) donor_blocks = std::max(1u, std::min(items, (uint32_t)atoi(e)));
         // ~1024 apply workgroups, at most 64 slice images (measured: cfg3 64 of 32/64/128, cfg4 5 of 2/3/5)
-        const uint32_t n_slices = std::max(1u, p->hgt_slices ? p->hgt_slices : std::min(64u, (1024u + parts - 1) / parts));
+        // (a donor shard has 1 / K of the events for the same images: fewer slices mean less to zero, publish and reduce --
+        // one rank of 8 at cfg4, with a wave per bin in the LDS-image pass: 5 / 3 / 2 / 1 slices 0.43 / 0.41 / 0.40 / 0.40 ms exposed)
+        const uint32_t base_slices = std::min(64u, (1024u + parts - 1) / parts);
+        const uint32_t auto_slices = sharded ? (uint32_t)(((uint64_t)base_slices * a.dn_cnt + p->d.N - 1) / p->d.N) : base_slices;
+        const uint32_t n_slices = std::max(1u, p->hgt_slices ? p->hgt_slices : auto_slices);
         const uint64_t words = (uint64_t)p->d.N * p->d.GW;
         const uint64_t img_bytes = (uint64_t)n_slices * words * 8;
         // events of a donor workgroup: Poisson with mean <= sum_c lambda_c * ceil(N / blocks); a partition
