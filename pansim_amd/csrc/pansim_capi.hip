@@ -497,7 +497,7 @@ extern "C" int ps_set_tuning(ps_population *p, const char *key, int64_t value)
     } else if (k == "davg_plain_division") {
         p->davg_plain_division = value != 0;
     } else if (k == "davg_nb") {
-        if (value < 0 || value > 2) return ps_fail(PS_ERR_INVALID, "davg_nb must be 0 (choose), 1 or 2");
+        if (value < 0 || value > 4 || value == 3) return ps_fail(PS_ERR_INVALID, "davg_nb must be 0 (choose), 1, 2 or (two-phase form only) 4");
         p->davg_nb = (uint32_t)value;
     } else if (k == "hgt_mode") {
         if (value < 0 || value > 2) return ps_fail(PS_ERR_INVALID, "hgt_mode must be 0 (auto), 1 (one atomic per event) or 2 (binned by recipient partition, two passes)");
@@ -1717,7 +1717,10 @@ static int average_distance_device(ps_population *p, double *d_out, hipStream_t 
                 uint32_t jsteps = 8u;
                 while (jsteps > 1u && (uint64_t)gx * ((steps + jsteps - 1u) / jsteps) < 2048u) jsteps >>= 1;
                 const dim3 grid(gx, (steps + jsteps - 1u) / jsteps);
-                if (nb == 2u) {
+                if (nb == 4u) {
+                    HIPCHK(hipFuncSetAttribute((const void *)acc_intersections_mfma_kernel<4u>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                    acc_intersections_mfma_kernel<4u><<<grid, 256, lds, st>>>(rowsP, WP, Npad, lo, rows, jsteps, In, ld);
+                } else if (nb == 2u) {
                     HIPCHK(hipFuncSetAttribute((const void *)acc_intersections_mfma_kernel<2u>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
                     acc_intersections_mfma_kernel<2u><<<grid, 256, lds, st>>>(rowsP, WP, Npad, lo, rows, jsteps, In, ld);
                 } else {
@@ -1732,7 +1735,7 @@ static int average_distance_device(ps_population *p, double *d_out, hipStream_t 
             }
         } else {
         // 64 individuals per wave (two B fragments: fewer table reads per MFMA) when that still gives every SIMD a wave
-        const uint32_t nb = p->davg_nb ? p->davg_nb : (i_cnt >= 64u * 1024u ? 2u : 1u);
+        const uint32_t nb = (p->davg_nb == 1u || p->davg_nb == 2u) ? p->davg_nb : (i_cnt >= 64u * 1024u ? 2u : 1u);
         const uint32_t waves = (uint32_t)((i_cnt + 32u * nb - 1) / (32u * nb)), grid = (waves + 3u) / 4u;
 #define PS_DAVG_LAUNCH(NB_, FAST_)                                                                                                    \
         {                                                                                                                             \

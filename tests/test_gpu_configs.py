@@ -148,7 +148,7 @@ def test_average_distance_large_populations(pa, orc, N, G, cg):
 
 @pytest.mark.parametrize("N,G,cg,nb", [(2, 9, 0, 0), (33, 65, 0, 1), (130, 257, 3, 2), (1000, 4000, 2000, 1), (2100, 130, 7, 2),
                                        (4100, 4000, 2000, 0), (9000, 64, 0, 0), (20000, 300, 11, 0),
-                                       (300, 5000, 17, 1), (700, 9000, 5, 2)])
+                                       (300, 5000, 17, 1), (700, 9000, 5, 2), (1000, 4000, 2000, 4), (333, 700, 1, 4)])
 def test_average_distance_on_the_matrix_cores(pa, orc, N, G, cg, nb):
     # D-avg with the intersections as a {0, 1} X X^T on the FP4 matrix cores and the ordered f64 fold in the accumulator
     # layout (acc_average_distance_mfma_kernel; population.rs:753-784, :114-151): ragged populations and gene counts (fewer
