@@ -5,7 +5,6 @@
 every cell).  At 1e4 / 1e8 the competition softmax saturates (population.rs:374-393): one individual parents the whole
 next generation, the window / wave sweeps gather from a single column, and D-avg must agree with the oracle to the last
 bit because strength * ln(avg) amplifies one ulp to a different winner."""
-import ctypes as C
 import os
 import subprocess
 
