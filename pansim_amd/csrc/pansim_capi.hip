@@ -1673,11 +1673,12 @@ static int average_distance_device(ps_population *p, double *d_out, hipStream_t 
     // 3 = matrix cores in two phases (round 5: contraction on every SIMD -> u16 counts -> division + ordered fold)
     const bool whole = i_lo == 0 && i_cnt == N;
     const bool mfma = p->d.G > 0 && N >= 2 && (p->davg_form >= 2 || !whole || (p->davg_form == 0 && N > 8192));
-    // Choice between the two matrix-core forms (davg_form 0): the one-kernel form needs 32 NB rows per wave for the whole
-    // fold, so below ~48 K rows it leaves SIMDs idle (a rank of 8 at N = 65536: 7.6 ms for 8192 rows) and the two-phase form
-    // wins (2.3 ms there; N = 16384 whole: 1.1 against 1.96 ms); with 65536 rows in one launch the one-kernel form's fused
-    // epilogue is cheaper than 8.6 GB of counts written and read back (11.1 against 12-15 ms)
-    const bool two_phase = mfma && p->davg_form != 2 && p->d.G <= 65535 && (p->davg_form == 3 || i_cnt < 49152);      // (u16 counts)
+    // Choice between the two matrix-core forms (davg_form 0).  The one-kernel form needs 32 NB rows per wave for the whole fold:
+    // a row shard leaves its SIMDs idle (a rank of 8 at N = 65536: 7.6 ms for 8192 rows) and always takes the two phases (1.96 ms);
+    // a whole population takes them while it is small (N = 16384: 1.03 against 1.95 ms) -- from about 24 K rows on the
+    // one-kernel form's fused epilogue is cheaper than the counts written and read back (N = 32768: 3.98 against 4.50 ms;
+    // N = 65536: 11.1 against 14.6)
+    const bool two_phase = mfma && p->davg_form != 2 && p->d.G <= 65535 && (p->davg_form == 3 || !whole || i_cnt <= 24576);      // (u16 counts)
     if (mfma) {
         const uint32_t WP = (2u * p->d.GW + 7u) & ~7u, Npad = (uint32_t)((N + 127) & ~127ull);
         const uint64_t need = (uint64_t)Npad * WP * 4 + (uint64_t)Npad * 4 + 64;
