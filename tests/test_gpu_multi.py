@@ -318,3 +318,28 @@ def test_bench_bare_form_two_ranks_one_gpu(pa):
     assert ns["exchange"]["mode"] == "torch" and ns["exchange"]["calls"] == 10
     chain = ns["exchange"]["provider_chain"]
     assert [c["provider"] for c in chain] == ["rccl", "torch"] and not chain[0]["ok"] and chain[1]["ok"]
+
+
+@pytest.mark.parametrize("exchange", ["sliced", "or"])
+def test_multi_eight_shards_with_competition(pa, orc, monkeypatch, exchange):
+    # ps_multi at the north-star's shard count: 8 shards of one process (all on this box's one GPU), HGT donors and D-avg rows
+    # sharded 8 ways, buffer lengths 8 does not divide (N = 301 doubles; N x GW = 301 x 7 words padded to 4096), both forms of
+    # the in-process exchange (peer copies on copy streams + one merge kernel; the reading kernels) -- always the unsharded
+    # oracle run
+    from orc_sim import OracleSim
+    if exchange == "or":
+        monkeypatch.setenv("PANSIM_MULTI_EXCHANGE", "or")
+    kw = dict(pop_size=301, core_size=1203, pan_genes=520, core_genes=100, HR_rate=0.2, HGT_rate=0.5, competition_strength=3.0)
+    ref = OracleSim(seed=14, **kw)
+    multi = pa.MultiSimulation(pa.make_params(seed=14, n_gen=4, max_distances=150, **kw), 8, devices=[0] * 8)
+    for g in range(4):
+        multi.run(1)
+        multi.sync()
+        ref.generation(g)
+        for s in multi.shards:
+            assert np.array_equal(s.last_parents(), ref.last_idx), "parents differ at generation %d" % g
+    assert np.array_equal(np.concatenate([s.core_genome.read_matrix() for s in multi.shards], axis=1), ref.core)
+    for s in multi.shards:
+        assert np.array_equal(s.pan_genome.read_matrix(), ref.acc)
+    assert [s.exchange_stats()[0] for s in multi.shards] == [8] * 8
+    multi.close()
