@@ -239,6 +239,60 @@ __device__ __forceinline__ uint32_t ps_candidates_swar(const ps_u4 &l1, uint32_t
            | (ps_bytes_lt(l1.w, c4) >> 3);
 }
 
+// the same flags in the LOW nibbles (cell 4*j + b is bit 8*b + 3 - j): the candidate masks of two rows then share one word
+__device__ __forceinline__ uint32_t ps_candidates_swar_lo(const ps_u4 &l1, uint32_t c4)
+{
+    return (ps_bytes_lt(l1.x, c4) >> 4) | (ps_bytes_lt(l1.y, c4) >> 5) | (ps_bytes_lt(l1.z, c4) >> 6)
+           | (ps_bytes_lt(l1.w, c4) >> 7);
+}
+
+// wave-wide inclusive prefix sum on the DPP path: four shifts inside the 16-lane rows, then lane 15 of a row into the next
+// row (rows 1 and 3) and lane 31 into rows 2 and 3.  Lanes without a source keep the 0 of `old` (bound_ctrl off).
+__device__ __forceinline__ uint32_t ps_wave_scan_incl(uint32_t x)
+{
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xF, 0xF, false);     // row_shr:1
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xF, 0xF, false);     // row_shr:2
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xF, 0xF, false);     // row_shr:4
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xF, 0xF, false);     // row_shr:8
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xA, 0xF, false);     // row_bcast:15
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xC, 0xF, false);     // row_bcast:31
+    return x;
+}
+
+// STASH push (phase 2 of the wave and window sweeps).  cm[] are the candidate masks of the batch's rows, even rows in the
+// high nibbles (ps_candidates_swar), odd rows in the low ones (ps_candidates_swar_lo), so that two rows make one word.  A
+// lane counts its candidates, ONE prefix sum over the wave gives every lane its own stretch of the queue, and the lane
+// writes its entries there in a loop of its own: ~6 vector instructions per trip and ~10 trips per batch of three rows,
+// where the ballot / mbcnt loop this replaces (one queue slot per ballot bit; kept for the non-STASH entries, which carry
+// the level-1 byte) spent ~36 per trip on ~5 trips plus three exec-mask branches each.  The order of the queue changes
+// (lane-major), its content does not; nothing is written when the batch does not fit (the caller redoes it queue-free).
+// Entry: bit position p (0-31) | lane << 5 | word << 12; returns the wave-uniform number of candidates of the batch.
+template <uint32_t PS_ROWS>
+__device__ __forceinline__ uint32_t ps_push_scan(const uint32_t (&cm)[PS_ROWS], uint32_t *q, uint32_t lane, uint32_t qcap)
+{
+    const uint32_t w0 = cm[0] | (PS_ROWS > 1 ? cm[PS_ROWS > 1 ? 1 : 0] : 0u);
+    const uint32_t w1 = PS_ROWS > 2 ? (cm[PS_ROWS > 2 ? 2 : 0] | (PS_ROWS > 3 ? cm[PS_ROWS > 3 ? 3 : 0] : 0u)) : 0u;
+    const uint32_t c = (uint32_t)__popc(w0) + (PS_ROWS > 2 ? (uint32_t)__popc(w1) : 0u);
+    const uint32_t incl = ps_wave_scan_incl(c);
+    const uint32_t qn = __builtin_amdgcn_readlane(incl, 63);
+    if (qn <= qcap) {
+        uint32_t *qp = q + (incl - c);
+        const uint32_t tag = lane << 5;
+        for (uint32_t m = w0; m; m &= m - 1u) *qp++ = tag | (uint32_t)__builtin_ctz(m);
+        if (PS_ROWS > 2)
+            for (uint32_t m = w1; m; m &= m - 1u) *qp++ = tag | 4096u | (uint32_t)__builtin_ctz(m);
+    }
+    return qn;
+}
+
+// ... and the cell of such an entry inside the lane's rows: lane * 16 + 4 * j + b, and the row (2 * word + nibble half)
+__device__ __forceinline__ void ps_push_scan_decode(uint32_t ent, uint32_t &cell, uint32_t &row)
+{
+    const uint32_t p = ent & 31u, t = ~p & 7u;          // t = j + 4 * (row & 1)
+    cell = (((ent >> 5) & 63u) << 4) + ((t & 3u) << 2) + (p >> 3);
+    row = ((ent >> 12) << 1) | (t >> 2);
+}
+
 // four zero-extended bytes -> one dword (two v_perm + v_or; the compiler's own form masks every byte again)
 __device__ __forceinline__ uint32_t ps_pack4(uint32_t b0, uint32_t b1, uint32_t b2, uint32_t b3)
 {
@@ -269,13 +323,19 @@ __device__ __forceinline__ uint4 ps_strip(uint4 v, bool on)
 // so a queue entry is just (bit position | lane << 5 | row << 11) -- one v_add per pushed candidate instead
 // of the v_perm byte extraction -- and the dense pass, with every lane busy, decodes the cell address and
 // reads the byte back from the row.  The nibbles are stripped when the row leaves LDS.
+#ifndef PS_WAVE_LB
+#define PS_WAVE_LB 8      // waves per SIMD the wave sweep is built for (8 = 64 VGPRs, 7 = 72, 6 = 84)
+#endif
 template <uint32_t PS_ROWS, bool DO_GATHER, bool DO_MUT, bool DO_HR, bool STASH, bool NT = false>
-__global__ void __launch_bounds__(256, PS_ROWS >= 4 ? 6 : 8) core_sweep_wave_kernel(core_sweep_args a)
+__global__ void __launch_bounds__(256, PS_ROWS >= 4 ? 6 : PS_WAVE_LB) core_sweep_wave_kernel(core_sweep_args a)
 {
 #ifdef PS_STAMP
     unsigned long long st_acc[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
     unsigned long long st_last;
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_last) :: "memory");
+#endif
+#ifdef PS_GROUP_TIMES      // (diagnostic builds: when does each of the 8 row groups start and end?  100 MHz clock; stamps 8.. / 16..)
+    const unsigned long long gt_start = __builtin_amdgcn_s_memrealtime();
 #endif
     constexpr uint32_t PS_QCAP = ps_qcap(PS_ROWS);
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
@@ -386,7 +446,7 @@ __global__ void __launch_bounds__(256, PS_ROWS >= 4 ? 6 : 8) core_sweep_wave_ker
             l1[rr] = ps_u4{ 0, 0, 0, 0 };
             if (events) {
                 l1[rr] = ps_philox_l1(a.site_offset + min(r0 + rr, a.rows - 1u), lane, a.gen, a.k0, a.k1);
-                cm[rr] = ps_candidates_swar(l1[rr], c4) & vperm;
+                cm[rr] = (STASH && (rr & 1u)) ? (ps_candidates_swar_lo(l1[rr], c4) & (vperm >> 4)) : (ps_candidates_swar(l1[rr], c4) & vperm);
                 if (STASH) {
                     d.x = ps_stash(d.x, l1[rr].x); d.y = ps_stash(d.y, l1[rr].y);
                     d.z = ps_stash(d.z, l1[rr].z); d.w = ps_stash(d.w, l1[rr].w);
@@ -398,8 +458,12 @@ __global__ void __launch_bounds__(256, PS_ROWS >= 4 ? 6 : 8) core_sweep_wave_ker
             if (DO_GATHER || events) *(uint4 *)(row + i0) = d;
             __builtin_amdgcn_sched_barrier(0);      // keep the rows apart (see above)
         }
-        if (events) {
-            // Phase 2: compact every candidate cell of the PS_ROWS rows into the wave queue.  ONE loop for all
+        const uint32_t qcap = a.qcap_limit ? min(PS_QCAP, a.qcap_limit) : PS_QCAP;
+        if (events && STASH) {
+            // Phase 2: every candidate cell of the PS_ROWS rows into the wave queue (one prefix sum, then lane-private writes)
+            qn = ps_push_scan<PS_ROWS>(cm, q, lane, qcap);
+        } else if (events) {
+            // ... entries that carry the level-1 byte: ONE ballot loop for all
             // rows -- its trip count is the largest number of candidates any lane holds in any single row
             // (about 4-5), not the sum over the rows, and the rows' ballots inside a trip are independent.
             for (;;) {
@@ -436,7 +500,6 @@ __global__ void __launch_bounds__(256, PS_ROWS >= 4 ? 6 : 8) core_sweep_wave_ker
         // once-in-the-age-of-the-universe event at the rates it admits -- and every batch under the test hook
         // `sweep_queue_cap`): nothing is dropped; the batch is redone by the queue-free method of
         // core_sweep_inline_kernel, every candidate handled by its owner lane.
-        const uint32_t qcap = a.qcap_limit ? min(PS_QCAP, a.qcap_limit) : PS_QCAP;
         if (events && qn > qcap) {
 #pragma unroll 1
             for (uint32_t rr = 0; rr < PS_ROWS; rr++) {
@@ -485,14 +548,18 @@ __global__ void __launch_bounds__(256, PS_ROWS >= 4 ? 6 : 8) core_sweep_wave_ker
                 const bool valid = e < qn;
                 uint32_t ent = valid ? q[e] : 0u;
                 if (STASH) {
-                    // (bit position p = 8b + 7 - j of cell 4j + b | lane << 5 | row << 11) -> byte address in rowbuf
-                    const uint32_t p = ent & 31u;
-                    const uint32_t addr = ((ent >> 5) << 4) + 4u * (7u - (p & 7u)) + (p >> 3);
+                    // ps_push_scan's entry -> byte address in rowbuf (cell | row << 10) | stashed nibble << 12
+                    uint32_t cl, rw;
+                    ps_push_scan_decode(ent, cl, rw);
+                    const uint32_t addr = cl | (rw << 10);
                     ent = addr | ((uint32_t)(rowbuf[addr] >> 4) << 12);
                 }
                 const uint32_t byte = (ent >> 12) & 0xFFu;
                 uint32_t allele = 0;
-                if (use_lut) {
+                if (STASH) {
+                    // (a stashed byte is below 16: the low word of the table, and 1 << 0 masked away)
+                    allele = (1u << (((uint32_t)lut >> (2u * byte)) & 3u)) & 14u;
+                } else if (use_lut) {
                     const uint32_t code = (uint32_t)(lut >> (2u * (byte & 31u))) & 3u;
                     allele = code ? (1u << code) : 0u;
                 } else {
@@ -570,6 +637,13 @@ __global__ void __launch_bounds__(256, PS_ROWS >= 4 ? 6 : 8) core_sweep_wave_ker
 #ifdef PS_STAMP
     if (lane == 0)
         for (int k = 0; k < 8; k++) atomicAdd((unsigned long long *)a.stamps + k, st_acc[k]);
+#endif
+#ifdef PS_GROUP_TIMES
+    if (lane == 0) {
+        atomicMax((unsigned long long *)a.stamps + 8 + grp, (unsigned long long)__builtin_amdgcn_s_memrealtime());
+        atomicMax((unsigned long long *)a.stamps + 16 + grp, gt_start);
+        if (blockIdx.x < 8 && wave == 0) ((unsigned long long *)a.stamps)[24 + grp] = gt_start;     // the group's first workgroup
+    }
 #endif
 }
 
@@ -768,7 +842,7 @@ __global__ void __launch_bounds__(256, PS_WLB) core_sweep_window_kernel(core_swe
             }
             uint4 d = make_uint4(w[0], w[1], w[2], w[3]);
             l1[rr] = ps_philox_l1(site, chunk, a.gen, a.k0, a.k1);
-            cm[rr] = ps_candidates_swar(l1[rr], c4) & vperm;
+            cm[rr] = (STASH && (rr & 1u)) ? (ps_candidates_swar_lo(l1[rr], c4) & (vperm >> 4)) : (ps_candidates_swar(l1[rr], c4) & vperm);
             if (STASH) {
                 d.x = ps_stash(d.x, l1[rr].x); d.y = ps_stash(d.y, l1[rr].y);
                 d.z = ps_stash(d.z, l1[rr].z); d.w = ps_stash(d.w, l1[rr].w);
@@ -777,7 +851,10 @@ __global__ void __launch_bounds__(256, PS_WLB) core_sweep_window_kernel(core_swe
             *(uint4 *)(win + i0) = d;
             __builtin_amdgcn_sched_barrier(0);      // keep the rows apart (see the wave sweep)
         }
-        // ONE push loop for all rows of the batch (the wave sweep's)
+        // the push of the wave sweep: one prefix sum and lane-private writes (STASH), or ONE ballot loop for all rows
+        const uint32_t qcap = a.qcap_limit ? min(PS_QCAP, a.qcap_limit) : PS_QCAP;
+        if (STASH) qn = ps_push_scan<PS_ROWS>(cm, q, lane, qcap);
+        else
         for (;;) {
             uint32_t any = cm[0];
 #pragma unroll
@@ -806,7 +883,6 @@ __global__ void __launch_bounds__(256, PS_WLB) core_sweep_window_kernel(core_swe
         }
         ps_wave_sync();
 
-        const uint32_t qcap = a.qcap_limit ? min(PS_QCAP, a.qcap_limit) : PS_QCAP;
         if (qn > qcap) {
             // full queue: the batch is redone by the queue-free method (see the wave sweep), donors recomputed
 #pragma unroll 1
@@ -839,15 +915,18 @@ __global__ void __launch_bounds__(256, PS_WLB) core_sweep_window_kernel(core_swe
                 const bool valid = e < qn;
                 uint32_t ent = valid ? q[e] : 0u;
                 if (STASH) {
-                    // (bit position p = 8b + 7 - j of cell 4j + b | lane << 5 | row << 11) -> cell | row << 10 | nibble << 12
-                    const uint32_t p = ent & 31u;
-                    const uint32_t cl = (((ent >> 5) & 63u) << 4) + 4u * (7u - (p & 7u)) + (p >> 3), rr = ent >> 11;
+                    // ps_push_scan's entry -> cell | row << 10 | nibble << 12
+                    uint32_t cl, rr;
+                    ps_push_scan_decode(ent, cl, rr);
                     ent = cl | (rr << 10);
                     ent |= (uint32_t)(rowbuf[cell_addr(ent)] >> 4) << 12;
                 }
                 const uint32_t byte = (ent >> 12) & 0xFFu;
                 uint32_t allele = 0;
-                if (use_lut) {
+                if (STASH) {
+                    // (a stashed byte is below 16: the low word of the table, and 1 << 0 masked away)
+                    allele = (1u << (((uint32_t)lut >> (2u * byte)) & 3u)) & 14u;
+                } else if (use_lut) {
                     const uint32_t code = (uint32_t)(lut >> (2u * (byte & 31u))) & 3u;
                     allele = code ? (1u << code) : 0u;
                 } else {

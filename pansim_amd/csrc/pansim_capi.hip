@@ -292,8 +292,12 @@ extern "C" void ps_population_destroy(ps_population *p)
         if (q) (void)hipFree(q);
     if (p->h_flag) (void)hipHostFree(p->h_flag);
     if (p->h_stamps) {
+        if (p->d_stamps) {
+            (void)hipMemcpy(p->h_stamps, p->d_stamps, 32 * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+            (void)hipFree(p->d_stamps);
+        }
         if (getenv("PANSIM_PRINT_STAMPS"))
-            for (int k = 0; k < 8; k++) fprintf(stderr, "stamp[%d] = %llu\n", k, p->h_stamps[k]);
+            for (int k = 0; k < 32; k++) fprintf(stderr, "stamp[%d] = %llu\n", k, p->h_stamps[k]);
         (void)hipHostFree(p->h_stamps);
     }
     if (p->stream) (void)hipStreamDestroy(p->stream);
@@ -353,9 +357,10 @@ static int pop_create_impl(const ps_config *cfg, const uint8_t *init_vec, ps_pop
     HIPCHK(hipMalloc(&p->d_idx, std::max<uint64_t>(N, 1) * sizeof(uint32_t)));
     HIPCHK(hipHostMalloc(&p->h_flag, sizeof(uint32_t), hipHostMallocMapped));
     *p->h_flag = 0;
-    HIPCHK(hipHostMalloc(&p->h_stamps, 8 * sizeof(unsigned long long), hipHostMallocMapped));
-    memset(p->h_stamps, 0, 8 * sizeof(unsigned long long));
-    HIPCHK(hipHostGetDevicePointer((void **)&p->d_stamps, p->h_stamps, 0));
+    HIPCHK(hipHostMalloc(&p->h_stamps, 32 * sizeof(unsigned long long), hipHostMallocMapped));
+    memset(p->h_stamps, 0, 32 * sizeof(unsigned long long));
+    HIPCHK(hipMalloc(&p->d_stamps, 32 * sizeof(unsigned long long)));      // (device memory: 64-bit atomics on mapped host memory are not dependable)
+    HIPCHK(hipMemset(p->d_stamps, 0, 32 * sizeof(unsigned long long)));
     HIPCHK(hipHostGetDevicePointer((void **)&p->d_flag, p->h_flag, 0));
     uint8_t *d_vec = nullptr;
     HIPCHK(hipMalloc(&d_vec, std::max<uint64_t>(C, 1)));
@@ -2872,7 +2877,9 @@ static int sim_create_impl(const ps_sim_params *p, ps_sim *s)
         // take turns where the binned HGT kernels are used (>= 1e7 expected events): their LDS images
         // could not share a CU with the sweep anyway
         const uint32_t parts = hgt_partitions(s->acc);
-        s->heavy_hgt = (double)N * s->der.n_recombinations_pan_total >= 1.0e7 && parts >= 1 && parts <= 1024;
+        // (N = 1000, 6000 genes, by HGT_rate -- events per generation: 0.1 -- 6e6 -- 1906 beside the sweep / 1882 in turns;
+        // 0.15 -- 9e6 -- 1567 / 1653; 0.2 -- 1.2e7 -- 1728 / 1884 generations/s: profiles/r05_sweep_experiments.md 11)
+        s->heavy_hgt = (double)N * s->der.n_recombinations_pan_total >= 7.5e6 && parts >= 1 && parts <= 1024;
     }
     if (const char *e = getenv("PANSIM_HEAVY_HGT")) s->heavy_hgt = atoi(e) != 0;
     // Inside the generation loop the sweep shares the GPU with the accessory chain of the next
@@ -2889,7 +2896,13 @@ static int sim_create_impl(const ps_sim_params *p, ps_sim *s)
         for (int c = 0; c < d.n_comp; c++) max_comp = std::max<uint64_t>(max_comp, d.comp_end[c] - d.comp_begin[c]);
         const uint64_t list_lds = 2 * max_comp;
         if (list_lds > 36 * 1024) s->acc->hgt_list_in_global = true;
-        s->core->sweep_blocks_per_cu = list_lds <= 16 * 1024 ? 7 : 6;
+        // Round 5 (scan push, leaner dense pass; profiles/r05_sweep_experiments.md 11): the sweep by itself is fastest at 5-6
+        // workgroups per CU (0.475 against 0.505 ms at 7, alone on the GPU), and the chain beside it decides: light HGT
+        // (cfg2) 4 / 5 / 6 / 7 -> 1993 / 2080 / 2093 / 1972 generations/s; with the D-avg of --competition_strength in the
+        // chain 1957 / 2007 / 1921 / 1848 (the authors' run 1942 / 1897 / 1841 / 1692); sweep and HGT in turns (cfg3)
+        // - / 1537 / 1617 / 1645.
+        const uint32_t light = p->competition_strength > 0.0 ? 5u : s->heavy_hgt ? 7u : 6u;
+        s->core->sweep_blocks_per_cu = list_lds <= 16 * 1024 ? light : std::min(light, 6u);
     }
     HIPCHK(hipHostMalloc(&s->h_num_genes, N * sizeof(int32_t), hipHostMallocMapped));
     HIPCHK(hipHostMalloc(&s->h_logw, N * sizeof(double), hipHostMallocMapped));
