@@ -302,7 +302,8 @@ __device__ __forceinline__ uint32_t ps_pack4(uint32_t b0, uint32_t b1, uint32_t 
 // child bytes (alleles, bits 0-3) with the low nibbles of the level-1 bytes in bits 4-7
 __device__ __forceinline__ uint32_t ps_stash(uint32_t d, uint32_t l1)
 {
-    return ((l1 & 0x0F0F0F0Fu) << 4) | d;
+    // ((l1 << 4) & 0xF0F0F0F0) | d as a shift and ONE v_bitop3_b32 ((a & b) | c = table 0xEA)
+    return __builtin_amdgcn_bitop3_b32(l1 << 4, 0xF0F0F0F0u, d, 0xEA);
 }
 
 __device__ __forceinline__ uint4 ps_strip(uint4 v, bool on)
