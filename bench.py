@@ -75,7 +75,7 @@ def pmc_traffic(kernel, algorithmic_bytes):
     by scripts/collect_pmc.py; FETCH_SIZE doubled per the gfx950 correction of MI355X_MICROARCH.md).  The passes ran on one
     workload per kernel (the file names it); for another workload of the same kernel the measured traffic / algorithmic
     ratio is applied to this workload's algorithmic bytes, and the source string says so.  None if no file is present."""
-    names = {"wave": ("r04_pmc_sweep.json", "r03_pmc_sweep.json", "r02_pmc_sweep.json", "r01_pmc_sweep.json"),
+    names = {"wave": ("r05_pmc_sweep.json", "r04_pmc_sweep.json", "r03_pmc_sweep.json", "r02_pmc_sweep.json", "r01_pmc_sweep.json"),
              "window": ("r05_pmc_window_sweep.json", "r04_pmc_window_sweep.json", "r03_pmc_window_sweep.json"),
              "block": ("r02_pmc_block_sweep.json", "r01_pmc_block_sweep.json")}.get(kernel, ())
     try:
