@@ -643,6 +643,37 @@ def test_sweeps_carry_bytes_above_15(pa, orc, N, L, tune):
     pop.close()
 
 
+@pytest.mark.parametrize("total,stash", [(0.0640, True), (0.0650, False), (0.0039, True), (0.1200, False)])
+@pytest.mark.parametrize("N,rows,ascending", [(1000, 3, False), (1024, 2, False), (777, 4, False), (17, 3, False),
+                                              (5000, 3, True), (4097, 3, True)])
+def test_candidate_push_on_both_sides_of_the_stash_limit(pa, orc, N, rows, ascending, total, stash):
+    # The candidate push of the wave / window sweeps has two forms (core_kernels.h): one wave prefix sum + lane-private writes
+    # when every candidate byte is below 16 (bC <= 15: the level-1 nibble rides in the child byte), the ballot loop when
+    # not.  Per-site event rates just below and just above the limit (0.0640 -> bC = 15, 0.0650 -> bC = 16), a very
+    # sparse plan (most lanes without a candidate: empty stretches of the queue) and a dense one, for 2 / 3 / 4 rows per
+    # wave trip (two rows share a mask word; the third / fourth row pair takes the second word), ragged last lanes (N = 777,
+    # 17, 4097) and both sweeps (ascending parents + N > 1024 = the window sweep).
+    LG, L = 1200000, 26
+    rng = np.random.default_rng(N * 31 + rows + int(total * 1e4))
+    m0 = _rand_core(rng, N, L)
+    sample = rng.integers(0, N, N).astype(np.uint32)
+    if ascending:
+        sample = np.sort(sample)
+    lm, lh = (total - 0.002) * LG, 0.002 * LG
+    plan = orc.core_plan(lm, lh, LG)
+    assert (plan.bC <= 15) == stash, plan.bC
+    want = orc.next_generation(m0, sample)
+    orc.mutate_core(want, 40, 77, 11, plan)
+    orc.recombine_core(want, 40, 77, 11, plan)
+    pop = pa.Population(N, L, 4, True, 0.0, 77, 0, col_offset=40, global_cols=LG)
+    pop.set_tuning("sweep_rows", rows)
+    pop.set_rates([lm], [lh])
+    pop.load_matrix(m0)
+    pop.step(11, sample, True)
+    assert np.array_equal(pop.read_matrix(), want)
+    pop.close()
+
+
 @pytest.mark.parametrize("N,L,tune", [(1000, 60, {}), (1000, 45, {"sweep_rows": 2}), (1000, 33, {"sweep_rows": 4}),
                                       (3000, 40, {}), (1000, 50, {"force_block_sweep": 1}), (9000, 24, {"block_batch": 2}),
                                       (9000, 20, {"no_block_preload": 1}), (5000, 40, {"block_waves": 4}),
