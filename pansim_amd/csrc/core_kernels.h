@@ -266,7 +266,7 @@ __device__ __forceinline__ uint32_t ps_wave_scan_incl(uint32_t x)
 // where the ballot / mbcnt loop this replaces (one queue slot per ballot bit; kept for the non-STASH entries, which carry
 // the level-1 byte) spent ~36 per trip on ~5 trips plus three exec-mask branches each.  The order of the queue changes
 // (lane-major), its content does not; nothing is written when the batch does not fit (the caller redoes it queue-free).
-// Entry: bit position p (0-31) | lane << 5 | word << 12; returns the wave-uniform number of candidates of the batch.
+// Entry: bit position p (0-31) | word << 5 | lane << 6; returns the wave-uniform number of candidates of the batch.
 template <uint32_t PS_ROWS>
 __device__ __forceinline__ uint32_t ps_push_scan(const uint32_t (&cm)[PS_ROWS], uint32_t *q, uint32_t lane, uint32_t qcap)
 {
@@ -277,20 +277,24 @@ __device__ __forceinline__ uint32_t ps_push_scan(const uint32_t (&cm)[PS_ROWS], 
     const uint32_t qn = __builtin_amdgcn_readlane(incl, 63);
     if (qn <= qcap) {
         uint32_t *qp = q + (incl - c);
-        const uint32_t tag = lane << 5;
+        const uint32_t tag = lane << 6;
         for (uint32_t m = w0; m; m &= m - 1u) *qp++ = tag | (uint32_t)__builtin_ctz(m);
         if (PS_ROWS > 2)
-            for (uint32_t m = w1; m; m &= m - 1u) *qp++ = tag | 4096u | (uint32_t)__builtin_ctz(m);
+            for (uint32_t m = w1; m; m &= m - 1u) *qp++ = tag | 32u | (uint32_t)__builtin_ctz(m);
     }
     return qn;
 }
 
-// ... and the cell of such an entry inside the lane's rows: lane * 16 + 4 * j + b, and the row (2 * word + nibble half)
-__device__ __forceinline__ void ps_push_scan_decode(uint32_t ent, uint32_t &cell, uint32_t &row)
+// ... and what the low six bits of such an entry (bit position | word << 5) mean, as a 64-entry table the wave keeps in its
+// LDS (the dense pass, every lane busy, then spends one ds_read_b32 where the bit arithmetic took nine vector instructions):
+// low half = byte offset of the cell in the wave's row buffers less the lane's 16 * lane (row * STRIDE + 4 * j + b), high half
+// = the same cell as the later passes name it (4 * j + b | row << 10).  Bit p = 8 * b + 7 - t, t = j + 4 * (row & 1).
+#define PS_PUSH_TABLE_BYTES 256u
+template <uint32_t STRIDE>
+__device__ __forceinline__ uint32_t ps_push_table_entry(uint32_t idx)
 {
-    const uint32_t p = ent & 31u, t = ~p & 7u;          // t = j + 4 * (row & 1)
-    cell = (((ent >> 5) & 63u) << 4) + ((t & 3u) << 2) + (p >> 3);
-    row = ((ent >> 12) << 1) | (t >> 2);
+    const uint32_t p = idx & 31u, t = ~p & 7u, cell = ((t & 3u) << 2) + (p >> 3), row = ((idx >> 5) << 1) | (t >> 2);
+    return (row * STRIDE + cell) | ((cell | (row << 10)) << 16);
 }
 
 // four zero-extended bytes -> one dword (two v_perm + v_or; the compiler's own form masks every byte again)
@@ -343,8 +347,10 @@ __global__ void __launch_bounds__(256, PS_ROWS >= 4 ? 6 : PS_WAVE_LB) core_sweep
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     // LDS rows have a fixed 1024-byte stride, so the low 12 bits of a queue entry
     // (cell | row << 10) are the byte address of the cell inside rowbuf
-    uint8_t *rowbuf = lds + wave * (PS_ROWS * 1024u + PS_QCAP * 4u);
+    uint8_t *rowbuf = lds + wave * (PS_ROWS * 1024u + PS_QCAP * 4u + PS_PUSH_TABLE_BYTES);
     uint32_t *q = (uint32_t *)(rowbuf + PS_ROWS * 1024u);
+    uint32_t *ptab = q + PS_QCAP;                      // the wave's copy of the push table (ps_push_table_entry)
+    if (STASH) ptab[lane] = ps_push_table_entry<1024u>(lane);
     const ps_core_plan pl = a.plan;
     // (the host launches the mutate / HR variants only for plans that have events: the per-row code below
     // is straight-line -- no wave-uniform branches around the Philox call, the LDS stores or the tail rows)
@@ -548,22 +554,19 @@ __global__ void __launch_bounds__(256, PS_ROWS >= 4 ? 6 : PS_WAVE_LB) core_sweep
                 const uint32_t e = base + lane;
                 const bool valid = e < qn;
                 uint32_t ent = valid ? q[e] : 0u;
-                if (STASH) {
-                    // ps_push_scan's entry -> byte address in rowbuf (cell | row << 10) | stashed nibble << 12
-                    uint32_t cl, rw;
-                    ps_push_scan_decode(ent, cl, rw);
-                    const uint32_t addr = cl | (rw << 10);
-                    ent = addr | ((uint32_t)(rowbuf[addr] >> 4) << 12);
-                }
-                const uint32_t byte = (ent >> 12) & 0xFFu;
                 uint32_t allele = 0;
                 if (STASH) {
-                    // (a stashed byte is below 16: the low word of the table, and 1 << 0 masked away)
-                    allele = (1u << (((uint32_t)lut >> (2u * byte)) & 3u)) & 14u;
+                    // ps_push_scan's entry -> (cell | row << 10 = byte address in rowbuf) | stashed nibble << 12; a stashed
+                    // byte is below 16: the low word of the interval table, and 1 << 0 masked away
+                    const uint32_t t = ptab[ent & 63u], lane16 = (ent >> 2) & 0x3F0u;
+                    const uint32_t nib = (uint32_t)rowbuf[(t & 0xFFFFu) + lane16] >> 4;
+                    allele = (1u << (((uint32_t)lut >> (2u * nib)) & 3u)) & 14u;
+                    ent = (t >> 16) | lane16 | (nib << 12);
                 } else if (use_lut) {
-                    const uint32_t code = (uint32_t)(lut >> (2u * (byte & 31u))) & 3u;
+                    const uint32_t code = (uint32_t)(lut >> (2u * ((ent >> 12) & 31u))) & 3u;
                     allele = code ? (1u << code) : 0u;
                 } else {
+                    const uint32_t byte = (ent >> 12) & 0xFFu;
                     if (byte < t0b) allele = 2u;
                     else if (byte > t0b && byte < t1b) allele = 4u;
                     else if (byte > t1b && byte < t2b) allele = 8u;
@@ -717,8 +720,10 @@ __global__ void __launch_bounds__(256, PS_WLB) core_sweep_window_kernel(core_swe
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     // per wave: PS_ROWS row buffers of PS_WCAP bytes -- the parents' window arrives there by LDS-DMA, the child row
     // (1024 bytes) overwrites its start once the gather has read it -- and the candidate queue
-    uint8_t *rowbuf = lds + wave * (PS_ROWS * PS_WSTRIDE + PS_QCAP * 4u);
+    uint8_t *rowbuf = lds + wave * (PS_ROWS * PS_WSTRIDE + PS_QCAP * 4u + PS_PUSH_TABLE_BYTES);
     uint32_t *q = (uint32_t *)(rowbuf + PS_ROWS * PS_WSTRIDE);
+    uint32_t *ptab = q + PS_QCAP;                      // the wave's copy of the push table (ps_push_table_entry)
+    if (STASH) ptab[lane] = ps_push_table_entry<PS_WSTRIDE>(lane);
     if (lane < PS_ROWS) *(uint4 *)(rowbuf + lane * PS_WSTRIDE + PS_WCAP) = make_uint4(0, 0, 0, 0);     // the zero bytes (never rewritten)
     const ps_core_plan pl = a.plan;
     // the wave's segment, fixed for the launch
@@ -915,28 +920,28 @@ __global__ void __launch_bounds__(256, PS_WLB) core_sweep_window_kernel(core_swe
                 const uint32_t e = base + lane;
                 const bool valid = e < qn;
                 uint32_t ent = valid ? q[e] : 0u;
+                uint32_t allele = 0, addr = 0;
                 if (STASH) {
-                    // ps_push_scan's entry -> cell | row << 10 | nibble << 12
-                    uint32_t cl, rr;
-                    ps_push_scan_decode(ent, cl, rr);
-                    ent = cl | (rr << 10);
-                    ent |= (uint32_t)(rowbuf[cell_addr(ent)] >> 4) << 12;
-                }
-                const uint32_t byte = (ent >> 12) & 0xFFu;
-                uint32_t allele = 0;
-                if (STASH) {
-                    // (a stashed byte is below 16: the low word of the table, and 1 << 0 masked away)
-                    allele = (1u << (((uint32_t)lut >> (2u * byte)) & 3u)) & 14u;
-                } else if (use_lut) {
-                    const uint32_t code = (uint32_t)(lut >> (2u * (byte & 31u))) & 3u;
-                    allele = code ? (1u << code) : 0u;
+                    // ps_push_scan's entry -> cell | row << 10 | nibble << 12 (see the wave sweep), and the cell's place in LDS
+                    const uint32_t t = ptab[ent & 63u], lane16 = (ent >> 2) & 0x3F0u;
+                    addr = (t & 0xFFFFu) + lane16;
+                    const uint32_t nib = (uint32_t)rowbuf[addr] >> 4;
+                    allele = (1u << (((uint32_t)lut >> (2u * nib)) & 3u)) & 14u;
+                    ent = (t >> 16) | lane16 | (nib << 12);
                 } else {
-                    if (byte < t0b) allele = 2u;
-                    else if (byte > t0b && byte < t1b) allele = 4u;
-                    else if (byte > t1b && byte < t2b) allele = 8u;
+                    const uint32_t byte = (ent >> 12) & 0xFFu;
+                    addr = cell_addr(ent);
+                    if (use_lut) {
+                        const uint32_t code = (uint32_t)(lut >> (2u * (byte & 31u))) & 3u;
+                        allele = code ? (1u << code) : 0u;
+                    } else {
+                        if (byte < t0b) allele = 2u;
+                        else if (byte > t0b && byte < t1b) allele = 4u;
+                        else if (byte > t1b && byte < t2b) allele = 8u;
+                    }
                 }
                 const bool amb = valid && allele == 0u;
-                if (DO_MUT && valid && allele) rowbuf[cell_addr(ent)] = (uint8_t)allele;
+                if (DO_MUT && valid && allele) rowbuf[addr] = (uint8_t)allele;
                 const uint64_t bal = __ballot(amb);
                 if (amb) q[n2 + ps_lane_prefix(bal)] = ent;
                 n2 += (uint32_t)__popcll(bal);

@@ -674,7 +674,7 @@ template <uint32_t ROWS, bool GA, bool MU, bool HR>
 static int launch_core_sweep_wave_r(ps_population *p, const core_sweep_args &a, hipStream_t st)
 {
     const uint32_t block = 256u, wpb = block / 64u;
-    const uint32_t lds = wpb * (ROWS * 1024u + ps_qcap(ROWS) * 4u);
+    const uint32_t lds = wpb * (ROWS * 1024u + ps_qcap(ROWS) * 4u + PS_PUSH_TABLE_BYTES);
     const uint32_t want = (a.rows + wpb * ROWS - 1) / (wpb * ROWS);
     const uint32_t fit = std::max(1u, std::min(8u, p->lds_limit / lds));
     const uint32_t bpc = std::min(p->sweep_blocks_per_cu, fit);
@@ -836,7 +836,7 @@ template <bool HR>
 static int launch_core_sweep_window(ps_population *p, const core_sweep_args &a, hipStream_t st)
 {
     constexpr uint32_t ROWS = 3;
-    const uint32_t lds = 4u * (ROWS * PS_WSTRIDE + PS_WQCAP * 4u);
+    const uint32_t lds = 4u * (ROWS * PS_WSTRIDE + PS_WQCAP * 4u + PS_PUSH_TABLE_BYTES);
     // ("window_blocks_per_cu": a donor-sharded run leaves the exchange's kernels room beside the sweep)
     const uint32_t bpc = std::max(1u, std::min(p->window_blocks_per_cu ? p->window_blocks_per_cu : (uint32_t)PS_WBPC, p->lds_limit / lds));
     const uint32_t segs = (a.N + 1023u) / 1024u;
@@ -900,7 +900,7 @@ static int launch_core_sweep(ps_population *p, const uint32_t *d_idx, uint32_t g
     bool window = !wave && parents_sorted && ga && mu && a.plan.has_events && p->window_sweep != 0 && p->pitch > 1024
                   && a.N <= (1u << 22)
                   && a.plan.bC <= 126u && !p->force_inline_sweep && !p->force_block_sweep
-                  && 4u * (3u * PS_WSTRIDE + PS_WQCAP * 4u) <= p->lds_limit;
+                  && 4u * (3u * PS_WSTRIDE + PS_WQCAP * 4u + PS_PUSH_TABLE_BYTES) <= p->lds_limit;
     if (window) {
         // (a full queue only sends the batch to the queue-free redo; 10 sigma of room as for the wave sweep)
         const double m = 3.0 * 1024.0 * (double)(a.plan.bC + 1u) / 256.0;
