@@ -93,9 +93,12 @@ __device__ __forceinline__ uint32_t ps_candidate_mask(const ps_u4 &l1, uint32_t 
 
 __device__ __forceinline__ uint32_t ps_l1_byte(const ps_u4 &l1, uint32_t k)
 {
-    const uint32_t j = k >> 2;
-    const uint32_t w = (j == 0) ? l1.x : (j == 1) ? l1.y : (j == 2) ? l1.z : l1.w;
-    return (w >> ((k & 3u) * 8u)) & 0xFFu;
+    // branch-free: the word pair by bit 3 of k, then one v_perm_b32 over its eight bytes (the ternary chain compiles to three
+    // levels of exec-mask branches).  By value: selecting between members of the referenced struct sends it to scratch.
+    const uint32_t x = l1.x, y = l1.y, z = l1.z, w = l1.w;
+    const bool hi = (k & 8u) != 0u;
+    const uint32_t lo_w = hi ? z : x, hi_w = hi ? w : y;
+    return __builtin_amdgcn_perm(hi_w, lo_w, (k & 7u) | 0x0c0c0c00u);
 }
 
 // Inline block sweep: the queue-free fallback of the block sweep below.  One 1024-thread
@@ -276,11 +279,11 @@ __device__ __forceinline__ uint32_t ps_push_scan(const uint32_t (&cm)[PS_ROWS], 
     const uint32_t incl = ps_wave_scan_incl(c);
     const uint32_t qn = __builtin_amdgcn_readlane(incl, 63);
     if (qn <= qcap) {
-        uint32_t *qp = q + (incl - c);
+        uint32_t *qp = q + (incl - c) - 1;      // (pre-increment: the store takes the new address, no register copy per trip)
         const uint32_t tag = lane << 6;
-        for (uint32_t m = w0; m; m &= m - 1u) *qp++ = tag | (uint32_t)__builtin_ctz(m);
+        for (uint32_t m = w0; m; m &= m - 1u) *++qp = tag | (uint32_t)__builtin_ctz(m);
         if (PS_ROWS > 2)
-            for (uint32_t m = w1; m; m &= m - 1u) *qp++ = tag | 32u | (uint32_t)__builtin_ctz(m);
+            for (uint32_t m = w1; m; m &= m - 1u) *++qp = tag | 32u | (uint32_t)__builtin_ctz(m);
     }
     return qn;
 }
@@ -481,7 +484,7 @@ __global__ void __launch_bounds__(256, PS_ROWS >= 4 ? 6 : PS_WAVE_LB) core_sweep
 #pragma unroll
                 for (uint32_t rr = 0; rr < PS_ROWS; rr++) {
                     const bool act = cm[rr] != 0u;
-                    const uint64_t bal = __ballot(act);
+                    const uint64_t bal = __builtin_amdgcn_ballot_w64(act);
                     if (act) {
                         const uint32_t p = __builtin_ctz(cm[rr]);
                         cm[rr] &= cm[rr] - 1u;
@@ -573,7 +576,7 @@ __global__ void __launch_bounds__(256, PS_ROWS >= 4 ? 6 : PS_WAVE_LB) core_sweep
                 }
                 const bool amb = valid && allele == 0u;
                 if (DO_MUT && valid && allele) rowbuf[ent & 4095u] = (uint8_t)allele;
-                const uint64_t bal = __ballot(amb);
+                const uint64_t bal = __builtin_amdgcn_ballot_w64(amb);
                 if (amb) q[n2 + ps_lane_prefix(bal)] = ent;
                 n2 += (uint32_t)__popcll(bal);
             }
@@ -869,7 +872,7 @@ __global__ void __launch_bounds__(256, PS_WLB) core_sweep_window_kernel(core_swe
 #pragma unroll
             for (uint32_t rr = 0; rr < PS_ROWS; rr++) {
                 const bool act = cm[rr] != 0u;
-                const uint64_t bal = __ballot(act);
+                const uint64_t bal = __builtin_amdgcn_ballot_w64(act);
                 if (act) {
                     const uint32_t p = __builtin_ctz(cm[rr]);
                     cm[rr] &= cm[rr] - 1u;
@@ -942,7 +945,7 @@ __global__ void __launch_bounds__(256, PS_WLB) core_sweep_window_kernel(core_swe
                 }
                 const bool amb = valid && allele == 0u;
                 if (DO_MUT && valid && allele) rowbuf[addr] = (uint8_t)allele;
-                const uint64_t bal = __ballot(amb);
+                const uint64_t bal = __builtin_amdgcn_ballot_w64(amb);
                 if (amb) q[n2 + ps_lane_prefix(bal)] = ent;
                 n2 += (uint32_t)__popcll(bal);
             }
@@ -1178,7 +1181,7 @@ __global__ void __launch_bounds__(1024) core_sweep_block_kernel(core_sweep_args 
                             const uint32_t off0 = s_base[s] + i0;
                             for (;;) {
                                 const bool act = cm != 0u;
-                                const uint64_t bal = __ballot(act);
+                                const uint64_t bal = __builtin_amdgcn_ballot_w64(act);
                                 if (bal == 0ull) break;
                                 if (act) {
                                     const uint32_t p = __builtin_ctz(cm);
@@ -1216,7 +1219,7 @@ __global__ void __launch_bounds__(1024) core_sweep_block_kernel(core_sweep_args 
 #pragma unroll
                     for (uint32_t s = 0; s < PS_SB; s++) {
                         const bool act = cmv[s] != 0u;
-                        const uint64_t bal = __ballot(act);
+                        const uint64_t bal = __builtin_amdgcn_ballot_w64(act);
                         if (act) {
                             const uint32_t p = __builtin_ctz(cmv[s]);
                             cmv[s] &= cmv[s] - 1u;
@@ -1265,7 +1268,7 @@ __global__ void __launch_bounds__(1024) core_sweep_block_kernel(core_sweep_args 
                 }
                 const bool amb = valid && allele == 0u;
                 if (DO_MUT && valid && allele) rowS[ent & 0xFFFFFu] = (uint8_t)allele;
-                const uint64_t bal = __ballot(amb);
+                const uint64_t bal = __builtin_amdgcn_ballot_w64(amb);
                 if (amb) q[n2 + ps_lane_prefix(bal)] = ent;
                 n2 += (uint32_t)__popcll(bal);
             }
@@ -1298,7 +1301,7 @@ __global__ void __launch_bounds__(1024) core_sweep_block_kernel(core_sweep_args 
                     }
                 }
                 if (DO_HR) {
-                    const uint64_t bal = __ballot(hr);
+                    const uint64_t bal = __builtin_amdgcn_ballot_w64(hr);
                     if (hr) {
                         const uint32_t pos = nhr + ps_lane_prefix(bal);
                         if (pos < hcap) { hr_a[pos] = off; hr_b[pos] = rbase + donor; }
