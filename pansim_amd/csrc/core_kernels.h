@@ -275,15 +275,17 @@ __device__ __forceinline__ uint32_t ps_push_scan(const uint32_t (&cm)[PS_ROWS], 
 {
     const uint32_t w0 = cm[0] | (PS_ROWS > 1 ? cm[PS_ROWS > 1 ? 1 : 0] : 0u);
     const uint32_t w1 = PS_ROWS > 2 ? (cm[PS_ROWS > 2 ? 2 : 0] | (PS_ROWS > 3 ? cm[PS_ROWS > 3 ? 3 : 0] : 0u)) : 0u;
-    const uint32_t c = (uint32_t)__popc(w0) + (PS_ROWS > 2 ? (uint32_t)__popc(w1) : 0u);
+    const uint32_t c0 = (uint32_t)__popc(w0), c = c0 + (PS_ROWS > 2 ? (uint32_t)__popc(w1) : 0u);
     const uint32_t incl = ps_wave_scan_incl(c);
     const uint32_t qn = __builtin_amdgcn_readlane(incl, 63);
     if (qn <= qcap) {
-        uint32_t *qp = q + (incl - c) - 1;      // (pre-increment: the store takes the new address, no register copy per trip)
+        // (pre-increment and a start of its own per loop: the store takes the new address and no pointer lives across the loops,
+        // i.e. no register copy per trip)
+        uint32_t *qp = q + (incl - c) - 1, *qp1 = qp + c0;
         const uint32_t tag = lane << 6;
         for (uint32_t m = w0; m; m &= m - 1u) *++qp = tag | (uint32_t)__builtin_ctz(m);
         if (PS_ROWS > 2)
-            for (uint32_t m = w1; m; m &= m - 1u) *++qp = tag | 32u | (uint32_t)__builtin_ctz(m);
+            for (uint32_t m = w1; m; m &= m - 1u) *++qp1 = tag | 32u | (uint32_t)__builtin_ctz(m);
     }
     return qn;
 }
