@@ -169,7 +169,7 @@ int ps_last_pair_form(ps_population *p);
 enum {
     PS_SWEEP_FORM_NONE = 0,
     PS_SWEEP_FORM_WAVE = 1,        /* core_sweep_wave_kernel, one wave per site row (N <= 1024) */
-    PS_SWEEP_FORM_WAVE_STASH = 2,  /* the same with the level-1 nibble carried in the child byte (every candidate byte < 16) */
+    PS_SWEEP_FORM_WAVE_STASH = 2,  /* the same with the level-1 nibble carried in the child byte (every candidate byte < 32; bit 4 in the queue entry) */
     PS_SWEEP_FORM_WINDOW = 3,      /* core_sweep_window_kernel: N > 1024, children in ascending parent order, out of place */
     PS_SWEEP_FORM_BLOCK = 4,       /* core_sweep_block_kernel: N > 1024, whole rows in workgroup-shared LDS, in place */
     PS_SWEEP_FORM_INLINE = 5       /* core_sweep_inline_kernel: the queue-free form for any rates */

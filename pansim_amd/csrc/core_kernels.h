@@ -270,12 +270,18 @@ __device__ __forceinline__ uint32_t ps_wave_scan_incl(uint32_t x)
 // the level-1 byte) spent ~36 per trip on ~5 trips plus three exec-mask branches each.  The order of the queue changes
 // (lane-major), its content does not; nothing is written when the batch does not fit (the caller redoes it queue-free).
 // Entry: bit position p (0-31) | word << 5 | lane << 6; returns the wave-uniform number of candidates of the batch.
+// Candidate bytes of 16-31 (plans with 15 < bC <= 31, `hi` wave-uniform): the stashed nibble is the byte's low one and bit 4 rides in
+// the ENTRY -- such cells come in two more mask words (w0h / w1h) and are pushed behind the others with bit 12 set.
 template <uint32_t PS_ROWS>
-__device__ __forceinline__ uint32_t ps_push_scan(const uint32_t (&cm)[PS_ROWS], uint32_t *q, uint32_t lane, uint32_t qcap)
+__device__ __forceinline__ uint32_t ps_push_scan(uint32_t w0, uint32_t w1, uint32_t w0h, uint32_t w1h, bool hi, uint32_t *q, uint32_t lane,
+                                                 uint32_t qcap)
 {
-    const uint32_t w0 = cm[0] | (PS_ROWS > 1 ? cm[PS_ROWS > 1 ? 1 : 0] : 0u);
-    const uint32_t w1 = PS_ROWS > 2 ? (cm[PS_ROWS > 2 ? 2 : 0] | (PS_ROWS > 3 ? cm[PS_ROWS > 3 ? 3 : 0] : 0u)) : 0u;
-    const uint32_t c0 = (uint32_t)__popc(w0), c = c0 + (PS_ROWS > 2 ? (uint32_t)__popc(w1) : 0u);
+    const uint32_t c0 = (uint32_t)__popc(w0), c1 = PS_ROWS > 2 ? (uint32_t)__popc(w1) : 0u;
+    uint32_t c = c0 + c1, c2 = 0;
+    if (hi) {
+        c2 = (uint32_t)__popc(w0h);
+        c += c2 + (PS_ROWS > 2 ? (uint32_t)__popc(w1h) : 0u);
+    }
     const uint32_t incl = ps_wave_scan_incl(c);
     const uint32_t qn = __builtin_amdgcn_readlane(incl, 63);
     if (qn <= qcap) {
@@ -286,6 +292,12 @@ __device__ __forceinline__ uint32_t ps_push_scan(const uint32_t (&cm)[PS_ROWS], 
         for (uint32_t m = w0; m; m &= m - 1u) *++qp = tag | (uint32_t)__builtin_ctz(m);
         if (PS_ROWS > 2)
             for (uint32_t m = w1; m; m &= m - 1u) *++qp1 = tag | 32u | (uint32_t)__builtin_ctz(m);
+        if (hi) {
+            uint32_t *qp2 = q + (incl - c) - 1 + c0 + c1, *qp3 = qp2 + c2;
+            for (uint32_t m = w0h; m; m &= m - 1u) *++qp2 = tag | 4096u | (uint32_t)__builtin_ctz(m);
+            if (PS_ROWS > 2)
+                for (uint32_t m = w1h; m; m &= m - 1u) *++qp3 = tag | (4096u | 32u) | (uint32_t)__builtin_ctz(m);
+        }
     }
     return qn;
 }
@@ -328,15 +340,16 @@ __device__ __forceinline__ uint4 ps_strip(uint4 v, bool on)
 #else
 #define PS_T(k) do { } while (0)
 #endif
-// STASH (host: every candidate byte is below 16, i.e. bC <= 15 -- the default rates): the low nibble of
+// STASH = 1 (host: every candidate byte is below 16, i.e. bC <= 15 -- the default rates): the low nibble of
 // a cell's level-1 byte rides in the high nibble of its child byte in LDS (alleles only use bits 0-3),
-// so a queue entry is just (bit position | lane << 5 | row << 11) -- one v_add per pushed candidate instead
-// of the v_perm byte extraction -- and the dense pass, with every lane busy, decodes the cell address and
-// reads the byte back from the row.  The nibbles are stripped when the row leaves LDS.
+// so a queue entry is just (bit position | word << 5 | lane << 6) -- no v_perm byte extraction per pushed candidate --
+// and the dense pass, with every lane busy, looks the cell up and reads the byte back from the row.  The nibbles
+// are stripped when the row leaves LDS.  STASH = 2 (15 < bC <= 31: cfg3's rates): the same with bit 4 of the byte
+// in the entry (a build of its own: the extra compare and mask words cost the STASH = 1 kernels registers).
 #ifndef PS_WAVE_LB
 #define PS_WAVE_LB 8      // waves per SIMD the wave sweep is built for (8 = 64 VGPRs, 7 = 72, 6 = 84)
 #endif
-template <uint32_t PS_ROWS, bool DO_GATHER, bool DO_MUT, bool DO_HR, bool STASH, bool NT = false>
+template <uint32_t PS_ROWS, bool DO_GATHER, bool DO_MUT, bool DO_HR, uint32_t STASH, bool NT = false>
 __global__ void __launch_bounds__(256, PS_ROWS >= 4 ? 6 : PS_WAVE_LB) core_sweep_wave_kernel(core_sweep_args a)
 {
 #ifdef PS_STAMP
@@ -379,6 +392,7 @@ __global__ void __launch_bounds__(256, PS_ROWS >= 4 ? 6 : PS_WAVE_LB) core_sweep
         lut |= code << (2u * bb);
     }
     const bool use_lut = pl.bC < 32u;
+    constexpr bool hi_class = STASH == 2u;      // candidate bytes reach 16-31: see ps_push_scan
 
     uint32_t pidx[16];
     if (DO_GATHER) {
@@ -441,6 +455,7 @@ __global__ void __launch_bounds__(256, PS_ROWS >= 4 ? 6 : PS_WAVE_LB) core_sweep
         // 0.543 against 0.530 ms.)
         uint32_t qn = 0;        // wave-uniform number of queued candidate cells
         uint32_t cm[PS_ROWS];
+        uint32_t wl[2] = { 0u, 0u }, wh[2] = { 0u, 0u };      // STASH: the mask words of ps_push_scan (two rows each; bytes < 16 / 16-31)
         ps_u4 l1[PS_ROWS];      // (only the non-STASH push loop reads it back)
 #pragma unroll
         for (uint32_t rr = 0; rr < PS_ROWS; rr++) {
@@ -462,6 +477,12 @@ __global__ void __launch_bounds__(256, PS_ROWS >= 4 ? 6 : PS_WAVE_LB) core_sweep
                 if (STASH) {
                     d.x = ps_stash(d.x, l1[rr].x); d.y = ps_stash(d.y, l1[rr].y);
                     d.z = ps_stash(d.z, l1[rr].z); d.w = ps_stash(d.w, l1[rr].w);
+                    uint32_t lo = cm[rr];
+                    if (hi_class) {       // candidate bytes 16-31 go to the second pair of mask words
+                        lo &= (rr & 1u) ? ps_candidates_swar_lo(l1[rr], 0x10101010u) : ps_candidates_swar(l1[rr], 0x10101010u);
+                        wh[rr >> 1] |= cm[rr] & ~lo;
+                    }
+                    wl[rr >> 1] |= lo;
                 }
             }
             PS_T(2);   // level-1 Philox + detection
@@ -473,7 +494,7 @@ __global__ void __launch_bounds__(256, PS_ROWS >= 4 ? 6 : PS_WAVE_LB) core_sweep
         const uint32_t qcap = a.qcap_limit ? min(PS_QCAP, a.qcap_limit) : PS_QCAP;
         if (events && STASH) {
             // Phase 2: every candidate cell of the PS_ROWS rows into the wave queue (one prefix sum, then lane-private writes)
-            qn = ps_push_scan<PS_ROWS>(cm, q, lane, qcap);
+            qn = ps_push_scan<PS_ROWS>(wl[0], wl[1], wh[0], wh[1], hi_class, q, lane, qcap);
         } else if (events) {
             // ... entries that carry the level-1 byte: ONE ballot loop for all
             // rows -- its trip count is the largest number of candidates any lane holds in any single row
@@ -564,8 +585,13 @@ __global__ void __launch_bounds__(256, PS_ROWS >= 4 ? 6 : PS_WAVE_LB) core_sweep
                     // ps_push_scan's entry -> (cell | row << 10 = byte address in rowbuf) | stashed nibble << 12; a stashed
                     // byte is below 16: the low word of the interval table, and 1 << 0 masked away
                     const uint32_t t = ptab[ent & 63u], lane16 = (ent >> 2) & 0x3F0u;
-                    const uint32_t nib = (uint32_t)rowbuf[(t & 0xFFFFu) + lane16] >> 4;
-                    allele = (1u << (((uint32_t)lut >> (2u * nib)) & 3u)) & 14u;
+                    uint32_t nib = (uint32_t)rowbuf[(t & 0xFFFFu) + lane16] >> 4;
+                    if (hi_class) {
+                        nib |= (ent >> 8) & 16u;        // bit 4 of the byte rode in the entry
+                        allele = (1u << ((uint32_t)(lut >> (2u * nib)) & 3u)) & 14u;
+                    } else {
+                        allele = (1u << (((uint32_t)lut >> (2u * nib)) & 3u)) & 14u;
+                    }
                     ent = (t >> 16) | lane16 | (nib << 12);
                 } else if (use_lut) {
                     const uint32_t code = (uint32_t)(lut >> (2u * ((ent >> 12) & 31u))) & 3u;
@@ -717,7 +743,7 @@ __device__ __forceinline__ uint32_t ps_donor_value(const core_sweep_args &a, con
 // the others (parents far apart: strong selection against a stretch of the population) -- same code, the bytes gathered
 // straight from the old row in global memory; ascending parents keep every load instruction's 64 addresses in one compact
 // range.  A wave whose segment belongs to the other launch leaves at once.
-template <uint32_t PS_ROWS, bool DO_MUT, bool DO_HR, bool STASH, bool NT, bool WIDE>
+template <uint32_t PS_ROWS, bool DO_MUT, bool DO_HR, uint32_t STASH, bool NT, bool WIDE>
 __global__ void __launch_bounds__(256, PS_WLB) core_sweep_window_kernel(core_sweep_args a)
 {
     constexpr uint32_t PS_QCAP = PS_WQCAP;
@@ -775,6 +801,7 @@ __global__ void __launch_bounds__(256, PS_WLB) core_sweep_window_kernel(core_swe
         lut |= code << (2u * bb);
     }
     const bool use_lut = pl.bC < 32u;
+    constexpr bool hi_class = STASH == 2u;      // candidate bytes reach 16-31: see ps_push_scan
     const bool ld0 = !WIDE && i0 < wbytes, ld1 = !WIDE && 1024u + i0 < wbytes;
     // LDS address of a queue entry's cell: (cell | row << 10) -> row * PS_WCAP + cell
     auto cell_addr = [](uint32_t ent) -> uint32_t { return (ent & 1023u) + ((ent >> 10) & 3u) * PS_WSTRIDE; };
@@ -831,6 +858,7 @@ __global__ void __launch_bounds__(256, PS_WLB) core_sweep_window_kernel(core_swe
         ps_wave_sync();
         uint32_t qn = 0;
         uint32_t cm[PS_ROWS];
+        uint32_t wl[2] = { 0u, 0u }, wh[2] = { 0u, 0u };      // STASH: the mask words of ps_push_scan (two rows each; bytes < 16 / 16-31)
         ps_u4 l1[PS_ROWS];      // (only the non-STASH push loop reads it back)
 #pragma unroll
         for (uint32_t rr = 0; rr < PS_ROWS; rr++) {
@@ -857,6 +885,12 @@ __global__ void __launch_bounds__(256, PS_WLB) core_sweep_window_kernel(core_swe
             if (STASH) {
                 d.x = ps_stash(d.x, l1[rr].x); d.y = ps_stash(d.y, l1[rr].y);
                 d.z = ps_stash(d.z, l1[rr].z); d.w = ps_stash(d.w, l1[rr].w);
+                uint32_t lo = cm[rr];
+                if (hi_class) {       // candidate bytes 16-31 go to the second pair of mask words
+                    lo &= (rr & 1u) ? ps_candidates_swar_lo(l1[rr], 0x10101010u) : ps_candidates_swar(l1[rr], 0x10101010u);
+                    wh[rr >> 1] |= cm[rr] & ~lo;
+                }
+                wl[rr >> 1] |= lo;
             }
             ps_wave_sync();                                     // the row buffer becomes the child row: every gather read precedes
             *(uint4 *)(win + i0) = d;
@@ -864,7 +898,7 @@ __global__ void __launch_bounds__(256, PS_WLB) core_sweep_window_kernel(core_swe
         }
         // the push of the wave sweep: one prefix sum and lane-private writes (STASH), or ONE ballot loop for all rows
         const uint32_t qcap = a.qcap_limit ? min(PS_QCAP, a.qcap_limit) : PS_QCAP;
-        if (STASH) qn = ps_push_scan<PS_ROWS>(cm, q, lane, qcap);
+        if (STASH) qn = ps_push_scan<PS_ROWS>(wl[0], wl[1], wh[0], wh[1], hi_class, q, lane, qcap);
         else
         for (;;) {
             uint32_t any = cm[0];
@@ -930,8 +964,13 @@ __global__ void __launch_bounds__(256, PS_WLB) core_sweep_window_kernel(core_swe
                     // ps_push_scan's entry -> cell | row << 10 | nibble << 12 (see the wave sweep), and the cell's place in LDS
                     const uint32_t t = ptab[ent & 63u], lane16 = (ent >> 2) & 0x3F0u;
                     addr = (t & 0xFFFFu) + lane16;
-                    const uint32_t nib = (uint32_t)rowbuf[addr] >> 4;
-                    allele = (1u << (((uint32_t)lut >> (2u * nib)) & 3u)) & 14u;
+                    uint32_t nib = (uint32_t)rowbuf[addr] >> 4;
+                    if (hi_class) {
+                        nib |= (ent >> 8) & 16u;        // bit 4 of the byte rode in the entry
+                        allele = (1u << ((uint32_t)(lut >> (2u * nib)) & 3u)) & 14u;
+                    } else {
+                        allele = (1u << (((uint32_t)lut >> (2u * nib)) & 3u)) & 14u;
+                    }
                     ent = (t >> 16) | lane16 | (nib << 12);
                 } else {
                     const uint32_t byte = (ent >> 12) & 0xFFu;

@@ -681,13 +681,16 @@ static int launch_core_sweep_wave_r(ps_population *p, const core_sweep_args &a, 
     const uint32_t grid = std::max(8u, std::min((want + 7u) & ~7u, 256u * bpc));   // a multiple of the 8 groups
     // every candidate byte below 16 and every state byte below 16 (a loaded matrix may hold any byte): the level-1
     // nibble rides in the child byte (core_kernels.h, STASH)
-    const bool stash = a.plan.has_events && a.plan.bC <= 15u && p->nibble_safe;
+    // (bytes 16-31: bit 4 rides in the queue entry, STASH = 2)
+    const uint32_t stash = (a.plan.has_events && p->nibble_safe) ? (a.plan.bC <= 15u ? 1u : a.plan.bC <= 31u ? 2u : 0u) : 0u;
     if (a.nt) {
-        if (stash) hipLaunchKernelGGL((core_sweep_wave_kernel<ROWS, GA, MU, HR, true, true>), dim3(grid), dim3(block), lds, st, a);
-        else hipLaunchKernelGGL((core_sweep_wave_kernel<ROWS, GA, MU, HR, false, true>), dim3(grid), dim3(block), lds, st, a);
+        if (stash == 1u) hipLaunchKernelGGL((core_sweep_wave_kernel<ROWS, GA, MU, HR, 1u, true>), dim3(grid), dim3(block), lds, st, a);
+        else if (stash == 2u) hipLaunchKernelGGL((core_sweep_wave_kernel<ROWS, GA, MU, HR, 2u, true>), dim3(grid), dim3(block), lds, st, a);
+        else hipLaunchKernelGGL((core_sweep_wave_kernel<ROWS, GA, MU, HR, 0u, true>), dim3(grid), dim3(block), lds, st, a);
     } else {
-        if (stash) hipLaunchKernelGGL((core_sweep_wave_kernel<ROWS, GA, MU, HR, true, false>), dim3(grid), dim3(block), lds, st, a);
-        else hipLaunchKernelGGL((core_sweep_wave_kernel<ROWS, GA, MU, HR, false, false>), dim3(grid), dim3(block), lds, st, a);
+        if (stash == 1u) hipLaunchKernelGGL((core_sweep_wave_kernel<ROWS, GA, MU, HR, 1u, false>), dim3(grid), dim3(block), lds, st, a);
+        else if (stash == 2u) hipLaunchKernelGGL((core_sweep_wave_kernel<ROWS, GA, MU, HR, 2u, false>), dim3(grid), dim3(block), lds, st, a);
+        else hipLaunchKernelGGL((core_sweep_wave_kernel<ROWS, GA, MU, HR, 0u, false>), dim3(grid), dim3(block), lds, st, a);
     }
     HIPCHK(hipGetLastError());
     return PS_OK;
@@ -842,7 +845,7 @@ static int launch_core_sweep_window(ps_population *p, const core_sweep_args &a, 
     const uint32_t segs = (a.N + 1023u) / 1024u;
     // at least one wave per (XCD group, segment); a multiple of the 8 groups
     const uint32_t grid = (std::max(8u * ((segs + 3u) / 4u), (256u - 8u * p->free_cus_per_xcd) * bpc) + 7u) & ~7u;
-    const bool stash = a.plan.bC <= 15u && p->nibble_safe;
+    const uint32_t stash = p->nibble_safe ? (a.plan.bC <= 15u ? 1u : a.plan.bC <= 31u ? 2u : 0u) : 0u;
     // two launches: the segments whose parent window fits the row buffer, then the others (usually none: its waves
     // leave at once); they alternate the counter sets like any two consecutive launches
     // (the counter sets alternate among the launches that use them: a parity of their own)
@@ -858,8 +861,8 @@ static int launch_core_sweep_window(ps_population *p, const core_sweep_args &a, 
         hipLaunchKernelGGL((core_sweep_window_kernel<ROWS, true, HR, ST_, NT_, false>), dim3(grid), dim3(256), lds, st, a0);          \
         hipLaunchKernelGGL((core_sweep_window_kernel<ROWS, true, HR, ST_, NT_, true>), dim3(grid), dim3(256), lds, st, b);            \
     }
-    if (a.nt) { if (stash) PS_WLAUNCH(true, true) else PS_WLAUNCH(false, true) }
-    else { if (stash) PS_WLAUNCH(true, false) else PS_WLAUNCH(false, false) }
+    if (a.nt) { if (stash == 1u) PS_WLAUNCH(1u, true) else if (stash == 2u) PS_WLAUNCH(2u, true) else PS_WLAUNCH(0u, true) }
+    else { if (stash == 1u) PS_WLAUNCH(1u, false) else if (stash == 2u) PS_WLAUNCH(2u, false) else PS_WLAUNCH(0u, false) }
 #undef PS_WLAUNCH
     HIPCHK(hipGetLastError());
     return PS_OK;
@@ -933,7 +936,7 @@ static int launch_core_sweep(ps_population *p, const uint32_t *d_idx, uint32_t g
     a.launch_parity = (uint32_t)(p->sweep_launches++ & 1u);
     a.idxT = p->d_idxT;
     p->last_sweep_form = window ? PS_SWEEP_FORM_WINDOW
-                         : wave ? ((a.plan.has_events && a.plan.bC <= 15u && p->nibble_safe) ? PS_SWEEP_FORM_WAVE_STASH : PS_SWEEP_FORM_WAVE)
+                         : wave ? ((a.plan.has_events && a.plan.bC <= 31u && p->nibble_safe) ? PS_SWEEP_FORM_WAVE_STASH : PS_SWEEP_FORM_WAVE)
                          : inline_form ? PS_SWEEP_FORM_INLINE : PS_SWEEP_FORM_BLOCK;
     if (window) return hr ? launch_core_sweep_window<true>(p, a, st) : launch_core_sweep_window<false>(p, a, st);
 #define PS_DISPATCH(G_, M_, H_)                                              \

@@ -280,7 +280,7 @@ def _shard_counts_sum(pa, kw, gens, P, n_shards, seed=0):
 
 
 def test_config3_full_size_properties(pa):
-    # BASELINE configs[2]: HR_rate = HGT_rate = 0.5 at the full 1.2 M sites (the plain, non-STASH wave sweep: bC = 18;
+    # BASELINE configs[2]: HR_rate = HGT_rate = 0.5 at the full 1.2 M sites (bC = 18: the wave sweep's STASH = 2 build;
     # the binned HGT taking turns with the sweep)
     kw = dict(pop_size=1000, core_size=1200000, pan_genes=6000, core_genes=2000, HR_rate=0.5, HGT_rate=0.5)
     P, gens = 50000, 4
@@ -291,7 +291,7 @@ def test_config3_full_size_properties(pa):
         (cnt,) = sim.core_genome.pairwise_counts(sim.range1, sim.range2)
         runs.append((sim.last_parents(), cnt, sim.pan_genome.gene_frequencies(), sim.pan_genome.read_matrix()))
         if len(runs) == 1:
-            assert sim.core_genome.last_sweep_form() == 1                # PS_SWEEP_FORM_WAVE (plain)
+            assert sim.core_genome.last_sweep_form() == 2                # PS_SWEEP_FORM_WAVE_STASH (here: bit 4 of the byte in the queue entry)
             assert (cnt % 2 == 0).all() and cnt.max() > 0                # alleles stay one-hot
             # HGT never clears a gene (population.rs:632): one more recombination on the same state only adds bits
             before = runs[0][3]

@@ -643,14 +643,15 @@ def test_sweeps_carry_bytes_above_15(pa, orc, N, L, tune):
     pop.close()
 
 
-@pytest.mark.parametrize("total,stash", [(0.0640, True), (0.0650, False), (0.0039, True), (0.1200, False)])
+@pytest.mark.parametrize("total,bC", [(0.0640, 15), (0.0650, 16), (0.0039, 0), (0.1200, 28), (0.1350, 32)])
 @pytest.mark.parametrize("N,rows,ascending", [(1000, 3, False), (1024, 2, False), (777, 4, False), (17, 3, False),
                                               (5000, 3, True), (4097, 3, True)])
-def test_candidate_push_on_both_sides_of_the_stash_limit(pa, orc, N, rows, ascending, total, stash):
-    # The candidate push of the wave / window sweeps has two forms (core_kernels.h): one wave prefix sum + lane-private writes
-    # when every candidate byte is below 16 (bC <= 15: the level-1 nibble rides in the child byte), the ballot loop when
-    # not.  Per-site event rates just below and just above the limit (0.0640 -> bC = 15, 0.0650 -> bC = 16), a very
-    # sparse plan (most lanes without a candidate: empty stretches of the queue) and a dense one, for 2 / 3 / 4 rows per
+def test_candidate_push_on_both_sides_of_the_stash_limit(pa, orc, N, rows, ascending, total, bC):
+    # The candidate push of the wave / window sweeps has three builds (core_kernels.h, STASH): one wave prefix sum + lane-private
+    # writes when every candidate byte is below 16 (bC <= 15: the level-1 nibble rides in the child byte), the same with bit 4
+    # of the byte in the queue entry and two more mask words for 15 < bC <= 31 (cfg3's rates), the ballot loop above that.
+    # Per-site event rates on both sides of both limits (bC = 15 / 16, 28 / 32; the last is a wave sweep only where its queue
+    # admits it, i.e. N = 17), a very sparse plan (most lanes without a candidate) and dense ones, for 2 / 3 / 4 rows per
     # wave trip (two rows share a mask word; the third / fourth row pair takes the second word), ragged last lanes (N = 777,
     # 17, 4097) and both sweeps (ascending parents + N > 1024 = the window sweep).
     LG, L = 1200000, 26
@@ -661,7 +662,7 @@ def test_candidate_push_on_both_sides_of_the_stash_limit(pa, orc, N, rows, ascen
         sample = np.sort(sample)
     lm, lh = (total - 0.002) * LG, 0.002 * LG
     plan = orc.core_plan(lm, lh, LG)
-    assert (plan.bC <= 15) == stash, plan.bC
+    assert plan.bC == bC
     want = orc.next_generation(m0, sample)
     orc.mutate_core(want, 40, 77, 11, plan)
     orc.recombine_core(want, 40, 77, 11, plan)
