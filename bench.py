@@ -75,8 +75,8 @@ def pmc_traffic(kernel, algorithmic_bytes):
     by scripts/collect_pmc.py; FETCH_SIZE doubled per the gfx950 correction of MI355X_MICROARCH.md).  The passes ran on one
     workload per kernel (the file names it); for another workload of the same kernel the measured traffic / algorithmic
     ratio is applied to this workload's algorithmic bytes, and the source string says so.  None if no file is present."""
-    names = {"wave": ("r05_pmc_sweep.json", "r04_pmc_sweep.json", "r03_pmc_sweep.json", "r02_pmc_sweep.json", "r01_pmc_sweep.json"),
-             "window": ("r05_pmc_window_sweep.json", "r04_pmc_window_sweep.json", "r03_pmc_window_sweep.json"),
+    names = {"wave": ("r06_pmc_sweep.json", "r05_pmc_sweep.json", "r04_pmc_sweep.json", "r03_pmc_sweep.json", "r02_pmc_sweep.json", "r01_pmc_sweep.json"),
+             "window": ("r06_pmc_window_sweep.json", "r05_pmc_window_sweep.json", "r04_pmc_window_sweep.json", "r03_pmc_window_sweep.json"),
              "block": ("r02_pmc_block_sweep.json", "r01_pmc_block_sweep.json")}.get(kernel, ())
     try:
         for name in names:
@@ -515,8 +515,7 @@ def measure(ctx, kw, P, steps, warmup, shard_rank, shard_count, seed=0, want_pai
 
 
 SWEEP_FORMS = {
-    1: ("wave", "core_sweep_wave_kernel<gather,mutate,HR> (plain form: level-1 byte extracted at push time)"),
-    2: ("wave", "core_sweep_wave_kernel<gather,mutate,HR> (STASH form)"),
+    1: ("wave", "core_sweep_wave_kernel<gather,mutate,HR> (one wave per site row, 4 rows per trip, out of place)"),
     3: ("window", "core_sweep_window_kernel<gather,mutate,HR> (children in ascending parent order, out of place)"),
     4: ("block", "core_sweep_block_kernel<gather,mutate,HR> (whole rows in workgroup-shared LDS, in place)"),
     5: ("inline", "core_sweep_inline_kernel<gather,mutate,HR> (queue-free form)"),

@@ -169,7 +169,7 @@ int ps_last_pair_form(ps_population *p);
 enum {
     PS_SWEEP_FORM_NONE = 0,
     PS_SWEEP_FORM_WAVE = 1,        /* core_sweep_wave_kernel, one wave per site row (N <= 1024) */
-    PS_SWEEP_FORM_WAVE_STASH = 2,  /* the same with the level-1 nibble carried in the child byte (every candidate byte < 32; bit 4 in the queue entry) */
+    /* 2: a former build of the wave sweep (rounds 3-5); never reported now */
     PS_SWEEP_FORM_WINDOW = 3,      /* core_sweep_window_kernel: N > 1024, children in ascending parent order, out of place */
     PS_SWEEP_FORM_BLOCK = 4,       /* core_sweep_block_kernel: N > 1024, whole rows in workgroup-shared LDS, in place */
     PS_SWEEP_FORM_INLINE = 5       /* core_sweep_inline_kernel: the queue-free form for any rates */
@@ -185,7 +185,7 @@ int ps_write(ps_population *p, const char *outpref);
 int ps_sync(ps_population *p);
 /* Launch tuning / test hooks (no reference counterpart).  Keys: "sweep_blocks_per_cu"
  * (resident 256-thread blocks per CU of the wave-per-row sweep, 1..8), "sweep_rows"
- * (site rows a wave of that sweep takes per iteration, 2..4),
+ * (2..4; accepted and ignored since round 6: a wave of that sweep takes the 4 sites of one level-1 block group per iteration),
  * "force_block_sweep" (0/1: use the block sweep even when a row fits one wavefront),
  * "force_inline_sweep" (0/1: use the queue-free inline block sweep), "pair_mode" (core
  * distances: 0 = choose by cost, 1 = sampled-pair kernel, 2 = all-pairs tiles + lookup, 3 = sampled-pair
@@ -193,8 +193,10 @@ int ps_sync(ps_population *p);
  * sampled form of populations too wide for an LDS tile, 5 = all-pairs xor + popcount tiles even for one-hot matrices,
  * 6 = all pairs on the i8 matrix cores; one-hot matrices go to the matrix cores in modes 0 and 2 (FP4 form) and 6 (i8 form)), "pair_ranges" (site ranges of the tiled
  * sampled-pair kernels, 0 = choose; the 16-bit counter cap still applies),
- * "davg_form" (average_distance: 0 = choose, 1 = LDS-tile popcount kernels, 2 = intersections on the matrix cores -- the default
- * above pop_size 8192 and for row shards), "davg_nb" (matrix-core form: 32-individual fragments per wave, 0 = choose, 1 or 2),
+ * "davg_form" (average_distance: 0 = choose, 1 = LDS-tile popcount kernels, 2 = intersections on the matrix cores in one kernel --
+ * the choice above pop_size 24576 --, 3 = the same in two phases, u16 counts then division + ordered fold -- the choice for row
+ * shards and for 8192 < pop_size <= 24576), "davg_nb" (matrix-core forms: 32-individual fragments per wave, 0 = choose, 1, 2, or --
+ * two-phase form only; the one-kernel form then chooses by itself -- 4),
  * "hgt_mode" (accessory recombination: 0 = choose, 1 = one atomic per event, 2 = two passes: bin
  * by recipient partition, OR in LDS images), "hgt_slices" (binned HGT: event slices, 0 = choose), "hgt_list_in_global" (0/1: donor gene lists in
  * global scratch instead of LDS; "hgt_bin_list_in_global": the same for the bin pass of the binned form),

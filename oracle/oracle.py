@@ -38,7 +38,7 @@ class Derived(C.Structure):
 
 
 class CorePlan(C.Structure):
-    _fields_ = [("T", C.c_uint32 * 7), ("has_events", C.c_uint32), ("bC", C.c_uint32)]
+    _fields_ = [("T", C.c_uint32 * 7), ("has_events", C.c_uint32), ("k", C.c_uint32), ("R", C.c_uint32), ("cshift", C.c_uint32)]
 
 
 _u8p = np.ctypeslib.ndpointer(np.uint8, flags="C_CONTIGUOUS")

@@ -145,7 +145,11 @@ static uint32_t prob_to_u32(double p)
 
 /* Dense form of population.rs:511-540 and :544-751 (core path).
  * Poisson splitting: a cell (individual, site) receives Poisson(lam_mut/L)
- * mutation events and Poisson(lam_hr/L) incoming HR events, independently. */
+ * mutation events and Poisson(lam_hr/L) incoming HR events, independently; the last mutation wins and is uniform over
+ * {2,4,8} (:531), the winning donor is uniform over the others.  Per cell: mutate to 2 / 4 / 8 only with mass a each,
+ * mutate AND receive a donor allele with mass b each, receive a donor allele only with mass c.
+ * Two levels: a 6-bit symbol decides k / 64 of each a outright; what is left of the event mass lives,
+ * scaled by 64 / R, in R residual symbols, inside which a 32-bit word is cut by the cumulative thresholds T. */
 void orc_core_plan_make(double lam_mut, double lam_hr, uint64_t L, orc_core_plan *plan)
 {
     double p = (lam_mut > 0.0) ? -expm1(-lam_mut / (double)L) : 0.0;
@@ -153,23 +157,34 @@ void orc_core_plan_make(double lam_mut, double lam_hr, uint64_t L, orc_core_plan
     double a = p * (1.0 - q) / 3.0;
     double b = p * q / 3.0;
     double c = (1.0 - p) * q;
+    uint32_t k = (uint32_t)floor(a * 64.0);
+    double a_left = a - (double)k / 64.0;
+    double m_res = a_left + a_left + a_left + b + b + b + c;
+    uint32_t R = (uint32_t)ceil(m_res * 64.0);
+    if (3u * k + R > 64u) R = 64u - 3u * k;
+    double scale = R ? 64.0 / (double)R : 0.0;
     double cum[7];
-    cum[0] = a;
-    cum[1] = a + a;
-    cum[2] = a + a + a;
-    cum[3] = cum[2] + b;
-    cum[4] = cum[2] + b + b;
-    cum[5] = cum[2] + b + b + b;
-    cum[6] = cum[5] + c;
+    cum[0] = a_left * scale;
+    cum[1] = (a_left + a_left) * scale;
+    cum[2] = (a_left + a_left + a_left) * scale;
+    cum[3] = (a_left + a_left + a_left + b) * scale;
+    cum[4] = (a_left + a_left + a_left + b + b) * scale;
+    cum[5] = (a_left + a_left + a_left + b + b + b) * scale;
+    cum[6] = m_res * scale;
     uint32_t prev = 0;
-    for (int k = 0; k < 7; k++) {
-        uint32_t t = prob_to_u32(cum[k]);
+    for (int j = 0; j < 7; j++) {
+        uint32_t t = prob_to_u32(cum[j]);
         if (t < prev) t = prev;
-        plan->T[k] = t;
+        plan->T[j] = t;
         prev = t;
     }
-    plan->has_events = plan->T[6] > 0u;
-    plan->bC = plan->has_events ? ((plan->T[6] - 1u) >> 24) : 0u;
+    if (plan->T[6] == 0u) R = 0u;
+    plan->k = k;
+    plan->R = R;
+    plan->has_events = (k > 0u || R > 0u) ? 1u : 0u;
+    uint32_t cs = 0;
+    while (cs < 4u && 3u * k + R > (4u << cs)) cs++;
+    plan->cshift = cs;
 }
 
 /* flip iff the Poisson(lam/n) toggle count of a cell is odd (population.rs:501-508) */
@@ -182,18 +197,48 @@ uint32_t orc_acc_flip_threshold(double lam, uint64_t n_genes_in_comp)
 
 typedef struct { uint8_t mut; uint8_t hr; uint32_t donor; } cell_outcome;
 
+/* The 6-bit symbol of cell (site, ind): bit-sliced over two Philox blocks.
+ *   A = Philox(site / 2, ind / 16, gen, CORE_L1):  word j = plane j (j = 0..3) of the sites 2 (site / 2) + {0, 1}
+ *   B = Philox(site / 4, ind / 16, gen, CORE_L1B): words 0 / 1 = plane 4 of the sites 4 (site / 4) + {0, 1} / {2, 3},
+ *                                                  words 2 / 3 = plane 5 of the same
+ * and inside a plane word the cell is bit (ind % 16) + 16 (site % 2).  Symbol = 4 n + t, bit j of n = plane j, bit 0 / 1
+ * of t = plane 4 / 5. */
+static void core_blocks(uint64_t seed, uint32_t gen, uint32_t site, uint32_t chunk, uint32_t A[4], uint32_t B[4])
+{
+    uint32_t key[2] = { (uint32_t)seed, (uint32_t)(seed >> 32) };
+    uint32_t ca[4] = { site >> 1, chunk, gen, ORC_STREAM_CORE_L1 };
+    uint32_t cb[4] = { site >> 2, chunk, gen, ORC_STREAM_CORE_L1B };
+    orc_philox4x32_10(ca, key, A);
+    orc_philox4x32_10(cb, key, B);
+}
+
+/* (A, B = core_blocks(site, ind / 16): the row loops below compute them once per 16 cells) */
+static uint32_t core_symbol(const uint32_t A[4], const uint32_t B[4], uint32_t site, uint32_t ind)
+{
+    uint32_t pos = (ind & 15u) + 16u * (site & 1u);
+    uint32_t n = ((A[0] >> pos) & 1u) | (((A[1] >> pos) & 1u) << 1) | (((A[2] >> pos) & 1u) << 2) | (((A[3] >> pos) & 1u) << 3);
+    uint32_t p4 = (site & 2u) ? B[1] : B[0], p5 = (site & 2u) ? B[3] : B[2];
+    uint32_t t = ((p4 >> pos) & 1u) | (((p5 >> pos) & 1u) << 1);
+    return 4u * n + t;
+}
+
 static cell_outcome core_cell(uint64_t seed, uint32_t gen, uint32_t site, uint32_t ind, uint64_t N,
-                              const orc_core_plan *plan, const uint32_t l1[4])
+                              const orc_core_plan *plan, const uint32_t A[4], const uint32_t B[4])
 {
     cell_outcome o = { 0, 0, 0 };
-    uint32_t k = ind & 15u;
-    uint32_t b = (l1[k >> 2] >> (8u * (k & 3u))) & 0xFFu;
-    if (!plan->has_events || b > plan->bC) return o;
+    if (!plan->has_events) return o;
+    uint32_t s = core_symbol(A, B, site, ind);
+    if ((s >> 2) >> plan->cshift) return o;          /* (implied by the ranges below: 3k + R <= 4 << cshift) */
+    if (s < plan->k) { o.mut = 2; return o; }
+    if (s < 2u * plan->k) { o.mut = 4; return o; }
+    if (s < 3u * plan->k) { o.mut = 8; return o; }
+    if (s >= 3u * plan->k + plan->R) return o;
+    /* residual symbol: one 32-bit word against the thresholds */
     uint32_t ctr[4] = { site, ind, gen, ORC_STREAM_CORE_L2 };
     uint32_t key[2] = { (uint32_t)seed, (uint32_t)(seed >> 32) };
     uint32_t w[4];
     orc_philox4x32_10(ctr, key, w);
-    uint32_t u = (b << 24) | (w[0] >> 8);
+    uint32_t u = w[0];
     const uint32_t *T = plan->T;
     if (u >= T[6]) return o;
     if (u < T[0]) o.mut = 2;
@@ -212,13 +257,6 @@ static cell_outcome core_cell(uint64_t seed, uint32_t gen, uint32_t site, uint32
     return o;
 }
 
-static void core_l1(uint64_t seed, uint32_t gen, uint32_t site, uint32_t chunk, uint32_t out[4])
-{
-    uint32_t ctr[4] = { site, chunk, gen, ORC_STREAM_CORE_L1 };
-    uint32_t key[2] = { (uint32_t)seed, (uint32_t)(seed >> 32) };
-    orc_philox4x32_10(ctr, key, out);
-}
-
 /* population.rs:511-540: the allele written is uniform over core_vec[1 >> value],
  * and `1 >> value` is 0 for every value >= 1, i.e. always {2,4,8}. */
 void orc_mutate_core(uint8_t *pop, uint64_t N, uint64_t L, uint64_t site_offset, uint64_t seed,
@@ -228,10 +266,10 @@ void orc_mutate_core(uint8_t *pop, uint64_t N, uint64_t L, uint64_t site_offset,
     for (uint64_t s = 0; s < L; s++) {
         uint32_t site = (uint32_t)(site_offset + s);
         for (uint64_t c = 0; c * 16 < N; c++) {
-            uint32_t l1[4];
-            core_l1(seed, gen, site, (uint32_t)c, l1);
+            uint32_t A[4], B[4];
+            core_blocks(seed, gen, site, (uint32_t)c, A, B);
             for (uint64_t i = c * 16; i < N && i < c * 16 + 16; i++) {
-                cell_outcome o = core_cell(seed, gen, site, (uint32_t)i, N, plan, l1);
+                cell_outcome o = core_cell(seed, gen, site, (uint32_t)i, N, plan, A, B);
                 if (o.mut) pop[i * L + s] = o.mut;
             }
         }
@@ -250,10 +288,10 @@ void orc_recombine_core(uint8_t *pop, uint64_t N, uint64_t L, uint64_t site_offs
         uint32_t site = (uint32_t)(site_offset + s);
         for (uint64_t i = 0; i < N; i++) col[i] = pop[i * L + s];
         for (uint64_t c = 0; c * 16 < N; c++) {
-            uint32_t l1[4];
-            core_l1(seed, gen, site, (uint32_t)c, l1);
+            uint32_t A[4], B[4];
+            core_blocks(seed, gen, site, (uint32_t)c, A, B);
             for (uint64_t i = c * 16; i < N && i < c * 16 + 16; i++) {
-                cell_outcome o = core_cell(seed, gen, site, (uint32_t)i, N, plan, l1);
+                cell_outcome o = core_cell(seed, gen, site, (uint32_t)i, N, plan, A, B);
                 if (o.hr) pop[i * L + s] = col[o.donor];
             }
         }

@@ -48,6 +48,7 @@ enum {
     ORC_STREAM_CORE_L2 = 2,
     ORC_STREAM_ACC_MUT = 3,
     ORC_STREAM_HGT = 4,
+    ORC_STREAM_CORE_L1B = 5,
     ORC_STREAM_INIT_CORE = 16,
     ORC_STREAM_INIT_ACC = 17,
     ORC_STREAM_SELECTION = 18,
@@ -91,9 +92,11 @@ void orc_derive(const orc_params *p, orc_derived *d);
 
 /* ---- keyed dense plans --------------------------------------------------- */
 typedef struct {
-    uint32_t T[7];      /* cumulative 32-bit thresholds, DESIGN.md section 3.2 */
+    uint32_t T[7];      /* cumulative 32-bit thresholds of a RESIDUAL cell's level-2 word, DESIGN.md section 3.2 */
     uint32_t has_events;
-    uint32_t bC;        /* last level-1 byte value that can hold an event */
+    uint32_t k;         /* 6-bit symbols s < k, < 2k, < 3k mutate to 2, 4, 8 */
+    uint32_t R;         /* symbols 3k <= s < 3k + R are residual */
+    uint32_t cshift;    /* a cell whose symbol's high part n = s / 4 has a bit at or above cshift holds no event */
 } orc_core_plan;
 void orc_core_plan_make(double lam_mut, double lam_hr, uint64_t L, orc_core_plan *plan);
 /* flip threshold for one accessory compartment, DESIGN.md section 3.3 */

@@ -29,10 +29,9 @@ struct core_sweep_args {
     uint32_t *work_ctr;        // wave sweep: 2 x 8 chunk counters, 128 bytes apart
     uint32_t launch_parity;    // which counter set this launch uses
     uint32_t nt;               // out-of-place form: nontemporal row loads / stores (every byte is touched once per launch)
+    uint32_t qcap;             // wave / window sweeps: entries of a wave's candidate queue (sized by the host for the plan)
     uint32_t qcap_limit;       // tests: pretend the candidate queues / HR lists hold only this many entries (0 = their real size)
     uint32_t *wide_flags;      // window sweep: [(generation & 1) * 32] != 0 iff the first launch met a segment for the second one
-    uint32_t gate_chunks;      // window sweep, experiment (PANSIM_WINDOW_GATE): a wave waits while its chunk is more than this many
-                               // chunks ahead of the slowest segment of its XCD group (0 = no gate)
 };
 
 typedef uint32_t ps_u32x4 __attribute__((ext_vector_type(4)));
@@ -75,30 +74,36 @@ __device__ __forceinline__ void ps_dma16(const uint8_t *gsrc, uint8_t *lds_base,
                                           (__attribute__((address_space(3))) void *)lds_base, 16, 0, 0);
 }
 
-// 16-bit mask of the level-1 bytes that may hold an event (byte <= bC)
-__device__ __forceinline__ uint32_t ps_candidate_mask(const ps_u4 &l1, uint32_t bC)
+// words of a block A whose set bits rule a cell out as a candidate: planes at or above cshift (ps_common.h)
+__device__ __forceinline__ uint32_t ps_noncand_word(const ps_u4 &A, uint32_t cshift)
 {
-    const uint32_t w[4] = { l1.x, l1.y, l1.z, l1.w };
-    uint32_t cm = 0;
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-#pragma unroll
-        for (int b = 0; b < 4; b++) {
-            const uint32_t byte = (w[j] >> (8 * b)) & 0xFFu;
-            cm |= (byte <= bC ? 1u : 0u) << (4 * j + b);
-        }
-    }
-    return cm;
+    return (cshift <= 0u ? A.x : 0u) | (cshift <= 1u ? A.y : 0u) | (cshift <= 2u ? A.z : 0u) | (cshift <= 3u ? A.w : 0u);
 }
 
-__device__ __forceinline__ uint32_t ps_l1_byte(const ps_u4 &l1, uint32_t k)
+// 16-bit mask (bit k = cell 16 * chunk + k) of the cells of one site that may hold an event
+__device__ __forceinline__ uint32_t ps_cand16(const ps_u4 &A, uint32_t site, uint32_t cshift)
 {
-    // branch-free: the word pair by bit 3 of k, then one v_perm_b32 over its eight bytes (the ternary chain compiles to three
-    // levels of exec-mask branches).  By value: selecting between members of the referenced struct sends it to scratch.
-    const uint32_t x = l1.x, y = l1.y, z = l1.z, w = l1.w;
-    const bool hi = (k & 8u) != 0u;
-    const uint32_t lo_w = hi ? z : x, hi_w = hi ? w : y;
-    return __builtin_amdgcn_perm(hi_w, lo_w, (k & 7u) | 0x0c0c0c00u);
+    return (~ps_noncand_word(A, cshift) >> (16u * (site & 1u))) & 0xFFFFu;
+}
+
+// Queue-free evaluation of one candidate cell from its two blocks: the allele it mutates to (0 = none) and whether it
+// receives a donor allele (then l2y is the word the donor is drawn from).  A pure function of (seed, generation, site,
+// individual): the redo paths, the inline sweep and the window sweep's donor recomputation all go through it.
+__device__ __forceinline__ ps_cell ps_cell_events(const ps_u4 &A, const ps_u4 &B, uint32_t site, uint32_t ind, uint32_t gen,
+                                                  uint32_t k0, uint32_t k1, const ps_core_plan &pl, uint32_t &l2y)
+{
+    ps_cell o = { 0u, 0u };
+    const uint32_t n = ps_cell_nibble(A, site, ind);
+    if (n >> pl.cshift) return o;
+    const uint32_t code = ps_sym_code(4u * n + ps_cell_pair(B, site, ind), pl);
+    if (code > 1u) {
+        o.mut = code;
+    } else if (code == 1u) {
+        const ps_u4 l2 = ps_philox(site, ind, gen, PS_STREAM_CORE_L2, k0, k1);
+        o = ps_classify(l2.x, pl);
+        l2y = l2.y;
+    }
+    return o;
 }
 
 // Inline block sweep: the queue-free fallback of the block sweep below.  One 1024-thread
@@ -144,16 +149,15 @@ __global__ void __launch_bounds__(1024) core_sweep_inline_kernel(core_sweep_args
             }
             uint32_t hm = 0;
             if (events) {
-                const ps_u4 l1 = ps_philox_l1(site, c, a.gen, a.k0, a.k1);
-                uint32_t cm = ps_candidate_mask(l1, pl.bC);
+                const ps_u4 A = ps_philox_l1a(site >> 1, c, a.gen, a.k0, a.k1), B = ps_philox_l1b(site >> 2, c, a.gen, a.k0, a.k1);
+                uint32_t cm = ps_cand16(A, site, pl.cshift);
                 while (cm) {
                     const uint32_t k = __builtin_ctz(cm);
                     cm &= cm - 1u;
                     const uint32_t i = c * 16u + k;
                     if (i >= a.N) continue;
-                    const ps_u4 l2 = ps_philox(site, i, a.gen, PS_STREAM_CORE_L2, a.k0, a.k1);
-                    const uint32_t u = (ps_l1_byte(l1, k) << 24) | (l2.x >> 8);
-                    const ps_cell cell = ps_classify(u, pl);
+                    uint32_t l2y;
+                    const ps_cell cell = ps_cell_events(A, B, site, i, a.gen, a.k0, a.k1, pl, l2y);
                     if (DO_MUT && cell.mut) ps_set_byte(d, k, cell.mut);
                     if (DO_HR && cell.hr) hm |= 1u << k;
                 }
@@ -192,26 +196,21 @@ __global__ void __launch_bounds__(1024) core_sweep_inline_kernel(core_sweep_args
 // per lane).  No workgroup barriers: the four waves of a block work on their own
 // rows and synchronise only through the in-order LDS queue of their own wave.
 //
-// A wave takes PS_ROWS consecutive site rows per iteration (their loads are in
-// flight together and the 16 parent indices of a lane are shared by all rows).
-// Events are sparse (about 5 % of the cells at the default rates), so
-//   1. per row, one Philox call per lane gives the 16 level-1 bytes and a SWAR compare
-//      finds the candidate bytes (<= bC); the gathered child bytes go back to the LDS
-//      row (STASH form: with the low nibble of the level-1 byte in bits 4-7);
-//   2. ONE ballot/mbcnt loop per iteration pushes EVERY candidate cell of the PS_ROWS
-//      rows into a wave-private LDS queue (nothing is decided at push time);
-//   3. a dense pass, 64 entries at a time with every lane busy, decides the candidates
-//      whose byte lies strictly inside one "mutate only" interval of the plan from the
-//      byte alone (the 24 refinement bits cannot change the outcome), writes their
-//      alleles into the LDS rows and compacts the undecided ones in place;
-//   4. an exact pass over the undecided cells: level-2 Philox, 32-bit thresholds,
-//      mutation bytes into the LDS rows; HR donors are read from the post-mutation rows
-//      and written back after all reads.
-// The host only selects this kernel when the queue cannot overflow in practice
-// (mean + 10 sigma of the entry count fits); an overflow raises a sticky error flag.
+// A wave takes the 4 site rows of one GLOBAL site group (sites 4g .. 4g + 3: the unit the level-1 blocks are keyed by,
+// ps_common.h) per iteration; their loads are in flight together and the 16 parent indices of a lane are shared by all
+// rows.  Events are sparse (about 5 % of the cells at the default rates), so
+//   1. per batch, THREE Philox calls per lane give the six symbol planes of its 4 x 16 cells; the cells whose symbol can
+//      hold an event are three boolean operations on the plane words of a row pair (no per-cell arithmetic at all);
+//   2. one prefix sum over the wave pushes EVERY such cell of the 4 rows into a wave-private LDS queue, each entry with
+//      the low three bits of its symbol (ps_push_scan: nothing is decided at push time);
+//   3. a dense pass, 64 entries at a time with every lane busy, writes the alleles the symbols decide into the LDS rows
+//      and compacts the residual cells in place;
+//   4. an exact pass over the residual cells: level-2 Philox, 32-bit thresholds, mutation bytes into the LDS rows; HR
+//      donors are read from the post-mutation rows and written back after all reads.
+// The host only selects this kernel when the queue cannot overflow in practice (mean + 10 sigma of the entry count
+// fits); a full queue sends the batch to the queue-free method, nothing is dropped.
 // ---------------------------------------------------------------------------
-// rows per wave iteration (template parameter ROWS) and queue capacity per wave
-__host__ __device__ constexpr uint32_t ps_qcap(uint32_t rows) { return rows >= 4 ? 640u : rows == 3 ? 512u : 384u; }
+#define PS_BATCH_ROWS 4u     // site rows per wave iteration = sites per level-1 block group
 
 __device__ __forceinline__ void ps_wave_sync()
 {
@@ -227,28 +226,6 @@ __device__ __forceinline__ uint32_t ps_lane_prefix(uint64_t bal)
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
 }
 
-// flags (0x80 per byte) of the bytes of w that are < c, for 1 <= c <= 128
-__device__ __forceinline__ uint32_t ps_bytes_lt(uint32_t w, uint32_t c4 /* c * 0x01010101 */)
-{
-    const uint32_t H = 0x80808080u;
-    return ~(((w | H) - c4) | w) & H;
-}
-
-// candidate cells of a lane in "permuted" order: cell k = 4*j + b (dword j, byte b)
-// is bit 8*b + 7 - j
-__device__ __forceinline__ uint32_t ps_candidates_swar(const ps_u4 &l1, uint32_t c4)
-{
-    return ps_bytes_lt(l1.x, c4) | (ps_bytes_lt(l1.y, c4) >> 1) | (ps_bytes_lt(l1.z, c4) >> 2)
-           | (ps_bytes_lt(l1.w, c4) >> 3);
-}
-
-// the same flags in the LOW nibbles (cell 4*j + b is bit 8*b + 3 - j): the candidate masks of two rows then share one word
-__device__ __forceinline__ uint32_t ps_candidates_swar_lo(const ps_u4 &l1, uint32_t c4)
-{
-    return (ps_bytes_lt(l1.x, c4) >> 4) | (ps_bytes_lt(l1.y, c4) >> 5) | (ps_bytes_lt(l1.z, c4) >> 6)
-           | (ps_bytes_lt(l1.w, c4) >> 7);
-}
-
 // wave-wide inclusive prefix sum on the DPP path: four shifts inside the 16-lane rows, then lane 15 of a row into the next
 // row (rows 1 and 3) and lane 31 into rows 2 and 3.  Lanes without a source keep the 0 of `old` (bound_ctrl off).
 __device__ __forceinline__ uint32_t ps_wave_scan_incl(uint32_t x)
@@ -262,75 +239,66 @@ __device__ __forceinline__ uint32_t ps_wave_scan_incl(uint32_t x)
     return x;
 }
 
-// STASH push (phase 2 of the wave and window sweeps).  cm[] are the candidate masks of the batch's rows, even rows in the
-// high nibbles (ps_candidates_swar), odd rows in the low ones (ps_candidates_swar_lo), so that two rows make one word.  A
-// lane counts its candidates, ONE prefix sum over the wave gives every lane its own stretch of the queue, and the lane
-// writes its entries there in a loop of its own: ~6 vector instructions per trip and ~10 trips per batch of three rows,
-// where the ballot / mbcnt loop this replaces (one queue slot per ballot bit; kept for the non-STASH entries, which carry
-// the level-1 byte) spent ~36 per trip on ~5 trips plus three exec-mask branches each.  The order of the queue changes
-// (lane-major), its content does not; nothing is written when the batch does not fit (the caller redoes it queue-free).
-// Entry: bit position p (0-31) | word << 5 | lane << 6; returns the wave-uniform number of candidates of the batch.
-// Candidate bytes of 16-31 (plans with 15 < bC <= 31, `hi` wave-uniform): the stashed nibble is the byte's low one and bit 4 rides in
-// the ENTRY -- such cells come in two more mask words (w0h / w1h) and are pushed behind the others with bit 12 set.
-template <uint32_t PS_ROWS>
-__device__ __forceinline__ uint32_t ps_push_scan(uint32_t w0, uint32_t w1, uint32_t w0h, uint32_t w1h, bool hi, uint32_t *q, uint32_t lane,
-                                                 uint32_t qcap)
+// Event words of a row pair: bit k + 16 * (row & 1) set iff the symbol of the lane's cell k can hold an event, i.e.
+// s < 3k + R =: nE.  For the plans the queued sweeps take (cshift <= 1: nE <= 8) that is n <= 1 and the 3-bit number
+// (plane 0, plane 5, plane 4) below nE -- ONE v_bitop3_b32 whose truth table is the constant (1 << nE) - 1 in the order
+// (P0, P5, P4) = (a, b, c), picked by a wave-uniform switch.
+__device__ __forceinline__ uint32_t ps_event_word(uint32_t p0, uint32_t p1, uint32_t p2, uint32_t p3, uint32_t p4, uint32_t p5,
+                                                 uint32_t nE, uint32_t vm)
 {
-    const uint32_t c0 = (uint32_t)__popc(w0), c1 = PS_ROWS > 2 ? (uint32_t)__popc(w1) : 0u;
-    uint32_t c = c0 + c1, c2 = 0;
-    if (hi) {
-        c2 = (uint32_t)__popc(w0h);
-        c += c2 + (PS_ROWS > 2 ? (uint32_t)__popc(w1h) : 0u);
+    const uint32_t c1 = __builtin_amdgcn_bitop3_b32(p1, p2, p3, 0x01) & vm;       // ~(p1 | p2 | p3): n <= 1
+    // bitop3 truth table: bit (a << 2 | b << 1 | c) of the immediate is the result for inputs (a, b, c); with a = P0,
+    // b = P5, c = P4 that index is the low three bits of the symbol
+    uint32_t lt;
+    switch (nE) {
+    case 1: lt = __builtin_amdgcn_bitop3_b32(p0, p5, p4, 0x01); break;
+    case 2: lt = __builtin_amdgcn_bitop3_b32(p0, p5, p4, 0x03); break;
+    case 3: lt = __builtin_amdgcn_bitop3_b32(p0, p5, p4, 0x07); break;
+    case 4: lt = __builtin_amdgcn_bitop3_b32(p0, p5, p4, 0x0F); break;
+    case 5: lt = __builtin_amdgcn_bitop3_b32(p0, p5, p4, 0x1F); break;
+    case 6: lt = __builtin_amdgcn_bitop3_b32(p0, p5, p4, 0x3F); break;
+    case 7: lt = __builtin_amdgcn_bitop3_b32(p0, p5, p4, 0x7F); break;
+    default: lt = 0xFFFFFFFFu; break;
     }
+    return c1 & lt;
+}
+
+// Candidate push (phase 2 of the wave and window sweeps).  w0 / w1 are the event words of the batch's row pairs (bit
+// k + 16 * (row & 1) = cell k of the lane: the plane layout itself).  A lane counts its events, ONE prefix sum over the
+// wave gives every lane its own stretch of the queue, and the lane writes its entries there in a loop of its own, each
+// with the low three bits of its symbol (planes 4, 5 and 0 at the entry's bit position): nothing else of level 1 is needed
+// later.  Nothing is written when the batch does not fit (the caller redoes it queue-free).
+// Entry (15 bits): bit position p (0-31) | row pair << 5 | lane << 6 | (plane 4, plane 5, plane 0) << 12; returns the
+// wave-uniform number of entries of the batch.
+__device__ __forceinline__ uint32_t ps_push_scan(uint32_t w0, uint32_t w1, const ps_u4 &A0, const ps_u4 &A1, const ps_u4 &B,
+                                                 uint16_t *q, uint32_t lane, uint32_t qcap)
+{
+    const uint32_t c0 = (uint32_t)__popc(w0), c = c0 + (uint32_t)__popc(w1);
     const uint32_t incl = ps_wave_scan_incl(c);
     const uint32_t qn = __builtin_amdgcn_readlane(incl, 63);
     if (qn <= qcap) {
         // (pre-increment and a start of its own per loop: the store takes the new address and no pointer lives across the loops,
         // i.e. no register copy per trip)
-        uint32_t *qp = q + (incl - c) - 1, *qp1 = qp + c0;
+        uint16_t *qp = q + (incl - c) - 1, *qp1 = qp + c0;
         const uint32_t tag = lane << 6;
-        for (uint32_t m = w0; m; m &= m - 1u) *++qp = tag | (uint32_t)__builtin_ctz(m);
-        if (PS_ROWS > 2)
-            for (uint32_t m = w1; m; m &= m - 1u) *++qp1 = tag | 32u | (uint32_t)__builtin_ctz(m);
-        if (hi) {
-            uint32_t *qp2 = q + (incl - c) - 1 + c0 + c1, *qp3 = qp2 + c2;
-            for (uint32_t m = w0h; m; m &= m - 1u) *++qp2 = tag | 4096u | (uint32_t)__builtin_ctz(m);
-            if (PS_ROWS > 2)
-                for (uint32_t m = w1h; m; m &= m - 1u) *++qp3 = tag | (4096u | 32u) | (uint32_t)__builtin_ctz(m);
+        for (uint32_t m = w0; m; m &= m - 1u) {
+            const uint32_t p = (uint32_t)__builtin_ctz(m);
+            const uint32_t sym = ((B.x >> p) & 1u) | (((B.z >> p) & 1u) << 1) | (((A0.x >> p) & 1u) << 2);
+            *++qp = (uint16_t)(tag | p | (sym << 12));
+        }
+        for (uint32_t m = w1; m; m &= m - 1u) {
+            const uint32_t p = (uint32_t)__builtin_ctz(m);
+            const uint32_t sym = ((B.y >> p) & 1u) | (((B.w >> p) & 1u) << 1) | (((A1.x >> p) & 1u) << 2);
+            *++qp1 = (uint16_t)(tag | 32u | p | (sym << 12));
         }
     }
     return qn;
-}
-
-// ... and what the low six bits of such an entry (bit position | word << 5) mean, as a 64-entry table the wave keeps in its
-// LDS (the dense pass, every lane busy, then spends one ds_read_b32 where the bit arithmetic took nine vector instructions):
-// low half = byte offset of the cell in the wave's row buffers less the lane's 16 * lane (row * STRIDE + 4 * j + b), high half
-// = the same cell as the later passes name it (4 * j + b | row << 10).  Bit p = 8 * b + 7 - t, t = j + 4 * (row & 1).
-#define PS_PUSH_TABLE_BYTES 256u
-template <uint32_t STRIDE>
-__device__ __forceinline__ uint32_t ps_push_table_entry(uint32_t idx)
-{
-    const uint32_t p = idx & 31u, t = ~p & 7u, cell = ((t & 3u) << 2) + (p >> 3), row = ((idx >> 5) << 1) | (t >> 2);
-    return (row * STRIDE + cell) | ((cell | (row << 10)) << 16);
 }
 
 // four zero-extended bytes -> one dword (two v_perm + v_or; the compiler's own form masks every byte again)
 __device__ __forceinline__ uint32_t ps_pack4(uint32_t b0, uint32_t b1, uint32_t b2, uint32_t b3)
 {
     return __builtin_amdgcn_perm(b1, b0, 0x0c0c0400u) | __builtin_amdgcn_perm(b3, b2, 0x04000c0cu);
-}
-
-// child bytes (alleles, bits 0-3) with the low nibbles of the level-1 bytes in bits 4-7
-__device__ __forceinline__ uint32_t ps_stash(uint32_t d, uint32_t l1)
-{
-    // ((l1 << 4) & 0xF0F0F0F0) | d as a shift and ONE v_bitop3_b32 ((a & b) | c = table 0xEA)
-    return __builtin_amdgcn_bitop3_b32(l1 << 4, 0xF0F0F0F0u, d, 0xEA);
-}
-
-__device__ __forceinline__ uint4 ps_strip(uint4 v, bool on)
-{
-    const uint32_t m = on ? 0x0F0F0F0Fu : 0xFFFFFFFFu;
-    return make_uint4(v.x & m, v.y & m, v.z & m, v.w & m);
 }
 
 #ifdef PS_STAMP
@@ -340,17 +308,15 @@ __device__ __forceinline__ uint4 ps_strip(uint4 v, bool on)
 #else
 #define PS_T(k) do { } while (0)
 #endif
-// STASH = 1 (host: every candidate byte is below 16, i.e. bC <= 15 -- the default rates): the low nibble of
-// a cell's level-1 byte rides in the high nibble of its child byte in LDS (alleles only use bits 0-3),
-// so a queue entry is just (bit position | word << 5 | lane << 6) -- no v_perm byte extraction per pushed candidate --
-// and the dense pass, with every lane busy, looks the cell up and reads the byte back from the row.  The nibbles
-// are stripped when the row leaves LDS.  STASH = 2 (15 < bC <= 31: cfg3's rates): the same with bit 4 of the byte
-// in the entry (a build of its own: the extra compare and mask words cost the STASH = 1 kernels registers).
 #ifndef PS_WAVE_LB
-#define PS_WAVE_LB 8      // waves per SIMD the wave sweep is built for (8 = 64 VGPRs, 7 = 72, 6 = 84)
+#define PS_WAVE_LB 6      // waves per SIMD the wave sweep is built for (8 = 64 VGPRs, 7 = 72, 6 = 80)
 #endif
-template <uint32_t PS_ROWS, bool DO_GATHER, bool DO_MUT, bool DO_HR, uint32_t STASH, bool NT = false>
-__global__ void __launch_bounds__(256, PS_ROWS >= 4 ? 6 : PS_WAVE_LB) core_sweep_wave_kernel(core_sweep_args a)
+// LDS of one wave: 4 child rows and the queue (a.qcap 16-bit entries)
+__host__ __device__ constexpr uint32_t ps_queue_bytes(uint32_t qcap) { return (qcap * 2u + 15u) & ~15u; }
+__host__ __device__ constexpr uint32_t ps_wave_lds(uint32_t qcap) { return PS_BATCH_ROWS * 1024u + ps_queue_bytes(qcap); }
+
+template <bool DO_GATHER, bool DO_MUT, bool DO_HR, bool NT = false>
+__global__ void __launch_bounds__(256, PS_WAVE_LB) core_sweep_wave_kernel(core_sweep_args a)
 {
 #ifdef PS_STAMP
     unsigned long long st_acc[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
@@ -360,39 +326,24 @@ __global__ void __launch_bounds__(256, PS_ROWS >= 4 ? 6 : PS_WAVE_LB) core_sweep
 #ifdef PS_GROUP_TIMES      // (diagnostic builds: when does each of the 8 row groups start and end?  100 MHz clock; stamps 8.. / 16..)
     const unsigned long long gt_start = __builtin_amdgcn_s_memrealtime();
 #endif
-    constexpr uint32_t PS_QCAP = ps_qcap(PS_ROWS);
+    constexpr uint32_t PS_ROWS = PS_BATCH_ROWS;
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     // LDS rows have a fixed 1024-byte stride, so the low 12 bits of a queue entry
     // (cell | row << 10) are the byte address of the cell inside rowbuf
-    uint8_t *rowbuf = lds + wave * (PS_ROWS * 1024u + PS_QCAP * 4u + PS_PUSH_TABLE_BYTES);
-    uint32_t *q = (uint32_t *)(rowbuf + PS_ROWS * 1024u);
-    uint32_t *ptab = q + PS_QCAP;                      // the wave's copy of the push table (ps_push_table_entry)
-    if (STASH) ptab[lane] = ps_push_table_entry<1024u>(lane);
+    uint8_t *rowbuf = lds + wave * ps_wave_lds(a.qcap);
+    uint16_t *q = (uint16_t *)(rowbuf + PS_ROWS * 1024u);
     const ps_core_plan pl = a.plan;
+    const uint32_t nE = 3u * pl.k + pl.R;             // symbols below nE can hold an event (<= 8 here)
     // (the host launches the mutate / HR variants only for plans that have events: the per-row code below
-    // is straight-line -- no wave-uniform branches around the Philox call, the LDS stores or the tail rows)
+    // is straight-line -- no wave-uniform branches around the Philox calls, the LDS stores or the tail rows)
     constexpr bool events = DO_MUT || DO_HR;
     const bool has_chunk = lane < a.cpr;
     const uint32_t i0 = lane * 16u;
     const uint32_t ld_off = has_chunk ? i0 : 0u;      // lanes past the row load its first bytes; nothing of theirs is stored
     const uint32_t nvalid = (i0 >= a.N) ? 0u : min(16u, a.N - i0);
-    uint32_t vperm = 0;
-#pragma unroll
-    for (uint32_t k = 0; k < 16; k++)
-        if (k < nvalid) vperm |= 1u << (8u * (k & 3u) + 7u - (k >> 2));
-    const uint32_t c4 = (pl.bC + 1u) * 0x01010101u;
-    // byte-level intervals that decide a mutation without refinement
-    const uint32_t t0b = pl.T[0] >> 24, t1b = pl.T[1] >> 24, t2b = pl.T[2] >> 24;
-    // the same intervals as a 2-bit code per byte value (0 undecided, 1/2/3 = allele 2/4/8),
-    // usable when every candidate byte is below 32
-    unsigned long long lut = 0;
-    for (uint32_t bb = 0; bb < 32u; bb++) {
-        const unsigned long long code = (bb < t0b) ? 1ull : (bb > t0b && bb < t1b) ? 2ull : (bb > t1b && bb < t2b) ? 3ull : 0ull;
-        lut |= code << (2u * bb);
-    }
-    const bool use_lut = pl.bC < 32u;
-    constexpr bool hi_class = STASH == 2u;      // candidate bytes reach 16-31: see ps_push_scan
+    const uint32_t vm = ((1u << nvalid) - 1u) * 0x10001u;     // the lane's cells that exist, in both halves of a plane word
+    const uint32_t lut = pl.lut8;
 
     uint32_t pidx[16];
     if (DO_GATHER) {
@@ -401,15 +352,17 @@ __global__ void __launch_bounds__(256, PS_ROWS >= 4 ? 6 : PS_WAVE_LB) core_sweep
         for (uint32_t k = 0; k < 16; k++) pidx[k] = (k < nvalid) ? a.idx[i0 + k] : min(a.N, a.pitch - 1u);
     }
 
-    // Dynamic row assignment.  The rows are split into 8 contiguous ranges, one per group of
+    // Dynamic row assignment.  The batches (global site groups: batch b = sites 4 * (site_offset / 4 + b) .. + 3, of which
+    // the first and the last may lie partly outside this shard) are split into 8 contiguous ranges, one per group of
     // workgroups that share blockIdx.x % 8 (observed to share an XCD: affinity only); inside a
     // range every wave grabs chunks of PS_CHUNK row batches from the range's atomic counter.
     // A workgroup that starts late (another kernel held its CU) simply takes fewer chunks, so
     // the kernel has no static tail.  The next grab is issued before the current chunk is
     // processed; its latency is hidden behind the chunk's work.
-    constexpr uint32_t PS_CHUNK = 4u;
+    constexpr uint32_t PS_CHUNK = 3u;
     const uint32_t grp = blockIdx.x & 7u;
-    const uint32_t batches = (a.rows + PS_ROWS - 1u) / PS_ROWS;
+    const uint32_t off = a.site_offset & 3u, g0 = a.site_offset >> 2;
+    const uint32_t batches = (a.rows + off + PS_ROWS - 1u) / PS_ROWS;
     const uint32_t b_lo = (uint32_t)((uint64_t)batches * grp / 8u), b_hi = (uint32_t)((uint64_t)batches * (grp + 1u) / 8u);
     // two counter sets alternate between launches; this launch zeroes the set of the next one
     // (the previous launch, which used that set, has completed: same stream)
@@ -424,39 +377,34 @@ __global__ void __launch_bounds__(256, PS_ROWS >= 4 ? 6 : PS_WAVE_LB) core_sweep
     for (uint32_t cb = 0; cb < PS_CHUNK; cb++) {
         const uint32_t batch = b_lo + chunk * PS_CHUNK + cb;
         if (batch >= b_hi) break;
-        const uint32_t r0 = batch * PS_ROWS;
-        const uint32_t nr = min(PS_ROWS, a.rows - r0);
-        // rows past the end of the last batch are processed as copies of the last row and never stored
+        // local row of the batch's first site (negative in a shard that starts inside a site group); rows outside the
+        // shard are processed as copies of its first / last row and never stored
+        const int lr0 = (int)(batch * PS_ROWS) - (int)off;
+        const uint32_t sg = g0 + batch;                 // global site group: sites 4 sg .. 4 sg + 3
+        auto lrow = [&](uint32_t rr) -> uint32_t { return (uint32_t)min(max(lr0 + (int)rr, 0), (int)a.rows - 1); };
         uint4 v[PS_ROWS];
-        if (DO_GATHER && PS_WAVE_DMA) {
-            // the parent rows straight into LDS (global_load_lds_dwordx4: no VGPRs, no ds_write; 1 KiB per instruction)
 #pragma unroll
-            for (uint32_t rr = 0; rr < PS_ROWS; rr++) {
-                v[rr] = make_uint4(0, 0, 0, 0);
-                ps_dma16(a.state + (size_t)min(r0 + rr, a.rows - 1u) * a.pitch + ld_off, rowbuf + rr * 1024u, NT);
-            }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // (the compiler does not track LDS-DMA)
+        for (uint32_t rr = 0; rr < PS_ROWS; rr++)
+            v[rr] = ps_load_row16(a.state + (size_t)lrow(rr) * a.pitch + ld_off, NT);
+        if (DO_GATHER) {
+#pragma unroll
+            for (uint32_t rr = 0; rr < PS_ROWS; rr++) *(uint4 *)(rowbuf + rr * 1024u + i0) = v[rr];
             ps_wave_sync();
-        } else {
-#pragma unroll
-            for (uint32_t rr = 0; rr < PS_ROWS; rr++)
-                v[rr] = ps_load_row16(a.state + (size_t)min(r0 + rr, a.rows - 1u) * a.pitch + ld_off, NT);
-            if (DO_GATHER) {
-#pragma unroll
-                for (uint32_t rr = 0; rr < PS_ROWS; rr++) *(uint4 *)(rowbuf + rr * 1024u + i0) = v[rr];
-                ps_wave_sync();
-            }
         }
         PS_T(0);   // global load + LDS stage
 
-        // Phase 1, row by row: child bytes, level-1 words, candidate masks.  (Interleaving the rows -- all
-        // gathers and Philox chains of a batch in one straight-line block -- needs 71 VGPRs: 7 waves per
-        // SIMD instead of 8, and the kernel, which is latency bound, loses more than the overlap gains:
-        // 0.543 against 0.530 ms.)
-        uint32_t qn = 0;        // wave-uniform number of queued candidate cells
-        uint32_t cm[PS_ROWS];
-        uint32_t wl[2] = { 0u, 0u }, wh[2] = { 0u, 0u };      // STASH: the mask words of ps_push_scan (two rows each; bytes < 16 / 16-31)
-        ps_u4 l1[PS_ROWS];      // (only the non-STASH push loop reads it back)
+        // Phase 1: the symbol planes of the batch (three Philox calls per lane for 4 x 16 cells), then, row by row, the child
+        // bytes.  (Interleaving the rows' gathers needs more registers than 8 waves per SIMD leave.)
+        uint32_t wl[2] = { 0u, 0u };      // the event words of ps_push_scan, one per row pair
+        ps_u4 A0 = { 0u, 0u, 0u, 0u }, A1 = A0, B = A0;
+        if (events) {
+            A0 = ps_philox_l1a(2u * sg, lane, a.gen, a.k0, a.k1);
+            A1 = ps_philox_l1a(2u * sg + 1u, lane, a.gen, a.k0, a.k1);
+            B = ps_philox_l1b(sg, lane, a.gen, a.k0, a.k1);
+            wl[0] = ps_event_word(A0.x, A0.y, A0.z, A0.w, B.x, B.z, nE, vm);
+            wl[1] = ps_event_word(A1.x, A1.y, A1.z, A1.w, B.y, B.w, nE, vm);
+        }
+        PS_T(2);   // level-1 Philox + detection
 #pragma unroll
         for (uint32_t rr = 0; rr < PS_ROWS; rr++) {
             uint8_t *row = rowbuf + rr * 1024u;
@@ -467,87 +415,63 @@ __global__ void __launch_bounds__(256, PS_ROWS >= 4 ? 6 : PS_WAVE_LB) core_sweep
                 for (int j = 0; j < 4; j++)
                     w[j] = ps_pack4(row[pidx[4 * j]], row[pidx[4 * j + 1]], row[pidx[4 * j + 2]], row[pidx[4 * j + 3]]);
                 d = make_uint4(w[0], w[1], w[2], w[3]);
+                // the LDS row becomes the child row; every gather read precedes this store
+                ps_wave_sync();
             }
-            PS_T(1);   // gather
-            cm[rr] = 0;
-            l1[rr] = ps_u4{ 0, 0, 0, 0 };
-            if (events) {
-                l1[rr] = ps_philox_l1(a.site_offset + min(r0 + rr, a.rows - 1u), lane, a.gen, a.k0, a.k1);
-                cm[rr] = (STASH && (rr & 1u)) ? (ps_candidates_swar_lo(l1[rr], c4) & (vperm >> 4)) : (ps_candidates_swar(l1[rr], c4) & vperm);
-                if (STASH) {
-                    d.x = ps_stash(d.x, l1[rr].x); d.y = ps_stash(d.y, l1[rr].y);
-                    d.z = ps_stash(d.z, l1[rr].z); d.w = ps_stash(d.w, l1[rr].w);
-                    uint32_t lo = cm[rr];
-                    if (hi_class) {       // candidate bytes 16-31 go to the second pair of mask words
-                        lo &= (rr & 1u) ? ps_candidates_swar_lo(l1[rr], 0x10101010u) : ps_candidates_swar(l1[rr], 0x10101010u);
-                        wh[rr >> 1] |= cm[rr] & ~lo;
-                    }
-                    wl[rr >> 1] |= lo;
-                }
-            }
-            PS_T(2);   // level-1 Philox + detection
-            // the LDS row becomes the child row; every gather read precedes this store
-            if (DO_GATHER) ps_wave_sync();
             if (DO_GATHER || events) *(uint4 *)(row + i0) = d;
             __builtin_amdgcn_sched_barrier(0);      // keep the rows apart (see above)
         }
-        const uint32_t qcap = a.qcap_limit ? min(PS_QCAP, a.qcap_limit) : PS_QCAP;
-        if (events && STASH) {
-            // Phase 2: every candidate cell of the PS_ROWS rows into the wave queue (one prefix sum, then lane-private writes)
-            qn = ps_push_scan<PS_ROWS>(wl[0], wl[1], wh[0], wh[1], hi_class, q, lane, qcap);
-        } else if (events) {
-            // ... entries that carry the level-1 byte: ONE ballot loop for all
-            // rows -- its trip count is the largest number of candidates any lane holds in any single row
-            // (about 4-5), not the sum over the rows, and the rows' ballots inside a trip are independent.
-            for (;;) {
-                uint32_t any = cm[0];
-#pragma unroll
-                for (uint32_t rr = 1; rr < PS_ROWS; rr++) any |= cm[rr];
-                if (__ballot(any != 0u) == 0ull) break;
-#pragma unroll
-                for (uint32_t rr = 0; rr < PS_ROWS; rr++) {
-                    const bool act = cm[rr] != 0u;
-                    const uint64_t bal = __builtin_amdgcn_ballot_w64(act);
-                    if (act) {
-                        const uint32_t p = __builtin_ctz(cm[rr]);
-                        cm[rr] &= cm[rr] - 1u;
-                        const uint32_t pos = qn + ps_lane_prefix(bal);
-                        if (STASH) {
-                            if (pos < PS_QCAP) q[pos] = (lane << 5) | (rr << 11) | p;
-                        } else {
-                            const uint32_t b = p >> 3, j = 7u - (p & 7u);
-                            const uint32_t sel = ((j & 1u) * 4u + b) | 0x0c0c0c00u;
-                            const uint32_t byte = (j & 2u) ? __builtin_amdgcn_perm(l1[rr].w, l1[rr].z, sel)
-                                                           : __builtin_amdgcn_perm(l1[rr].y, l1[rr].x, sel);
-                            if (pos < PS_QCAP) q[pos] = (i0 + 4u * j + b) | (rr << 10) | (byte << 12);
-                        }
-                    }
-                    qn += (uint32_t)__popcll(bal);
-                }
-            }
-        }
+        PS_T(1);   // gather
+        const uint32_t qcap = a.qcap_limit ? min(a.qcap, a.qcap_limit) : a.qcap;
+        uint32_t qn = 0;        // wave-uniform number of queued candidate cells
+        // Phase 2: every event cell of the batch into the wave queue (one prefix sum, then lane-private writes)
+        if (events) qn = ps_push_scan(wl[0], wl[1], A0, A1, B, q, lane, qcap);
         PS_T(3);   // queue push
         ps_wave_sync();
 
-        // Queue overflow (the host sizes the queue for mean + 10 sigma of the candidate count, so this is a
+        bool redo = events && qn > qcap;       // wave-uniform
+        uint32_t n2 = 0;
+        if (events && !redo) {
+            // dense pass: an entry whose symbol decides an allele gets it; the residual cells are compacted in place
+            // to the front of the queue (the write index never passes the read index) as (cell | row << 10), which is
+            // also the cell's byte address in rowbuf
+            for (uint32_t base = 0; base < qn; base += 64u) {
+                const uint32_t e = base + lane;
+                const bool valid = e < qn;
+                const uint32_t ent = valid ? (uint32_t)q[e] : 0u;
+                const uint32_t addr = ((ent & 0x30u) << 6) | ((ent >> 2) & 0x3F0u) | (ent & 15u);
+                const uint32_t code = valid ? (lut >> ((ent >> 10) & 28u)) & 15u : 0u;      // 4 bits per symbol < 8
+                if (DO_MUT && (code & 14u)) rowbuf[addr] = (uint8_t)code;
+                const bool amb = (code & 1u) != 0u;
+                const uint64_t bal = __builtin_amdgcn_ballot_w64(amb);
+                if (amb) q[n2 + ps_lane_prefix(bal)] = (uint16_t)addr;
+                n2 += (uint32_t)__popcll(bal);
+            }
+            ps_wave_sync();
+            // (HR parks a second 16-bit word per residual cell in the queue's upper half, mirrored: entry e at qcap - 1 - e)
+            if (DO_HR && 2u * n2 > qcap) redo = true;
+        }
+        PS_T(4);   // dense symbol classification
+        // Queue overflow (the host sizes the queue for mean + 10 sigma of the entry count, so this is a
         // once-in-the-age-of-the-universe event at the rates it admits -- and every batch under the test hook
         // `sweep_queue_cap`): nothing is dropped; the batch is redone by the queue-free method of
-        // core_sweep_inline_kernel, every candidate handled by its owner lane.
-        if (events && qn > qcap) {
+        // core_sweep_inline_kernel, every candidate handled by its owner lane (cells the dense pass has already
+        // mutated get the same allele again).
+        if (redo) {
 #pragma unroll 1
             for (uint32_t rr = 0; rr < PS_ROWS; rr++) {
                 uint8_t *row = rowbuf + rr * 1024u;
-                const uint32_t site = a.site_offset + min(r0 + rr, a.rows - 1u);
-                const ps_u4 l1r = ps_philox_l1(site, lane, a.gen, a.k0, a.k1);
-                uint32_t cmr = ps_candidates_swar(l1r, c4) & vperm;
+                const uint32_t site = 4u * sg + rr;
+                const ps_u4 Ar = ps_philox_l1a(site >> 1, lane, a.gen, a.k0, a.k1);
+                const ps_u4 Br = ps_philox_l1b(sg, lane, a.gen, a.k0, a.k1);
+                uint32_t cmr = ps_cand16(Ar, site, pl.cshift) & vm;
                 uint32_t hm = 0;
                 while (cmr) {
-                    const uint32_t p = __builtin_ctz(cmr);
+                    const uint32_t k = __builtin_ctz(cmr), cellidx = i0 + k;
                     cmr &= cmr - 1u;
-                    const uint32_t k = 4u * (7u - (p & 7u)) + (p >> 3), cellidx = i0 + k;
-                    const ps_u4 l2 = ps_philox(site, cellidx, a.gen, PS_STREAM_CORE_L2, a.k0, a.k1);
-                    const ps_cell cell = ps_classify((ps_l1_byte(l1r, k) << 24) | (l2.x >> 8), pl);
-                    if (DO_MUT && cell.mut) row[cellidx] = (uint8_t)cell.mut;       // (a STASH nibble goes with the old byte)
+                    uint32_t l2y = 0;
+                    const ps_cell cell = ps_cell_events(Ar, Br, site, cellidx, a.gen, a.k0, a.k1, pl, l2y);
+                    if (DO_MUT && cell.mut) row[cellidx] = (uint8_t)cell.mut;
                     if (DO_HR && cell.hr) hm |= 1u << k;
                 }
                 if (DO_HR) {
@@ -559,7 +483,7 @@ __global__ void __launch_bounds__(256, PS_ROWS >= 4 ? 6 : PS_WAVE_LB) core_sweep
                         const ps_u4 l2 = ps_philox(site, cellidx, a.gen, PS_STREAM_CORE_L2, a.k0, a.k1);
                         uint32_t donor = ps_mulhi(l2.y, a.N - 1u);
                         donor += (donor >= cellidx) ? 1u : 0u;                       // population.rs:618
-                        ps_set_byte(dv, k, (uint32_t)row[donor] & (STASH ? 15u : 255u));
+                        ps_set_byte(dv, k, (uint32_t)row[donor]);
                     }
                     ps_wave_sync();       // all donor reads are done
                     for (uint32_t tmp = hm; tmp;) {
@@ -570,63 +494,25 @@ __global__ void __launch_bounds__(256, PS_ROWS >= 4 ? 6 : PS_WAVE_LB) core_sweep
                 }
             }
             ps_wave_sync();
-        } else
-        if (events) {
-            // dense pass: a candidate whose byte lies strictly inside one "mutate only"
-            // interval is decided by the byte; the others are compacted in place to the
-            // front of the queue (the write index never passes the read index)
-            uint32_t n2 = 0;
-            for (uint32_t base = 0; base < qn; base += 64u) {
-                const uint32_t e = base + lane;
-                const bool valid = e < qn;
-                uint32_t ent = valid ? q[e] : 0u;
-                uint32_t allele = 0;
-                if (STASH) {
-                    // ps_push_scan's entry -> (cell | row << 10 = byte address in rowbuf) | stashed nibble << 12; a stashed
-                    // byte is below 16: the low word of the interval table, and 1 << 0 masked away
-                    const uint32_t t = ptab[ent & 63u], lane16 = (ent >> 2) & 0x3F0u;
-                    uint32_t nib = (uint32_t)rowbuf[(t & 0xFFFFu) + lane16] >> 4;
-                    if (hi_class) {
-                        nib |= (ent >> 8) & 16u;        // bit 4 of the byte rode in the entry
-                        allele = (1u << ((uint32_t)(lut >> (2u * nib)) & 3u)) & 14u;
-                    } else {
-                        allele = (1u << (((uint32_t)lut >> (2u * nib)) & 3u)) & 14u;
-                    }
-                    ent = (t >> 16) | lane16 | (nib << 12);
-                } else if (use_lut) {
-                    const uint32_t code = (uint32_t)(lut >> (2u * ((ent >> 12) & 31u))) & 3u;
-                    allele = code ? (1u << code) : 0u;
-                } else {
-                    const uint32_t byte = (ent >> 12) & 0xFFu;
-                    if (byte < t0b) allele = 2u;
-                    else if (byte > t0b && byte < t1b) allele = 4u;
-                    else if (byte > t1b && byte < t2b) allele = 8u;
-                }
-                const bool amb = valid && allele == 0u;
-                if (DO_MUT && valid && allele) rowbuf[ent & 4095u] = (uint8_t)allele;
-                const uint64_t bal = __builtin_amdgcn_ballot_w64(amb);
-                if (amb) q[n2 + ps_lane_prefix(bal)] = ent;
-                n2 += (uint32_t)__popcll(bal);
-            }
-            ps_wave_sync();
-            PS_T(4);   // dense byte classification
-            // exact pass over the undecided cells: level-2 Philox, 32-bit thresholds
+        } else if (events) {
+            // exact pass over the residual cells: level-2 Philox, 32-bit thresholds
+            uint16_t *qh = q + qcap - 1u;       // HR: donor | 0x8000, later the donor's allele | 0x8000, of entry e at qh[-e]
             for (uint32_t base = 0; base < n2; base += 64u) {
                 const uint32_t e = base + lane;
                 if (e < n2) {
                     const uint32_t ent = q[e];
-                    const uint32_t cellidx = ent & 1023u, rr = (ent >> 10) & 3u, byte = (ent >> 12) & 0xFFu;
-                    const ps_u4 l2 = ps_philox(a.site_offset + r0 + rr, cellidx, a.gen, PS_STREAM_CORE_L2, a.k0, a.k1);
-                    const ps_cell cell = ps_classify((byte << 24) | (l2.x >> 8), pl);
-                    if (DO_MUT && cell.mut) rowbuf[ent & 4095u] = (uint8_t)cell.mut;
+                    const uint32_t cellidx = ent & 1023u, rr = ent >> 10;
+                    const ps_u4 l2 = ps_philox(4u * sg + rr, cellidx, a.gen, PS_STREAM_CORE_L2, a.k0, a.k1);
+                    const ps_cell cell = ps_classify(l2.x, pl);
+                    if (DO_MUT && cell.mut) rowbuf[ent] = (uint8_t)cell.mut;
                     if (DO_HR) {
                         uint32_t out = 0;
                         if (cell.hr) {
                             uint32_t donor = ps_mulhi(l2.y, a.N - 1u);
                             donor += (donor >= cellidx) ? 1u : 0u;       // population.rs:618
-                            out = (ent & 4095u) | (donor << 12) | 0x80000000u;
+                            out = donor | 0x8000u;
                         }
-                        q[e] = out;
+                        *(qh - e) = (uint16_t)out;
                     }
                 }
             }
@@ -635,19 +521,16 @@ __global__ void __launch_bounds__(256, PS_ROWS >= 4 ? 6 : PS_WAVE_LB) core_sweep
                 for (uint32_t base = 0; base < n2; base += 64u) {
                     const uint32_t e = base + lane;
                     if (e < n2) {
-                        const uint32_t ent = q[e];
-                        if (ent >> 31) {
-                            const uint32_t donor = (ent >> 12) & 1023u;
-                            q[e] = (ent & 4095u) | (((uint32_t)rowbuf[(ent & 3072u) | donor] & (STASH ? 15u : 255u)) << 12) | 0x80000000u;
-                        }
+                        const uint32_t h = *(qh - e);
+                        if (h >> 15) *(qh - e) = (uint16_t)((uint32_t)rowbuf[((uint32_t)q[e] & 3072u) | (h & 1023u)] | 0x8000u);
                     }
                 }
                 ps_wave_sync();   // all donor reads are done; now apply the copies
                 for (uint32_t base = 0; base < n2; base += 64u) {
                     const uint32_t e = base + lane;
                     if (e < n2) {
-                        const uint32_t ent = q[e];
-                        if (ent >> 31) rowbuf[ent & 4095u] = (uint8_t)((ent >> 12) & 0xFFu);
+                        const uint32_t h = *(qh - e);
+                        if (h >> 15) rowbuf[q[e]] = (uint8_t)(h & 0xFFu);
                     }
                 }
             }
@@ -658,10 +541,10 @@ __global__ void __launch_bounds__(256, PS_ROWS >= 4 ? 6 : PS_WAVE_LB) core_sweep
         if (has_chunk) {
 #pragma unroll
             for (uint32_t rr = 0; rr < PS_ROWS; rr++) {
-                if (rr < nr) {
-                    uint4 o = (DO_GATHER || events) ? *(const uint4 *)(rowbuf + rr * 1024u + i0) : v[rr];
-                    if (STASH && events) { o.x &= 0x0F0F0F0Fu; o.y &= 0x0F0F0F0Fu; o.z &= 0x0F0F0F0Fu; o.w &= 0x0F0F0F0Fu; }
-                    ps_store_row16(a.out + (size_t)(r0 + rr) * a.pitch + i0, o, NT);
+                const int lr = lr0 + (int)rr;
+                if (lr >= 0 && lr < (int)a.rows) {
+                    const uint4 o = (DO_GATHER || events) ? *(const uint4 *)(rowbuf + rr * 1024u + i0) : v[rr];
+                    ps_store_row16(a.out + (size_t)lr * a.pitch + i0, o, NT);
                 }
             }
         }
@@ -703,23 +586,18 @@ __global__ void __launch_bounds__(256, PS_ROWS >= 4 ? 6 : PS_WAVE_LB) core_sweep
 #ifndef PS_WCAP
 #define PS_WCAP 1216u     // bytes of parent window staged per row (under drift a window spans 1024 + 15 +- 32 parents: 5.5 sigma)
 #endif
-#ifndef PS_WQCAP
-#define PS_WQCAP 384u     // candidate queue entries per wave
-#endif
 #ifndef PS_WBPC
-#define PS_WBPC 7         // workgroups per CU the kernel is launched at (7 x 20.9 KB of LDS);
-                          // measured in the loop at N = 65536 / 8: 6 per CU (1536 / 512) 4.055 ms, 7 (1280 / 448) 3.949, 8 (1152 / 384) = 7
+#define PS_WBPC 6         // workgroups per CU the kernel is launched at (6 x 23.3 KB of LDS at the default rates)
 #endif
 #ifndef PS_WLB
-#define PS_WLB 8          // ... and the waves per SIMD it is BUILT for: 64 VGPRs, so that 7 resident waves leave a SIMD 64 VGPRs and
-                          // a wave slot (and the CU 13 KB of LDS) for the accessory chain of the next generation.  At 72 VGPRs
-                          // nothing else fitted: every chain kernel -- even the runtime's memset -- waited for the sweep to end
-                          // (2.8 ms at N = 65536 / 8), and the whole chain ran exposed behind it
+#define PS_WLB 6          // ... and the waves per SIMD it is BUILT for (80 VGPRs)
 #endif
 #ifndef PS_WINDOW_NT_LOADS
 #define PS_WINDOW_NT_LOADS 0   // window sweep: 1 = the window loads nt as well; 0 = default cache policy (neighbouring windows share lines, HR donors read the rows), stores nt: 4.107 vs 4.142 ms
 #endif
 #define PS_WSTRIDE (PS_WCAP + 16u)   // row buffer stride in LDS: 16 zero bytes behind the window (what cells past N gather)
+// LDS of one wave: 4 row buffers and the queue (a.qcap 16-bit entries)
+__host__ __device__ constexpr uint32_t ps_window_lds(uint32_t qcap) { return PS_BATCH_ROWS * PS_WSTRIDE + ps_queue_bytes(qcap); }
 
 // post-mutation, pre-recombination value of cell (site row, individual donor), from the old generation
 __device__ __forceinline__ uint32_t ps_donor_value(const core_sweep_args &a, const ps_core_plan &pl, const uint8_t *old_row,
@@ -727,12 +605,18 @@ __device__ __forceinline__ uint32_t ps_donor_value(const core_sweep_args &a, con
 {
     uint32_t val = old_row[a.idx[donor]];                       // population.rs:450-465: the donor's gathered byte
     if (do_mut) {
-        const ps_u4 l1 = ps_philox_l1(site, donor >> 4, a.gen, a.k0, a.k1);
-        const uint32_t byte = ps_l1_byte(l1, donor & 15u);
-        if (byte <= pl.bC) {
-            const ps_u4 l2 = ps_philox(site, donor, a.gen, PS_STREAM_CORE_L2, a.k0, a.k1);
-            const ps_cell cell = ps_classify((byte << 24) | (l2.x >> 8), pl);
-            if (cell.mut) val = cell.mut;                        // population.rs:511-540
+        const ps_u4 A = ps_philox_l1a(site >> 1, donor >> 4, a.gen, a.k0, a.k1);
+        const uint32_t n = ps_cell_nibble(A, site, donor);
+        if ((n >> pl.cshift) == 0u) {
+            const ps_u4 B = ps_philox_l1b(site >> 2, donor >> 4, a.gen, a.k0, a.k1);
+            const uint32_t code = ps_sym_code(4u * n + ps_cell_pair(B, site, donor), pl);
+            if (code > 1u) {
+                val = code;                                      // population.rs:511-540
+            } else if (code == 1u) {
+                const ps_u4 l2 = ps_philox(site, donor, a.gen, PS_STREAM_CORE_L2, a.k0, a.k1);
+                const ps_cell cell = ps_classify(l2.x, pl);
+                if (cell.mut) val = cell.mut;
+            }
         }
     }
     return val;
@@ -743,48 +627,46 @@ __device__ __forceinline__ uint32_t ps_donor_value(const core_sweep_args &a, con
 // the others (parents far apart: strong selection against a stretch of the population) -- same code, the bytes gathered
 // straight from the old row in global memory; ascending parents keep every load instruction's 64 addresses in one compact
 // range.  A wave whose segment belongs to the other launch leaves at once.
-template <uint32_t PS_ROWS, bool DO_MUT, bool DO_HR, uint32_t STASH, bool NT, bool WIDE>
+template <bool DO_MUT, bool DO_HR, bool NT, bool WIDE>
 __global__ void __launch_bounds__(256, PS_WLB) core_sweep_window_kernel(core_sweep_args a)
 {
-    constexpr uint32_t PS_QCAP = PS_WQCAP;
+    constexpr uint32_t PS_ROWS = PS_BATCH_ROWS;
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     // per wave: PS_ROWS row buffers of PS_WCAP bytes -- the parents' window arrives there by LDS-DMA, the child row
     // (1024 bytes) overwrites its start once the gather has read it -- and the candidate queue
-    uint8_t *rowbuf = lds + wave * (PS_ROWS * PS_WSTRIDE + PS_QCAP * 4u + PS_PUSH_TABLE_BYTES);
-    uint32_t *q = (uint32_t *)(rowbuf + PS_ROWS * PS_WSTRIDE);
-    uint32_t *ptab = q + PS_QCAP;                      // the wave's copy of the push table (ps_push_table_entry)
-    if (STASH) ptab[lane] = ps_push_table_entry<PS_WSTRIDE>(lane);
+    uint8_t *rowbuf = lds + wave * ps_window_lds(a.qcap);
+    uint16_t *q = (uint16_t *)(rowbuf + PS_ROWS * PS_WSTRIDE);
     if (lane < PS_ROWS) *(uint4 *)(rowbuf + lane * PS_WSTRIDE + PS_WCAP) = make_uint4(0, 0, 0, 0);     // the zero bytes (never rewritten)
     const ps_core_plan pl = a.plan;
     // the wave's segment, fixed for the launch
     const uint32_t segs = (a.N + 1023u) >> 10;
     // Workgroups with equal blockIdx.x % 8 share an XCD (observed; affinity only) and with it an L2: group g takes the
-    // rows [rows g / 8, rows (g + 1) / 8) and ALL segments of them, so that a whole row passes through one L2 at about the
-    // same time -- the donors' bytes of HR (anywhere in the row), the overlap of neighbouring windows and the patched
-    // bytes then hit it.
+    // batches [batches g / 8, batches (g + 1) / 8) and ALL segments of them, so that a whole row passes through one L2 at
+    // about the same time -- the donors' bytes of HR (anywhere in the row), the overlap of neighbouring windows and the
+    // patched bytes then hit it.
     const uint32_t grp = blockIdx.x & 7u;
     const uint32_t wg = __builtin_amdgcn_readfirstlane((blockIdx.x >> 3) * 4u + wave);     // wave index inside its group
-    const uint32_t sg = wg % segs;
+    const uint32_t sgm = wg % segs;
     // this launch zeroes the chunk counters of the next one (two sets alternate by launch parity) ...
     if (wg < segs && lane == 0) a.work_ctr[(((a.launch_parity ^ 1u) * 8u + grp) * segs + wg) * 32u] = 0u;
     // ... and the second launch (WIDE) leaves here unless the first one met a segment for it (one flag per generation
     // parity, cleared a generation ahead): under drift there is none, and 7168 waves each reading their window bounds and 16
-    // parent indices just to find that out cost 31 us between two sweeps
+    // parent indices just to find that out cost 31 us between two sweeps.  (Both launches of a generation go to the SAME
+    // stream, the first before the second, and nothing in between touches slot gen & 1: launch_core_sweep_window.)
     if (WIDE) {
         if (__builtin_amdgcn_readfirstlane(a.wide_flags[(a.gen & 1u) * 32u]) == 0u) return;
     } else if (blockIdx.x == 0 && threadIdx.x == 0) {
         a.wide_flags[((a.gen + 1u) & 1u) * 32u] = 0u;
     }
-    const uint32_t c_first = sg * 1024u, c_last = min(c_first + 1023u, a.N - 1u);
-    const uint32_t chunk = sg * 64u + lane;                 // the lane's 16-cell chunk of the row (Philox counter word)
+    const uint32_t c_first = sgm * 1024u, c_last = min(c_first + 1023u, a.N - 1u);
+    const uint32_t chunk = sgm * 64u + lane;                // the lane's 16-cell chunk of the row (Philox counter word)
     const bool has_chunk = chunk < a.cpr;
     const uint32_t i0 = lane * 16u, c0 = c_first + i0;      // cell offset inside the segment / global index of the first cell
     const uint32_t nvalid = (c0 >= a.N) ? 0u : min(16u, a.N - c0);
-    uint32_t vperm = 0;
-#pragma unroll
-    for (uint32_t k = 0; k < 16; k++)
-        if (k < nvalid) vperm |= 1u << (8u * (k & 3u) + 7u - (k >> 2));
+    const uint32_t vm = ((1u << nvalid) - 1u) * 0x10001u;   // the lane's cells that exist, in both halves of a plane word
+    const uint32_t lut = pl.lut8;
+    const uint32_t nE = 3u * pl.k + pl.R;                   // symbols below nE can hold an event (<= 8 here)
     // the parents' window [w_lo, w_hi] of the parent row, staged from its 16-byte aligned start
     const uint32_t w_lo = __builtin_amdgcn_readfirstlane(a.idx[c_first]) & ~15u;
     const uint32_t w_hi = __builtin_amdgcn_readfirstlane(a.idx[c_last]);
@@ -793,84 +675,59 @@ __global__ void __launch_bounds__(256, PS_WLB) core_sweep_window_kernel(core_swe
     uint32_t pidx[16];      // parents relative to the window start; cells past N gather a zero byte behind the window
 #pragma unroll
     for (uint32_t k = 0; k < 16; k++) pidx[k] = (k < nvalid) ? a.idx[c0 + k] - w_lo : PS_WCAP;
-    const uint32_t c4 = (pl.bC + 1u) * 0x01010101u;
-    const uint32_t t0b = pl.T[0] >> 24, t1b = pl.T[1] >> 24, t2b = pl.T[2] >> 24;
-    unsigned long long lut = 0;     // 2-bit code per byte value < 32 (see the wave sweep)
-    for (uint32_t bb = 0; bb < 32u; bb++) {
-        const unsigned long long code = (bb < t0b) ? 1ull : (bb > t0b && bb < t1b) ? 2ull : (bb > t1b && bb < t2b) ? 3ull : 0ull;
-        lut |= code << (2u * bb);
-    }
-    const bool use_lut = pl.bC < 32u;
-    constexpr bool hi_class = STASH == 2u;      // candidate bytes reach 16-31: see ps_push_scan
     const bool ld0 = !WIDE && i0 < wbytes, ld1 = !WIDE && 1024u + i0 < wbytes;
-    // LDS address of a queue entry's cell: (cell | row << 10) -> row * PS_WCAP + cell
+    // LDS address of a queue entry's cell: (cell | row << 10) -> row * PS_WSTRIDE + cell
     auto cell_addr = [](uint32_t ent) -> uint32_t { return (ent & 1023u) + ((ent >> 10) & 3u) * PS_WSTRIDE; };
 
-    // rows: the waves of a segment share the segment's chunk counter (two counter sets alternate by launch parity; this
-    // launch zeroes the next one's)
-    constexpr uint32_t PS_CHUNK = 4u;
-    const uint32_t batches = (a.rows + PS_ROWS - 1u) / PS_ROWS;
+    // batches = global site groups (see the wave sweep); the waves of a segment share the segment's chunk counter (two
+    // counter sets alternate by launch parity; this launch zeroes the next one's)
+    constexpr uint32_t PS_CHUNK = 3u;
+    const uint32_t off = a.site_offset & 3u, g0 = a.site_offset >> 2;
+    const uint32_t batches = (a.rows + off + PS_ROWS - 1u) / PS_ROWS;
     const uint32_t b_lo = (uint32_t)((uint64_t)batches * grp / 8u), b_hi = (uint32_t)((uint64_t)batches * (grp + 1u) / 8u);
-    uint32_t *ctr = a.work_ctr + ((a.launch_parity * 8u + grp) * segs + sg) * 32u;
+    uint32_t *ctr = a.work_ctr + ((a.launch_parity * 8u + grp) * segs + sgm) * 32u;
     if (wide != WIDE) {                                     // the segment belongs to the other launch (no workgroup barriers here)
         if (!WIDE && lane == 0) a.wide_flags[(a.gen & 1u) * 32u] = 1u;
         return;
     }
     uint32_t next_chunk = 0;
     if (lane == 0) next_chunk = __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#ifdef PS_WINDOW_GATE
-    uint32_t gate_budget = 4096u;      // (bounded: a gate that cannot open -- a segment whose waves are not resident -- is abandoned)
-#endif
     for (;;) {
         const uint32_t chk = __builtin_amdgcn_readfirstlane(next_chunk);
         if (b_lo + chk * PS_CHUNK >= b_hi) break;
         if (lane == 0) next_chunk = __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#ifdef PS_WINDOW_GATE      // (A/B builds only -- make variant NAME=gate VFLAGS=-DPS_WINDOW_GATE=1: the code costs the default kernel 3 spilled registers)
-        if (a.gate_chunks) {
-            // soft progress gate: the chunk counters of the group's segments ARE their frontiers (read past L1, no
-            // atomics): stay within gate_chunks of the slowest, so that the row an HR donor byte is read from is still
-            // in the group's L2
-            const uint32_t *cbase = a.work_ctr + (a.launch_parity * 8u + grp) * segs * 32u;
-            while (gate_budget) {
-                uint32_t c = lane < segs ? __hip_atomic_load(cbase + lane * 32u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0xFFFFFFFFu;
-#pragma unroll
-                for (int off = 32; off >= 1; off >>= 1) c = min(c, (uint32_t)__shfl_xor((int)c, off));
-                if (chk <= c + a.gate_chunks) break;
-                __builtin_amdgcn_s_sleep(64);
-                gate_budget--;
-            }
-        }
-#endif
     for (uint32_t cb = 0; cb < PS_CHUNK; cb++) {
         const uint32_t batch = b_lo + chk * PS_CHUNK + cb;
         if (batch >= b_hi) break;
-        const uint32_t r0 = batch * PS_ROWS;
-        const uint32_t nr = min(PS_ROWS, a.rows - r0);
+        const int lr0 = (int)(batch * PS_ROWS) - (int)off;  // local row of the batch's first site (see the wave sweep)
+        const uint32_t sg = g0 + batch;                     // global site group
+        auto lrow = [&](uint32_t rr) -> uint32_t { return (uint32_t)min(max(lr0 + (int)rr, 0), (int)a.rows - 1); };
         // the first window piece of every row of the batch by LDS-DMA: two 16-byte pieces per lane, the second only where
-        // the window is longer than 1 KiB (rows past the end of the last batch are processed as copies, never stored)
+        // the window is longer than 1 KiB (rows outside the shard are processed as copies, never stored)
 #pragma unroll
         for (uint32_t rr = 0; rr < PS_ROWS; rr++) {
-            const uint8_t *src = a.state + (size_t)min(r0 + rr, a.rows - 1u) * a.pitch + w_lo;
+            const uint8_t *src = a.state + (size_t)lrow(rr) * a.pitch + w_lo;
             if (ld0) ps_dma16(src + i0, rowbuf + rr * PS_WSTRIDE, NT && PS_WINDOW_NT_LOADS);
             if (ld1) ps_dma16(src + 1024u + i0, rowbuf + rr * PS_WSTRIDE + 1024u, NT && PS_WINDOW_NT_LOADS);
         }
+        // the symbol planes of the batch while the windows are in flight (see the wave sweep)
+        const ps_u4 A0 = ps_philox_l1a(2u * sg, chunk, a.gen, a.k0, a.k1);
+        const ps_u4 A1 = ps_philox_l1a(2u * sg + 1u, chunk, a.gen, a.k0, a.k1);
+        const ps_u4 B = ps_philox_l1b(sg, chunk, a.gen, a.k0, a.k1);
+        const uint32_t wl0 = ps_event_word(A0.x, A0.y, A0.z, A0.w, B.x, B.z, nE, vm);
+        const uint32_t wl1 = ps_event_word(A1.x, A1.y, A1.z, A1.w, B.y, B.w, nE, vm);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // (the compiler does not track LDS-DMA)
         ps_wave_sync();
-        uint32_t qn = 0;
-        uint32_t cm[PS_ROWS];
-        uint32_t wl[2] = { 0u, 0u }, wh[2] = { 0u, 0u };      // STASH: the mask words of ps_push_scan (two rows each; bytes < 16 / 16-31)
-        ps_u4 l1[PS_ROWS];      // (only the non-STASH push loop reads it back)
 #pragma unroll
         for (uint32_t rr = 0; rr < PS_ROWS; rr++) {
             uint8_t *win = rowbuf + rr * PS_WSTRIDE;
-            const uint32_t site = a.site_offset + min(r0 + rr, a.rows - 1u);
             uint32_t w[4] = { 0u, 0u, 0u, 0u };
             if (!WIDE) {
 #pragma unroll
                 for (int j = 0; j < 4; j++)
                     w[j] = ps_pack4(win[pidx[4 * j]], win[pidx[4 * j + 1]], win[pidx[4 * j + 2]], win[pidx[4 * j + 3]]);
             } else {
-                const uint8_t *src = a.state + (size_t)min(r0 + rr, a.rows - 1u) * a.pitch + w_lo;
+                const uint8_t *src = a.state + (size_t)lrow(rr) * a.pitch + w_lo;
 #pragma unroll
                 for (int j = 0; j < 4; j++) {
                     uint32_t bsel[4];
@@ -879,53 +736,13 @@ __global__ void __launch_bounds__(256, PS_WLB) core_sweep_window_kernel(core_swe
                     w[j] = ps_pack4(bsel[0], bsel[1], bsel[2], bsel[3]);
                 }
             }
-            uint4 d = make_uint4(w[0], w[1], w[2], w[3]);
-            l1[rr] = ps_philox_l1(site, chunk, a.gen, a.k0, a.k1);
-            cm[rr] = (STASH && (rr & 1u)) ? (ps_candidates_swar_lo(l1[rr], c4) & (vperm >> 4)) : (ps_candidates_swar(l1[rr], c4) & vperm);
-            if (STASH) {
-                d.x = ps_stash(d.x, l1[rr].x); d.y = ps_stash(d.y, l1[rr].y);
-                d.z = ps_stash(d.z, l1[rr].z); d.w = ps_stash(d.w, l1[rr].w);
-                uint32_t lo = cm[rr];
-                if (hi_class) {       // candidate bytes 16-31 go to the second pair of mask words
-                    lo &= (rr & 1u) ? ps_candidates_swar_lo(l1[rr], 0x10101010u) : ps_candidates_swar(l1[rr], 0x10101010u);
-                    wh[rr >> 1] |= cm[rr] & ~lo;
-                }
-                wl[rr >> 1] |= lo;
-            }
             ps_wave_sync();                                     // the row buffer becomes the child row: every gather read precedes
-            *(uint4 *)(win + i0) = d;
+            *(uint4 *)(win + i0) = make_uint4(w[0], w[1], w[2], w[3]);
             __builtin_amdgcn_sched_barrier(0);      // keep the rows apart (see the wave sweep)
         }
-        // the push of the wave sweep: one prefix sum and lane-private writes (STASH), or ONE ballot loop for all rows
-        const uint32_t qcap = a.qcap_limit ? min(PS_QCAP, a.qcap_limit) : PS_QCAP;
-        if (STASH) qn = ps_push_scan<PS_ROWS>(wl[0], wl[1], wh[0], wh[1], hi_class, q, lane, qcap);
-        else
-        for (;;) {
-            uint32_t any = cm[0];
-#pragma unroll
-            for (uint32_t rr = 1; rr < PS_ROWS; rr++) any |= cm[rr];
-            if (__ballot(any != 0u) == 0ull) break;
-#pragma unroll
-            for (uint32_t rr = 0; rr < PS_ROWS; rr++) {
-                const bool act = cm[rr] != 0u;
-                const uint64_t bal = __builtin_amdgcn_ballot_w64(act);
-                if (act) {
-                    const uint32_t p = __builtin_ctz(cm[rr]);
-                    cm[rr] &= cm[rr] - 1u;
-                    const uint32_t pos = qn + ps_lane_prefix(bal);
-                    if (STASH) {
-                        if (pos < PS_QCAP) q[pos] = (lane << 5) | (rr << 11) | p;
-                    } else {
-                        const uint32_t b = p >> 3, j = 7u - (p & 7u);
-                        const uint32_t sel = ((j & 1u) * 4u + b) | 0x0c0c0c00u;
-                        const uint32_t byte = (j & 2u) ? __builtin_amdgcn_perm(l1[rr].w, l1[rr].z, sel)
-                                                       : __builtin_amdgcn_perm(l1[rr].y, l1[rr].x, sel);
-                        if (pos < PS_QCAP) q[pos] = (i0 + 4u * j + b) | (rr << 10) | (byte << 12);
-                    }
-                }
-                qn += (uint32_t)__popcll(bal);
-            }
-        }
+        // the push of the wave sweep: one prefix sum and lane-private writes
+        const uint32_t qcap = a.qcap_limit ? min(a.qcap, a.qcap_limit) : a.qcap;
+        const uint32_t qn = ps_push_scan(wl0, wl1, A0, A1, B, q, lane, qcap);
         ps_wave_sync();
 
         if (qn > qcap) {
@@ -933,19 +750,19 @@ __global__ void __launch_bounds__(256, PS_WLB) core_sweep_window_kernel(core_swe
 #pragma unroll 1
             for (uint32_t rr = 0; rr < PS_ROWS; rr++) {
                 uint8_t *row = rowbuf + rr * PS_WSTRIDE;
-                const uint32_t rg = min(r0 + rr, a.rows - 1u), site = a.site_offset + rg;
-                const uint8_t *old_row = a.state + (size_t)rg * a.pitch;
-                const ps_u4 l1r = ps_philox_l1(site, chunk, a.gen, a.k0, a.k1);
-                uint32_t cmr = ps_candidates_swar(l1r, c4) & vperm;
+                const uint32_t site = 4u * sg + rr;
+                const uint8_t *old_row = a.state + (size_t)lrow(rr) * a.pitch;
+                const ps_u4 Ar = ps_philox_l1a(site >> 1, chunk, a.gen, a.k0, a.k1);
+                const ps_u4 Br = ps_philox_l1b(sg, chunk, a.gen, a.k0, a.k1);
+                uint32_t cmr = ps_cand16(Ar, site, pl.cshift) & vm;
                 while (cmr) {
-                    const uint32_t p = __builtin_ctz(cmr);
+                    const uint32_t k = __builtin_ctz(cmr), cell = c0 + k;
                     cmr &= cmr - 1u;
-                    const uint32_t k = 4u * (7u - (p & 7u)) + (p >> 3), cell = c0 + k;
-                    const ps_u4 l2 = ps_philox(site, cell, a.gen, PS_STREAM_CORE_L2, a.k0, a.k1);
-                    const ps_cell cl = ps_classify((ps_l1_byte(l1r, k) << 24) | (l2.x >> 8), pl);
+                    uint32_t l2y = 0;
+                    const ps_cell cl = ps_cell_events(Ar, Br, site, cell, a.gen, a.k0, a.k1, pl, l2y);
                     if (DO_MUT && cl.mut) row[i0 + k] = (uint8_t)cl.mut;
                     if (DO_HR && cl.hr) {
-                        uint32_t donor = ps_mulhi(l2.y, a.N - 1u);
+                        uint32_t donor = ps_mulhi(l2y, a.N - 1u);
                         donor += (donor >= cell) ? 1u : 0u;                      // population.rs:618
                         row[i0 + k] = (uint8_t)ps_donor_value(a, pl, old_row, site, donor, DO_MUT);
                     }
@@ -953,41 +770,18 @@ __global__ void __launch_bounds__(256, PS_WLB) core_sweep_window_kernel(core_swe
             }
             ps_wave_sync();
         } else {
-            // dense pass (the wave sweep's): byte-decided mutations; the others compacted in place
+            // dense pass (the wave sweep's): symbol-decided mutations; the residual cells compacted in place
             uint32_t n2 = 0;
             for (uint32_t base = 0; base < qn; base += 64u) {
                 const uint32_t e = base + lane;
                 const bool valid = e < qn;
-                uint32_t ent = valid ? q[e] : 0u;
-                uint32_t allele = 0, addr = 0;
-                if (STASH) {
-                    // ps_push_scan's entry -> cell | row << 10 | nibble << 12 (see the wave sweep), and the cell's place in LDS
-                    const uint32_t t = ptab[ent & 63u], lane16 = (ent >> 2) & 0x3F0u;
-                    addr = (t & 0xFFFFu) + lane16;
-                    uint32_t nib = (uint32_t)rowbuf[addr] >> 4;
-                    if (hi_class) {
-                        nib |= (ent >> 8) & 16u;        // bit 4 of the byte rode in the entry
-                        allele = (1u << ((uint32_t)(lut >> (2u * nib)) & 3u)) & 14u;
-                    } else {
-                        allele = (1u << (((uint32_t)lut >> (2u * nib)) & 3u)) & 14u;
-                    }
-                    ent = (t >> 16) | lane16 | (nib << 12);
-                } else {
-                    const uint32_t byte = (ent >> 12) & 0xFFu;
-                    addr = cell_addr(ent);
-                    if (use_lut) {
-                        const uint32_t code = (uint32_t)(lut >> (2u * (byte & 31u))) & 3u;
-                        allele = code ? (1u << code) : 0u;
-                    } else {
-                        if (byte < t0b) allele = 2u;
-                        else if (byte > t0b && byte < t1b) allele = 4u;
-                        else if (byte > t1b && byte < t2b) allele = 8u;
-                    }
-                }
-                const bool amb = valid && allele == 0u;
-                if (DO_MUT && valid && allele) rowbuf[addr] = (uint8_t)allele;
+                const uint32_t ent = valid ? (uint32_t)q[e] : 0u;
+                const uint32_t e2 = ((ent & 0x30u) << 6) | ((ent >> 2) & 0x3F0u) | (ent & 15u);      // cell | row << 10
+                const uint32_t code = valid ? (lut >> ((ent >> 10) & 28u)) & 15u : 0u;      // 4 bits per symbol < 8
+                if (DO_MUT && (code & 14u)) rowbuf[cell_addr(e2)] = (uint8_t)code;
+                const bool amb = (code & 1u) != 0u;
                 const uint64_t bal = __builtin_amdgcn_ballot_w64(amb);
-                if (amb) q[n2 + ps_lane_prefix(bal)] = ent;
+                if (amb) q[n2 + ps_lane_prefix(bal)] = (uint16_t)e2;
                 n2 += (uint32_t)__popcll(bal);
             }
             ps_wave_sync();
@@ -1000,15 +794,16 @@ __global__ void __launch_bounds__(256, PS_WLB) core_sweep_window_kernel(core_swe
                 const uint32_t e = base + lane;
                 if (e < n2) {
                     const uint32_t ent = q[e];
-                    const uint32_t rr = (ent >> 10) & 3u, byte = (ent >> 12) & 0xFFu;
+                    const uint32_t rr = (ent >> 10) & 3u;
                     const uint32_t cell = c_first + (ent & 1023u);
-                    const uint32_t rg = min(r0 + rr, a.rows - 1u), site = a.site_offset + rg;
+                    const uint32_t site = 4u * sg + rr;
                     const ps_u4 l2 = ps_philox(site, cell, a.gen, PS_STREAM_CORE_L2, a.k0, a.k1);
-                    const ps_cell cl = ps_classify((byte << 24) | (l2.x >> 8), pl);
+                    const ps_cell cl = ps_classify(l2.x, pl);
                     if (DO_MUT && cl.mut) rowbuf[cell_addr(ent)] = (uint8_t)cl.mut;
                     if (DO_HR && cl.hr) {
                         uint32_t donor = ps_mulhi(l2.y, a.N - 1u);
                         donor += (donor >= cell) ? 1u : 0u;                      // population.rs:618
+                        const uint32_t rg = (uint32_t)min(max(lr0 + (int)rr, 0), (int)a.rows - 1);
                         rowbuf[cell_addr(ent)] = (uint8_t)ps_donor_value(a, pl, a.state + (size_t)rg * a.pitch, site, donor, DO_MUT);
                     }
                 }
@@ -1019,10 +814,10 @@ __global__ void __launch_bounds__(256, PS_WLB) core_sweep_window_kernel(core_swe
         if (has_chunk) {
 #pragma unroll
             for (uint32_t rr = 0; rr < PS_ROWS; rr++) {
-                if (rr < nr) {
-                    uint4 o = *(const uint4 *)(rowbuf + rr * PS_WSTRIDE + i0);
-                    if (STASH) { o.x &= 0x0F0F0F0Fu; o.y &= 0x0F0F0F0Fu; o.z &= 0x0F0F0F0Fu; o.w &= 0x0F0F0F0Fu; }
-                    ps_store_row16(a.out + (size_t)(r0 + rr) * a.pitch + c0, o, NT);
+                const int lr = lr0 + (int)rr;
+                if (lr >= 0 && lr < (int)a.rows) {
+                    const uint4 o = *(const uint4 *)(rowbuf + rr * PS_WSTRIDE + i0);
+                    ps_store_row16(a.out + (size_t)lr * a.pitch + c0, o, NT);
                 }
             }
         }
@@ -1035,15 +830,15 @@ __global__ void __launch_bounds__(256, PS_WLB) core_sweep_window_kernel(core_swe
 // Block sweep for rows wider than one wavefront (pitch > 1024: cfg4/cfg5 populations).
 // A workgroup of nw waves stages R whole site rows in LDS (parent rows and child rows) and
 // splits them into 1024-cell segments.  A wave takes PS_SB consecutive segments per
-// iteration and treats them exactly like the wave-per-row sweep treats its PS_ROWS rows:
-// level-1 Philox, SWAR detection, ONE wave-private candidate queue for the whole batch,
-// dense byte classification, one exact level-2 pass with (nearly) every lane busy.
+// iteration and treats them like the wave-per-row sweep treats its rows: the symbol planes of
+// the slot (two Philox blocks per segment here: a slot is ONE site of a block pair's two / four),
+// ONE wave-private candidate queue for the whole batch, dense symbol classification, one exact
+// level-2 pass with (nearly) every lane busy.
 // A mutation only touches cells of the wave's own segments, so it needs no block barrier;
 // cells that receive a donor allele are collected in a per-wave HR list, and the donor
 // reads / writes happen between block barriers once every segment of the row group has
 // been mutated (the donor may sit in any segment).
-// Queue entry: LDS byte offset of the cell in rowS (20 bits) | level-1 byte << 20 | slot << 28; in the STASH form
-// the push loop writes (bit position | lane << 5 | slot << 11) and the dense pass expands it to that format.
+// Queue entry: LDS byte offset of the cell in rowS (20 bits) | low three bits of the symbol << 20 | slot << 28.
 // ---------------------------------------------------------------------------
 #define PS_PF 4u   // prefetch registers (uint4) per thread: pf0..pf3 in the kernel
 // Workgroup barrier that orders LDS traffic only: outstanding global loads (the prefetch of the
@@ -1062,17 +857,13 @@ struct core_block_geom {
     uint32_t ovf_off;  // LDS byte offset of the workgroup's "a queue or an HR list was full" word (the last 4 bytes)
 };
 
-// mask (in the permuted bit order of ps_candidates_swar) of the cells i0 .. i0+15 that exist (< N)
+// 16-bit mask of the cells i0 .. i0+15 that exist (< N)
 __device__ __forceinline__ uint32_t ps_valid_cells(uint32_t i0, uint32_t N)
 {
-    if (i0 + 16u <= N) return 0xF0F0F0F0u;
-    uint32_t m = 0;
-    for (uint32_t k = 0; k < 16u; k++)
-        if (i0 + k < N) m |= 1u << (8u * (k & 3u) + 7u - (k >> 2));
-    return m;
+    return i0 + 16u <= N ? 0xFFFFu : i0 >= N ? 0u : (1u << (N - i0)) - 1u;
 }
 
-template <uint32_t PS_SB, bool PRE, bool DO_GATHER, bool DO_MUT, bool DO_HR, bool STASH>
+template <uint32_t PS_SB, bool PRE, bool DO_GATHER, bool DO_MUT, bool DO_HR>
 __global__ void __launch_bounds__(1024) core_sweep_block_kernel(core_sweep_args a, core_block_geom g)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
@@ -1094,14 +885,7 @@ __global__ void __launch_bounds__(1024) core_sweep_block_kernel(core_sweep_args 
     // (the last entry of an HR list is never used: the last wave's holds the overflow word, see block_sweep_geometry)
     const uint32_t qcap = a.qcap_limit ? min(g.QW, a.qcap_limit) : g.QW, hcap = a.qcap_limit ? min(g.HW - 1u, a.qcap_limit) : g.HW - 1u;
     if (tid == 0) *ovf = 0u;        // (ordered before any use by the barrier that follows the first staging)
-    const uint32_t c4 = (pl.bC + 1u) * 0x01010101u;
-    const uint32_t t0b = pl.T[0] >> 24, t1b = pl.T[1] >> 24, t2b = pl.T[2] >> 24;
-    unsigned long long lut = 0;     // 2-bit code per byte value < 32 (see the wave sweep)
-    for (uint32_t bb = 0; bb < 32u; bb++) {
-        const unsigned long long code = (bb < t0b) ? 1ull : (bb > t0b && bb < t1b) ? 2ull : (bb > t1b && bb < t2b) ? 3ull : 0ull;
-        lut |= code << (2u * bb);
-    }
-    const bool use_lut = pl.bC < 32u;
+    const uint32_t lut = pl.lut8;       // (the host launches this kernel for plans with cshift <= 1: symbols below 8)
     // (row, segment) of the first item of this wave's first batch, and the batch-to-batch stride
     const uint32_t first_rr = (wave * PS_SB) / g.segs, first_sg = (wave * PS_SB) % g.segs;
     const uint32_t step_rr = (nw * PS_SB) / g.segs, step_sg = (nw * PS_SB) % g.segs;
@@ -1162,8 +946,9 @@ __global__ void __launch_bounds__(1024) core_sweep_block_kernel(core_sweep_args 
         uint32_t rr0 = first_rr, sg0 = first_sg;
         for (uint32_t item0 = wave * PS_SB; item0 < items; item0 += nw * PS_SB) {
             uint32_t s_base[PS_SB], s_site[PS_SB];   // wave-uniform per slot: LDS offset of the row, site
-            uint32_t s_seg[PS_SB];                   // STASH: LDS offset of the slot's segment
-            uint32_t cmv[PS_SB];                     // STASH: candidate masks of the batch (one push loop for all slots)
+            uint32_t s_seg[PS_SB];                   // LDS offset of the slot's segment
+            uint32_t cmv[PS_SB];                     // candidate masks of the batch (one push loop for all slots)
+            uint32_t tv[PS_SB], nv[PS_SB];           // planes 4 | 5 << 16 and plane 0 of the slot's 16 cells
             uint32_t qn = 0;
             uint32_t rr = rr0, sg = sg0;
             // FULL (wave-uniform): every slot of the batch exists and every lane of every segment holds a chunk
@@ -1176,6 +961,7 @@ __global__ void __launch_bounds__(1024) core_sweep_block_kernel(core_sweep_args 
                 s_seg[s] = rr * a.pitch + sg * 1024u;
                 s_site[s] = a.site_offset + r0 + rr;
                 cmv[s] = 0u;
+                tv[s] = nv[s] = 0u;
                 if (FULL || item0 + s < items) {
                     // lanes past the row (chunk >= cpr) compute on the row's last chunk and only their LDS store is
                     // masked; their candidate mask is empty (no valid cells)
@@ -1203,40 +989,16 @@ __global__ void __launch_bounds__(1024) core_sweep_block_kernel(core_sweep_args 
                                 ip += 4u * a.cpr;
                             }
                         }
-                        if (!(STASH && events) && has_chunk) *(uint4 *)(row + i0) = make_uint4(w[0], w[1], w[2], w[3]);
-                    } else if (STASH && events) {
-                        const uint4 cur = *(const uint4 *)(row + chunkc * 16u);
-                        w[0] = cur.x; w[1] = cur.y; w[2] = cur.z; w[3] = cur.w;
+                        if (has_chunk) *(uint4 *)(row + i0) = make_uint4(w[0], w[1], w[2], w[3]);
                     }
                     if (events) {
-                        const uint32_t vperm = FULL ? 0xF0F0F0F0u : PRE ? vperm_pre[s] : ps_valid_cells(i0, a.N);
-                        const ps_u4 l1 = ps_philox_l1(s_site[s], chunk, a.gen, a.k0, a.k1);
-                        uint32_t cm = ps_candidates_swar(l1, c4) & vperm;
-                        if (STASH) {
-                            // child bytes with the level-1 nibbles (see the wave sweep); the push happens below
-                            if (has_chunk)
-                                *(uint4 *)(row + i0) = make_uint4(ps_stash(w[0], l1.x), ps_stash(w[1], l1.y),
-                                                                  ps_stash(w[2], l1.z), ps_stash(w[3], l1.w));
-                            cmv[s] = cm;
-                        } else {
-                            const uint32_t off0 = s_base[s] + i0;
-                            for (;;) {
-                                const bool act = cm != 0u;
-                                const uint64_t bal = __builtin_amdgcn_ballot_w64(act);
-                                if (bal == 0ull) break;
-                                if (act) {
-                                    const uint32_t p = __builtin_ctz(cm);
-                                    cm &= cm - 1u;
-                                    const uint32_t pos = qn + ps_lane_prefix(bal);
-                                    const uint32_t b = p >> 3, j = 7u - (p & 7u);
-                                    const uint32_t sel = ((j & 1u) * 4u + b) | 0x0c0c0c00u;
-                                    const uint32_t byte = (j & 2u) ? __builtin_amdgcn_perm(l1.w, l1.z, sel)
-                                                                   : __builtin_amdgcn_perm(l1.y, l1.x, sel);
-                                    if (pos < g.QW) q[pos] = (off0 + 4u * j + b) | (byte << 20) | (s << 28);
-                                }
-                                qn += (uint32_t)__popcll(bal);
-                            }
-                        }
+                        const uint32_t vcell = FULL ? 0xFFFFu : PRE ? vperm_pre[s] : ps_valid_cells(i0, a.N);
+                        const uint32_t site = s_site[s], sh = 16u * (site & 1u);
+                        const ps_u4 A = ps_philox_l1a(site >> 1, chunk, a.gen, a.k0, a.k1);
+                        const ps_u4 B = ps_philox_l1b(site >> 2, chunk, a.gen, a.k0, a.k1);
+                        cmv[s] = ps_cand16(A, site, pl.cshift) & vcell;
+                        nv[s] = (A.x >> sh) & 0xFFFFu;
+                        tv[s] = ((((site & 2u) ? B.y : B.x) >> sh) & 0xFFFFu) | ((((site & 2u) ? B.w : B.z) >> sh) << 16);
                     }
                 }
                 if (++sg == g.segs) { sg = 0; rr++; }
@@ -1249,9 +1011,9 @@ __global__ void __launch_bounds__(1024) core_sweep_block_kernel(core_sweep_args 
                 for (uint32_t s = 0; s < PS_SB; s++) slot(std::false_type{}, s);
             }
             PS_T(1);   // gather + level-1 Philox + child store (all slots)
-            if (STASH && events) {
+            if (events) {
                 // ONE push loop for the batch: its trip count is the largest number of candidates any lane holds in
-                // one segment, not the sum over the segments
+                // one segment, not the sum over the segments.  The entry carries the low three bits of the symbol.
                 for (;;) {
                     uint32_t any = cmv[0];
 #pragma unroll
@@ -1265,7 +1027,8 @@ __global__ void __launch_bounds__(1024) core_sweep_block_kernel(core_sweep_args 
                             const uint32_t p = __builtin_ctz(cmv[s]);
                             cmv[s] &= cmv[s] - 1u;
                             const uint32_t pos = qn + ps_lane_prefix(bal);
-                            if (pos < g.QW) q[pos] = (lane << 5) | (s << 11) | p;
+                            const uint32_t sym = ((tv[s] >> p) & 1u) | (((tv[s] >> (16u + p)) & 1u) << 1) | (((nv[s] >> p) & 1u) << 2);
+                            if (pos < g.QW) q[pos] = (s_seg[s] + lane * 16u + p) | (sym << 20) | (s << 28);
                         }
                         qn += (uint32_t)__popcll(bal);
                     }
@@ -1282,33 +1045,15 @@ __global__ void __launch_bounds__(1024) core_sweep_block_kernel(core_sweep_args 
                 if (lane == 0) *ovf = 1u;
                 continue;
             }
-            // dense pass: byte-decided mutations; the others compacted in place
+            // dense pass: symbol-decided mutations; the residual cells compacted in place
             uint32_t n2 = 0;
             for (uint32_t base = 0; base < qn; base += 64u) {
                 const uint32_t e = base + lane;
                 const bool valid = e < qn;
-                uint32_t ent = valid ? q[e] : 0u;
-                if (STASH) {
-                    // (bit position p = 8b + 7 - j of cell 4j + b | lane << 5 | slot << 11) -> LDS offset in rowS
-                    const uint32_t p = ent & 31u, sl = ent >> 11;
-                    uint32_t seg = s_seg[0];
-#pragma unroll
-                    for (uint32_t k = 1; k < PS_SB; k++) seg = (sl == k) ? s_seg[k] : seg;
-                    const uint32_t off = seg + (((ent >> 5) & 63u) << 4) + 4u * (7u - (p & 7u)) + (p >> 3);
-                    ent = off | ((uint32_t)(rowS[off] >> 4) << 20) | (sl << 28);
-                }
-                const uint32_t byte = (ent >> 20) & 0xFFu;
-                uint32_t allele = 0;
-                if (use_lut) {
-                    const uint32_t code = (uint32_t)(lut >> (2u * (byte & 31u))) & 3u;
-                    allele = code ? (1u << code) : 0u;
-                } else {
-                    if (byte < t0b) allele = 2u;
-                    else if (byte > t0b && byte < t1b) allele = 4u;
-                    else if (byte > t1b && byte < t2b) allele = 8u;
-                }
-                const bool amb = valid && allele == 0u;
-                if (DO_MUT && valid && allele) rowS[ent & 0xFFFFFu] = (uint8_t)allele;
+                const uint32_t ent = valid ? q[e] : 0u;
+                const uint32_t code = valid ? (lut >> (4u * ((ent >> 20) & 7u))) & 15u : 0u;
+                const bool amb = (code & 1u) != 0u;
+                if (DO_MUT && (code & 14u)) rowS[ent & 0xFFFFFu] = (uint8_t)code;
                 const uint64_t bal = __builtin_amdgcn_ballot_w64(amb);
                 if (amb) q[n2 + ps_lane_prefix(bal)] = ent;
                 n2 += (uint32_t)__popcll(bal);
@@ -1323,7 +1068,7 @@ __global__ void __launch_bounds__(1024) core_sweep_block_kernel(core_sweep_args 
                 if (e < n2) {
                     const uint32_t ent = q[e];
                     off = ent & 0xFFFFFu;
-                    const uint32_t byte = (ent >> 20) & 0xFFu, s = ent >> 28;
+                    const uint32_t s = ent >> 28;
                     rbase = s_base[0];
                     uint32_t site = s_site[0];
 #pragma unroll
@@ -1333,7 +1078,7 @@ __global__ void __launch_bounds__(1024) core_sweep_block_kernel(core_sweep_args 
                     }
                     const uint32_t cellidx = off - rbase;
                     const ps_u4 l2 = ps_philox(site, cellidx, a.gen, PS_STREAM_CORE_L2, a.k0, a.k1);
-                    const ps_cell cell = ps_classify((byte << 24) | (l2.x >> 8), pl);
+                    const ps_cell cell = ps_classify(l2.x, pl);
                     if (DO_MUT && cell.mut) rowS[off] = (uint8_t)cell.mut;
                     if (DO_HR && cell.hr) {
                         hr = true;
@@ -1392,19 +1137,19 @@ __global__ void __launch_bounds__(1024) core_sweep_block_kernel(core_sweep_args 
                         d[j] = w;
                     }
                 } else {
-                    // the row itself: cells already mutated keep their (identical) value; STASH nibbles are dropped
-                    const uint4 cur = ps_strip(*(const uint4 *)(row + i0), STASH);
+                    // the row itself: cells already mutated keep their (identical) value
+                    const uint4 cur = *(const uint4 *)(row + i0);
                     d[0] = cur.x; d[1] = cur.y; d[2] = cur.z; d[3] = cur.w;
                 }
-                const ps_u4 l1 = ps_philox_l1(site, chunk, a.gen, a.k0, a.k1);
-                uint32_t cm = ps_candidate_mask(l1, pl.bC), hm = 0;
+                const ps_u4 A = ps_philox_l1a(site >> 1, chunk, a.gen, a.k0, a.k1), B = ps_philox_l1b(site >> 2, chunk, a.gen, a.k0, a.k1);
+                uint32_t cm = ps_cand16(A, site, pl.cshift), hm = 0;
                 while (cm) {
                     const uint32_t k = __builtin_ctz(cm);
                     cm &= cm - 1u;
                     const uint32_t i = i0 + k;
                     if (i >= a.N) continue;
-                    const ps_u4 l2 = ps_philox(site, i, a.gen, PS_STREAM_CORE_L2, a.k0, a.k1);
-                    const ps_cell cell = ps_classify((ps_l1_byte(l1, k) << 24) | (l2.x >> 8), pl);
+                    uint32_t l2y = 0;
+                    const ps_cell cell = ps_cell_events(A, B, site, i, a.gen, a.k0, a.k1, pl, l2y);
                     if (DO_MUT && cell.mut) ps_set_byte(d, k, cell.mut);
                     if (DO_HR && cell.hr) hm |= 1u << k;
                 }
@@ -1429,7 +1174,7 @@ __global__ void __launch_bounds__(1024) core_sweep_block_kernel(core_sweep_args 
             });
             if (tid == 0) *ovf = 0u;
         } else if (DO_HR && events) {
-            for (uint32_t e = lane; e < nhr; e += 64u) hr_b[e] = (uint32_t)rowS[hr_b[e]] & (STASH ? 15u : 255u);
+            for (uint32_t e = lane; e < nhr; e += 64u) hr_b[e] = (uint32_t)rowS[hr_b[e]];
             ps_block_sync_lds();    // all donor reads done
             for (uint32_t e = lane; e < nhr; e += 64u) rowS[hr_a[e]] = (uint8_t)hr_b[e];
         }
@@ -1459,17 +1204,17 @@ __global__ void __launch_bounds__(1024) core_sweep_block_kernel(core_sweep_args 
             } else if (pipelined) {
                 // at most PS_PF pieces per thread: the LDS reads together, then the stores
                 uint4 o0 = make_uint4(0, 0, 0, 0), o1 = o0, o2 = o0, o3 = o0;
-                if (po0 < nbytes) o0 = ps_strip(*(const uint4 *)(rowS + po0), STASH && events);
-                if (po1 < nbytes) o1 = ps_strip(*(const uint4 *)(rowS + po1), STASH && events);
-                if (po2 < nbytes) o2 = ps_strip(*(const uint4 *)(rowS + po2), STASH && events);
-                if (po3 < nbytes) o3 = ps_strip(*(const uint4 *)(rowS + po3), STASH && events);
+                if (po0 < nbytes) o0 = *(const uint4 *)(rowS + po0);
+                if (po1 < nbytes) o1 = *(const uint4 *)(rowS + po1);
+                if (po2 < nbytes) o2 = *(const uint4 *)(rowS + po2);
+                if (po3 < nbytes) o3 = *(const uint4 *)(rowS + po3);
                 if (po0 < nbytes) *(uint4 *)(dstg + po0) = o0;
                 if (po1 < nbytes) *(uint4 *)(dstg + po1) = o1;
                 if (po2 < nbytes) *(uint4 *)(dstg + po2) = o2;
                 if (po3 < nbytes) *(uint4 *)(dstg + po3) = o3;
             } else {
                 for (uint32_t o = tid * 16u; o < nbytes; o += blockDim.x * 16u)
-                    *(uint4 *)(dstg + o) = ps_strip(*(const uint4 *)(rowS + o), STASH && events);
+                    *(uint4 *)(dstg + o) = *(const uint4 *)(rowS + o);
             }
         }
         // stage the next row group; a thread overwrites only LDS bytes it has just read itself

@@ -135,6 +135,7 @@ static uint32_t prob_to_u32(double p)
     return (uint32_t)x;
 }
 
+// (the tests' CPU restatement evaluates the same expressions in the same order: the plans agree bit for bit)
 static void make_core_plan(double lam_mut, double lam_hr, uint64_t L, ps_core_plan *plan)
 {
     const double p = (lam_mut > 0.0) ? -std::expm1(-lam_mut / (double)L) : 0.0;
@@ -142,23 +143,38 @@ static void make_core_plan(double lam_mut, double lam_hr, uint64_t L, ps_core_pl
     const double a = p * (1.0 - q) / 3.0;
     const double b = p * q / 3.0;
     const double c = (1.0 - p) * q;
+    // k symbols of mass 1/64 per allele are decided by the symbol alone ...
+    const uint32_t k = (uint32_t)std::floor(a * 64.0);
+    const double a_left = a - (double)k / 64.0;
+    // ... and the rest of the event mass goes to R residual symbols, inside which it is scaled by 64 / R
+    const double m_res = a_left + a_left + a_left + b + b + b + c;
+    uint32_t R = (uint32_t)std::ceil(m_res * 64.0);
+    if (3u * k + R > 64u) R = 64u - 3u * k;
+    const double scale = R ? 64.0 / (double)R : 0.0;
     double cum[7];
-    cum[0] = a;
-    cum[1] = a + a;
-    cum[2] = a + a + a;
-    cum[3] = cum[2] + b;
-    cum[4] = cum[2] + b + b;
-    cum[5] = cum[2] + b + b + b;
-    cum[6] = cum[5] + c;
+    cum[0] = a_left * scale;
+    cum[1] = (a_left + a_left) * scale;
+    cum[2] = (a_left + a_left + a_left) * scale;
+    cum[3] = (a_left + a_left + a_left + b) * scale;
+    cum[4] = (a_left + a_left + a_left + b + b) * scale;
+    cum[5] = (a_left + a_left + a_left + b + b + b) * scale;
+    cum[6] = m_res * scale;
     uint32_t prev = 0;
-    for (int k = 0; k < 7; k++) {
-        uint32_t t = prob_to_u32(cum[k]);
+    for (int j = 0; j < 7; j++) {
+        uint32_t t = prob_to_u32(cum[j]);
         if (t < prev) t = prev;
-        plan->T[k] = t;
+        plan->T[j] = t;
         prev = t;
     }
-    plan->has_events = plan->T[6] > 0u;
-    plan->bC = plan->has_events ? ((plan->T[6] - 1u) >> 24) : 0u;
+    if (plan->T[6] == 0u) R = 0u;       // nothing left for the residual symbols to decide
+    plan->k = k;
+    plan->R = R;
+    plan->has_events = (k > 0u || R > 0u) ? 1u : 0u;
+    uint32_t cs = 0;
+    while (cs < 4u && 3u * k + R > (4u << cs)) cs++;
+    plan->cshift = cs;
+    plan->lut8 = 0u;
+    for (uint32_t sy = 0; sy < 8u; sy++) plan->lut8 |= ps_sym_code(sy, *plan) << (4u * sy);
 }
 
 static uint32_t acc_flip_threshold(double lam, uint64_t n_genes)
@@ -184,7 +200,7 @@ struct ps_population {
                                      // memory; measured -2 % at cfg2, -9 % at cfg3), 0 for the block sweep (no gain at N = 65536)
     uint32_t pitch = 0, cpr = 0;
     ps_core_plan cplan{};
-    bool nibble_safe = true;
+    bool nibble_safe = true;         // every byte is below 16 (the nibble-packed distance kernels; checked on load)
     bool onehot_safe = true;         // every byte is 1, 2, 4 or 8 (true for simulated states; checked on load)
     uint32_t *d_pack2 = nullptr;     // 2-bit packed copy of the matrix for the sampled-pair distances
     uint32_t *d_pair_part = nullptr; // partial pair counts per site range (tiled distance kernels)
@@ -240,10 +256,10 @@ struct ps_population {
     double *d_Dt = nullptr;          // all-pairs Jaccard distances (D-avg), N x N
     void *d_davg = nullptr;          // matrix-core D-avg: the padded bit rows + row counts
     uint64_t davg_cap = 0;
-    int davg_form = 0;               // 0 = choose, 1 = LDS-tile popcount kernels, 2 = matrix cores (one kernel), 3 = matrix cores, two phases
+    int davg_form = 0;               // 0 = choose, 1 = LDS-tile popcount kernels, 2 = matrix cores (one kernel), 3 = matrix cores, two phases (the choice for row shards and N <= 24576)
     void *d_davg_in = nullptr;       // two-phase D-avg: u16 intersection counts of one band of rows
     uint64_t davg_in_cap = 0;
-    uint32_t davg_nb = 0;            // matrix-core D-avg: B fragments per wave (0 = choose, 1 or 2)
+    uint32_t davg_nb = 0;            // matrix-core D-avg: B fragments per wave (0 = choose, 1 or 2; 4 in the two-phase form only)
     bool davg_plain_division = false; // matrix-core D-avg: the compiler's f64 division in the epilogue ("davg_plain_division": A/B, tests)
     uint64_t H_cap = 0;
     int pair_mode = 0;               // 0 auto, 1 sampled kernel, 2 all-pairs kernel (tuning/tests)
@@ -258,7 +274,7 @@ struct ps_population {
     std::vector<uint32_t> h_r1, h_r2; // the caller's list the device copy was built from
     uint32_t lds_limit = 160 * 1024;
     uint32_t sweep_blocks_per_cu = 8;   // wave-per-row sweep: resident 256-thread blocks per CU (capped by LDS)
-    uint32_t sweep_rows = 3;            // wave-per-row sweep: site rows per wave iteration (2..4)
+    uint32_t sweep_rows = 4;            // (accepted and ignored since round 6: a wave takes the 4 sites of a level-1 block group per iteration)
     bool force_block_sweep = false;     // tests: run the block sweep on small populations
     bool force_inline_sweep = false;    // tests: run the inline (queue-free) block sweep
     uint32_t block_waves = 0;           // block sweep: waves per workgroup (0 = auto: 4, 8 or 16)
@@ -670,61 +686,46 @@ extern "C" int ps_set_rates(ps_population *p, int n_comp, const double *lam_mut,
 // ---------------------------------------------------------------------------
 // core sweep launch
 // ---------------------------------------------------------------------------
-template <uint32_t ROWS, bool GA, bool MU, bool HR>
-static int launch_core_sweep_wave_r(ps_population *p, const core_sweep_args &a, hipStream_t st)
+// candidate queue of a wave of the wave / window sweeps: every cell of one batch (4 rows x `cells` cells) whose symbol
+// can hold an event (s < 3k + R), with 10 standard deviations to spare (a full queue only sends the batch to the
+// queue-free redo; with HR a batch whose residual cells fill more than half of it as well); 0 = the plan is not one
+// the queued sweeps take (cshift > 1: symbols of 8 and above hold events)
+static uint32_t sweep_queue_entries(const ps_core_plan &pl, uint32_t cells)
+{
+    if (!pl.has_events) return 16u;
+    if (pl.cshift > 1u) return 0u;
+    const double m = (double)PS_BATCH_ROWS * (double)cells * (double)(3u * pl.k + pl.R) / 64.0;
+    return ((uint32_t)std::ceil(m + 10.0 * std::sqrt(m) + 16.0) + 15u) & ~15u;
+}
+
+template <bool GA, bool MU, bool HR>
+static int launch_core_sweep_wave(ps_population *p, core_sweep_args a, hipStream_t st)
 {
     const uint32_t block = 256u, wpb = block / 64u;
-    const uint32_t lds = wpb * (ROWS * 1024u + ps_qcap(ROWS) * 4u + PS_PUSH_TABLE_BYTES);
-    const uint32_t want = (a.rows + wpb * ROWS - 1) / (wpb * ROWS);
+    a.qcap = sweep_queue_entries(a.plan, std::min(1024u, (uint32_t)p->cfg.pop_size));
+    // (the two sets of chunk counters alternate among the launches that USE them: a launch zeroes the other set)
+    a.launch_parity = (uint32_t)(p->sweep_launches++ & 1u);
+    const uint32_t lds = wpb * ps_wave_lds(a.qcap);
+    const uint32_t batches = (a.rows + (a.site_offset & 3u) + PS_BATCH_ROWS - 1u) / PS_BATCH_ROWS;
+    const uint32_t want = (batches + wpb - 1u) / wpb;
     const uint32_t fit = std::max(1u, std::min(8u, p->lds_limit / lds));
     const uint32_t bpc = std::min(p->sweep_blocks_per_cu, fit);
     const uint32_t grid = std::max(8u, std::min((want + 7u) & ~7u, 256u * bpc));   // a multiple of the 8 groups
-    // every candidate byte below 16 and every state byte below 16 (a loaded matrix may hold any byte): the level-1
-    // nibble rides in the child byte (core_kernels.h, STASH)
-    // (bytes 16-31: bit 4 rides in the queue entry, STASH = 2)
-    const uint32_t stash = (a.plan.has_events && p->nibble_safe) ? (a.plan.bC <= 15u ? 1u : a.plan.bC <= 31u ? 2u : 0u) : 0u;
-    if (a.nt) {
-        if (stash == 1u) hipLaunchKernelGGL((core_sweep_wave_kernel<ROWS, GA, MU, HR, 1u, true>), dim3(grid), dim3(block), lds, st, a);
-        else if (stash == 2u) hipLaunchKernelGGL((core_sweep_wave_kernel<ROWS, GA, MU, HR, 2u, true>), dim3(grid), dim3(block), lds, st, a);
-        else hipLaunchKernelGGL((core_sweep_wave_kernel<ROWS, GA, MU, HR, 0u, true>), dim3(grid), dim3(block), lds, st, a);
-    } else {
-        if (stash == 1u) hipLaunchKernelGGL((core_sweep_wave_kernel<ROWS, GA, MU, HR, 1u, false>), dim3(grid), dim3(block), lds, st, a);
-        else if (stash == 2u) hipLaunchKernelGGL((core_sweep_wave_kernel<ROWS, GA, MU, HR, 2u, false>), dim3(grid), dim3(block), lds, st, a);
-        else hipLaunchKernelGGL((core_sweep_wave_kernel<ROWS, GA, MU, HR, 0u, false>), dim3(grid), dim3(block), lds, st, a);
-    }
+    if (a.nt) hipLaunchKernelGGL((core_sweep_wave_kernel<GA, MU, HR, true>), dim3(grid), dim3(block), lds, st, a);
+    else hipLaunchKernelGGL((core_sweep_wave_kernel<GA, MU, HR, false>), dim3(grid), dim3(block), lds, st, a);
     HIPCHK(hipGetLastError());
     return PS_OK;
 }
 
-template <bool GA, bool MU, bool HR>
-static int launch_core_sweep_wave(ps_population *p, const core_sweep_args &a, hipStream_t st)
-{
-    switch (p->sweep_rows) {
-    case 2: return launch_core_sweep_wave_r<2, GA, MU, HR>(p, a, st);
-    case 3: return launch_core_sweep_wave_r<3, GA, MU, HR>(p, a, st);
-    default: return launch_core_sweep_wave_r<4, GA, MU, HR>(p, a, st);
-    }
-}
-
-// The wave-per-row sweep queues every candidate cell (level-1 byte <= bC) of `rows`
-// site rows.  It is selected only when that many cells fit the queue with 10 standard
-// deviations to spare (and the SWAR byte compare applies: bC < 127).
-static bool wave_sweep_fits(const ps_population *p, uint32_t rows)
-{
-    const ps_core_plan &pl = p->cplan;
-    const double m = (double)rows * (double)p->cfg.pop_size * (double)(pl.bC + 1u) / 256.0;
-    return m + 10.0 * std::sqrt(m) + 16.0 <= (double)ps_qcap(rows);
-}
-
+// The wave-per-row sweep queues every cell of a batch whose symbol can hold an event; it is selected only when those
+// fit a queue (cshift <= 1: at most an eighth of the cells) that fits the LDS beside the rows.
 static bool wave_sweep_eligible(ps_population *p, bool mu, bool hr)
 {
     if (p->pitch > 1024 || p->force_block_sweep) return false;
     const ps_core_plan &pl = p->cplan;
-    if (p->sweep_rows < 2 || p->sweep_rows > 4) p->sweep_rows = 3;
     if (!pl.has_events || (!mu && !hr)) return true;
-    if (pl.bC > 126) return false;
-    while (p->sweep_rows > 2 && !wave_sweep_fits(p, p->sweep_rows)) p->sweep_rows--;
-    return wave_sweep_fits(p, p->sweep_rows);
+    const uint32_t qe = sweep_queue_entries(pl, std::min(1024u, (uint32_t)p->cfg.pop_size));
+    return qe != 0u && 4u * ps_wave_lds(qe) <= p->lds_limit;
 }
 
 // geometry of the block sweep for this population and these rates; false if its queues cannot
@@ -734,10 +735,10 @@ static bool block_sweep_geometry(const ps_population *p, bool ga, bool mu, bool 
 {
     const ps_core_plan &pl = p->cplan;
     const bool events = pl.has_events && (mu || hr);
-    if (events && pl.bC > 126) return false;
+    if (events && pl.cshift > 1u) return false;       // (its queue entries carry three symbol bits)
     g->segs = (p->cpr + 63u) / 64u;
     auto up16 = [](double x) { return (uint32_t)(((uint64_t)std::ceil(x) + 15u) & ~15ull); };
-    const double hr_frac = (events && hr) ? (double)(pl.T[6] - pl.T[2]) / 4294967296.0 : 0.0;
+    const double hr_frac = (events && hr) ? (double)(pl.T[6] - pl.T[2]) / 4294967296.0 * (double)pl.R / 64.0 : 0.0;
     // a wave works on batches of SB segments (4, or 2 when the queues of 4 do not fit beside the
     // rows); the workgroup is as small as a row allows (4, 8 or 16 waves), so that several
     // workgroups per CU overlap their load / compute / store phases
@@ -747,7 +748,7 @@ static bool block_sweep_geometry(const ps_population *p, bool ga, bool mu, bool 
         if (p->block_waves) nw = p->block_waves;
         *waves = nw;
         g->SB = SB;
-        const double mq = events ? SB * 1024.0 * (double)(pl.bC + 1u) / 256.0 : 0.0;
+        const double mq = events ? SB * 1024.0 * (pl.cshift ? 0.125 : 0.0625) : 0.0;
         g->QW = std::max(64u, up16(mq + 10.0 * std::sqrt(mq)));
         for (uint32_t R = std::max(1u, nw * SB / std::max(1u, g->segs)); R >= 1; R >>= 1) {
             const uint32_t batches_per_wave = (R * g->segs + nw * SB - 1u) / (nw * SB);
@@ -775,10 +776,10 @@ static bool block_sweep_preload(const ps_population *p, const core_block_geom &g
     return p->pitch <= 65536u && g.R * g.segs <= nw * g.SB && !p->no_block_preload;
 }
 
-template <uint32_t SB, bool PRE, bool GA, bool MU, bool HR, bool STASH>
-static int launch_block_kernel_s(const core_sweep_args &a, const core_block_geom &g, uint32_t lds, uint32_t nw, hipStream_t st)
+template <uint32_t SB, bool PRE, bool GA, bool MU, bool HR>
+static int launch_block_kernel(const core_sweep_args &a, const core_block_geom &g, uint32_t lds, uint32_t nw, hipStream_t st)
 {
-    auto kern = core_sweep_block_kernel<SB, PRE, GA, MU, HR, STASH>;
+    auto kern = core_sweep_block_kernel<SB, PRE, GA, MU, HR>;
     if (lds > 64 * 1024)
         HIPCHK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const uint32_t groups = (a.rows + g.R - 1) / g.R;
@@ -789,14 +790,6 @@ static int launch_block_kernel_s(const core_sweep_args &a, const core_block_geom
     hipLaunchKernelGGL(kern, dim3(grid), dim3(64u * nw), lds, st, a, g);
     HIPCHK(hipGetLastError());
     return PS_OK;
-}
-
-template <uint32_t SB, bool PRE, bool GA, bool MU, bool HR>
-static int launch_block_kernel(const core_sweep_args &a, const core_block_geom &g, uint32_t lds, uint32_t nw, hipStream_t st, bool nibble_safe)
-{
-    // every candidate byte and every state byte below 16: the level-1 nibble rides in the child byte (core_kernels.h, STASH)
-    if (a.plan.has_events && a.plan.bC <= 15u && nibble_safe) return launch_block_kernel_s<SB, PRE, GA, MU, HR, true>(a, g, lds, nw, st);
-    return launch_block_kernel_s<SB, PRE, GA, MU, HR, false>(a, g, lds, nw, st);
 }
 
 template <bool GA, bool MU, bool HR>
@@ -812,10 +805,10 @@ static int launch_core_sweep_block(ps_population *p, const core_sweep_args &a, c
             else idx_transpose_kernel<<<(n + 255) / 256, 256, 0, st>>>(d_idx, p->d_idxT, a.N, p->cpr);
         }
         if (GA && pre)
-            return g.SB == 4u ? launch_block_kernel<4, GA, GA, MU, HR>(a, g, lds, nw, st, p->nibble_safe)
-                              : launch_block_kernel<2, GA, GA, MU, HR>(a, g, lds, nw, st, p->nibble_safe);
-        return g.SB == 4u ? launch_block_kernel<4, false, GA, MU, HR>(a, g, lds, nw, st, p->nibble_safe)
-                          : launch_block_kernel<2, false, GA, MU, HR>(a, g, lds, nw, st, p->nibble_safe);
+            return g.SB == 4u ? launch_block_kernel<4, GA, GA, MU, HR>(a, g, lds, nw, st)
+                              : launch_block_kernel<2, GA, GA, MU, HR>(a, g, lds, nw, st);
+        return g.SB == 4u ? launch_block_kernel<4, false, GA, MU, HR>(a, g, lds, nw, st)
+                          : launch_block_kernel<2, false, GA, MU, HR>(a, g, lds, nw, st);
     }
     // inline kernel: every candidate handled by its owner lane, no queues to overflow
     const uint32_t block = 1024u;
@@ -835,34 +828,35 @@ static int launch_core_sweep_block(ps_population *p, const core_sweep_args &a, c
 }
 
 // window sweep (core_kernels.h): N > 1024, fused gather + mutate (+ HR), parents in ascending order, out of place
+static uint32_t window_sweep_lds(const ps_core_plan &pl)
+{
+    const uint32_t qe = sweep_queue_entries(pl, 1024u);
+    return qe ? 4u * ps_window_lds(qe) : 0u;
+}
+
 template <bool HR>
 static int launch_core_sweep_window(ps_population *p, const core_sweep_args &a, hipStream_t st)
 {
-    constexpr uint32_t ROWS = 3;
-    const uint32_t lds = 4u * (ROWS * PS_WSTRIDE + PS_WQCAP * 4u + PS_PUSH_TABLE_BYTES);
+    const uint32_t lds = window_sweep_lds(a.plan);
     // ("window_blocks_per_cu": a donor-sharded run leaves the exchange's kernels room beside the sweep)
     const uint32_t bpc = std::max(1u, std::min(p->window_blocks_per_cu ? p->window_blocks_per_cu : (uint32_t)PS_WBPC, p->lds_limit / lds));
     const uint32_t segs = (a.N + 1023u) / 1024u;
     // at least one wave per (XCD group, segment); a multiple of the 8 groups
     const uint32_t grid = (std::max(8u * ((segs + 3u) / 4u), (256u - 8u * p->free_cus_per_xcd) * bpc) + 7u) & ~7u;
-    const uint32_t stash = p->nibble_safe ? (a.plan.bC <= 15u ? 1u : a.plan.bC <= 31u ? 2u : 0u) : 0u;
-    // two launches: the segments whose parent window fits the row buffer, then the others (usually none: its waves
-    // leave at once); they alternate the counter sets like any two consecutive launches
-    // (the counter sets alternate among the launches that use them: a parity of their own)
+    // Two launches ON THE SAME STREAM, the first before the second: the segments whose parent window fits the row buffer,
+    // then the others (usually none: its waves leave at once, told by the flag of this generation's parity that only the
+    // first launch sets and that the first launch of the generation before cleared -- core_kernels.h).  They alternate the
+    // counter sets like any two consecutive launches (a parity of their own among the launches that use them).
     core_sweep_args a0 = a, b = a;
-    // (experiment, round 5: PANSIM_WINDOW_GATE = rows a segment may run ahead of the slowest one of its XCD group; only
-    // where every segment of a group has resident waves: at most 64 segments, the grid one round of workgroups)
-    static const int gate_rows = getenv("PANSIM_WINDOW_GATE") ? atoi(getenv("PANSIM_WINDOW_GATE")) : 0;
-    if (gate_rows > 0 && segs <= 64u && grid <= (256u - 8u * p->free_cus_per_xcd) * bpc) a0.gate_chunks = std::max(1u, (uint32_t)gate_rows / (4u * ROWS));
+    a0.qcap = b.qcap = sweep_queue_entries(a.plan, 1024u);
     a0.launch_parity = (uint32_t)(p->window_launches++ & 1u);
     b.launch_parity = (uint32_t)(p->window_launches++ & 1u);
-#define PS_WLAUNCH(ST_, NT_)                                                                                                           \
-    {                                                                                                                                 \
-        hipLaunchKernelGGL((core_sweep_window_kernel<ROWS, true, HR, ST_, NT_, false>), dim3(grid), dim3(256), lds, st, a0);          \
-        hipLaunchKernelGGL((core_sweep_window_kernel<ROWS, true, HR, ST_, NT_, true>), dim3(grid), dim3(256), lds, st, b);            \
+#define PS_WLAUNCH(NT_)                                                                                                    \
+    {                                                                                                                     \
+        hipLaunchKernelGGL((core_sweep_window_kernel<true, HR, NT_, false>), dim3(grid), dim3(256), lds, st, a0);          \
+        hipLaunchKernelGGL((core_sweep_window_kernel<true, HR, NT_, true>), dim3(grid), dim3(256), lds, st, b);            \
     }
-    if (a.nt) { if (stash == 1u) PS_WLAUNCH(1u, true) else if (stash == 2u) PS_WLAUNCH(2u, true) else PS_WLAUNCH(0u, true) }
-    else { if (stash == 1u) PS_WLAUNCH(1u, false) else if (stash == 2u) PS_WLAUNCH(2u, false) else PS_WLAUNCH(0u, false) }
+    if (a.nt) PS_WLAUNCH(true) else PS_WLAUNCH(false)
 #undef PS_WLAUNCH
     HIPCHK(hipGetLastError());
     return PS_OK;
@@ -900,15 +894,11 @@ static int launch_core_sweep(ps_population *p, const uint32_t *d_idx, uint32_t g
     // window sweep: the wave-per-row design for N > 1024 -- needs the children in ascending parent order (ps_sim's
     // generations), the fused gather + mutate (+ HR) step with events, its queue sized like the wave sweep's, a second
     // buffer (it is out of place by construction) and 4 x 5.2 KB of LDS
+    const uint32_t wlds = window_sweep_lds(a.plan);
     bool window = !wave && parents_sorted && ga && mu && a.plan.has_events && p->window_sweep != 0 && p->pitch > 1024
                   && a.N <= (1u << 22)
-                  && a.plan.bC <= 126u && !p->force_inline_sweep && !p->force_block_sweep
-                  && 4u * (3u * PS_WSTRIDE + PS_WQCAP * 4u + PS_PUSH_TABLE_BYTES) <= p->lds_limit;
-    if (window) {
-        // (a full queue only sends the batch to the queue-free redo; 10 sigma of room as for the wave sweep)
-        const double m = 3.0 * 1024.0 * (double)(a.plan.bC + 1u) / 256.0;
-        window = m + 10.0 * std::sqrt(m) + 16.0 <= (double)PS_WQCAP;
-    }
+                  && !p->force_inline_sweep && !p->force_block_sweep
+                  && wlds != 0u && wlds <= p->lds_limit;
     if (window && !p->state2 && hipMalloc(&p->state2, (uint64_t)p->cfg.ncols * p->pitch) != hipSuccess) {
         (void)hipGetLastError();
         p->state2 = nullptr;
@@ -928,15 +918,15 @@ static int launch_core_sweep(ps_population *p, const uint32_t *d_idx, uint32_t g
         }
     }
     a.overflow_flag = p->d_flag;
+    a.qcap = 0;
     a.qcap_limit = p->sweep_queue_cap;
-    a.gate_chunks = 0;
     a.stamps = p->d_stamps;
     a.work_ctr = p->d_work;
     a.wide_flags = p->d_work + p->work_flags_ofs;
-    a.launch_parity = (uint32_t)(p->sweep_launches++ & 1u);
+    a.launch_parity = 0;
     a.idxT = p->d_idxT;
     p->last_sweep_form = window ? PS_SWEEP_FORM_WINDOW
-                         : wave ? ((a.plan.has_events && a.plan.bC <= 31u && p->nibble_safe) ? PS_SWEEP_FORM_WAVE_STASH : PS_SWEEP_FORM_WAVE)
+                         : wave ? PS_SWEEP_FORM_WAVE
                          : inline_form ? PS_SWEEP_FORM_INLINE : PS_SWEEP_FORM_BLOCK;
     if (window) return hr ? launch_core_sweep_window<true>(p, a, st) : launch_core_sweep_window<false>(p, a, st);
 #define PS_DISPATCH(G_, M_, H_)                                              \
@@ -1709,7 +1699,8 @@ static int average_distance_device(ps_population *p, double *d_out, hipStream_t 
             // (row pitch of the counts: Npad u16 + 256 bytes -- with a power-of-two pitch the 32 rows one store instruction
             // touches, and the 16 rows a phase-2 workgroup reads, fall on ONE memory channel)
             const uint32_t nb = p->davg_nb ? p->davg_nb : 2u, ld = Npad + 128u;
-            uint64_t band = std::min<uint64_t>((i_cnt + 63) & ~63ull, std::max<uint64_t>(256, ((9ull << 30) / ((uint64_t)ld * 2)) & ~255ull));
+            // (a wave of phase 1 stores 32 * nb whole rows, at most 128: the band -- the scratch's row count -- is a multiple of that)
+            uint64_t band = std::min<uint64_t>((i_cnt + 127) & ~127ull, std::max<uint64_t>(256, ((9ull << 30) / ((uint64_t)ld * 2)) & ~255ull));
             const uint64_t need_in = band * ld * 2;
             if (p->davg_in_cap < need_in) {
                 if (p->d_davg_in) HIPCHK(hipFree(p->d_davg_in));
@@ -2904,7 +2895,10 @@ static int sim_create_impl(const ps_sim_params *p, ps_sim *s)
         // (cfg2) 4 / 5 / 6 / 7 -> 1993 / 2080 / 2093 / 1972 generations/s; with the D-avg of --competition_strength in the
         // chain 1957 / 2007 / 1921 / 1848 (the authors' run 1942 / 1897 / 1841 / 1692); sweep and HGT in turns (cfg3)
         // - / 1537 / 1617 / 1645.
-        const uint32_t light = p->competition_strength > 0.0 ? 5u : s->heavy_hgt ? 7u : 6u;
+        // Round 6 (bit-sliced level 1, 4-row batches; profiles/r06_sweep_experiments.md): light HGT 5 / 6 / 7 / 8 -> 1966 / 1843 /
+        // 1841 / 1829 generations/s (the sweep itself 0.492-0.496 ms at every setting: from 6 on the chain no longer hides
+        // behind it); the authors' run 1813 / 1779 / 1618 at 5 / 6 / 7; cfg3 1686 / 1685 / 1683 at 7 / 6 / 8.
+        const uint32_t light = s->heavy_hgt ? 7u : 5u;
         s->core->sweep_blocks_per_cu = list_lds <= 16 * 1024 ? light : std::min(light, 6u);
     }
     HIPCHK(hipHostMalloc(&s->h_num_genes, N * sizeof(int32_t), hipHostMallocMapped));

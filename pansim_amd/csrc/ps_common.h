@@ -9,10 +9,11 @@
 
 // RNG streams (Philox counter word 3; word 2 is the generation)
 enum : uint32_t {
-    PS_STREAM_CORE_L1 = 1,    // ctr = (site, individual/16, gen): 16 level-1 bytes
-    PS_STREAM_CORE_L2 = 2,    // ctr = (site, individual, gen): refine bits + donor
+    PS_STREAM_CORE_L1 = 1,    // ctr = (site/2, individual/16, gen): symbol planes 0-3 of 2 sites x 16 individuals
+    PS_STREAM_CORE_L2 = 2,    // ctr = (site, individual, gen): the residual word + donor
     PS_STREAM_ACC_MUT = 3,    // ctr = (gene/4, individual, gen): 4 flip words
     PS_STREAM_HGT = 4,        // ctr = (event / 2, donor, gen), | compartment << 8: (x, y) event 2m, (z, w) event 2m + 1
+    PS_STREAM_CORE_L1B = 5,   // ctr = (site/4, individual/16, gen): symbol planes 4-5 of 4 sites x 16 individuals
     PS_STREAM_INIT_CORE = 16, // host sequential streams: ctr = (n lo, n hi, gen)
     PS_STREAM_INIT_ACC = 17,
     PS_STREAM_SELECTION = 18,
@@ -61,14 +62,20 @@ PS_HD ps_u4 ps_philox(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32
     return ps_philox_r<10>(c0, c1, c2, c3, k0, k1);
 }
 
-// the level-1 bytes of the core cell plan: one block per 16 cells of EVERY row, the one Philox call of
-// the sweeps that is not amortised over candidates
-#ifndef PS_L1_ROUNDS
-#define PS_L1_ROUNDS 10
-#endif
-PS_HD ps_u4 ps_philox_l1(uint32_t site, uint32_t chunk, uint32_t gen, uint32_t k0, uint32_t k1)
+// Level 1 of the core cell plan: a 6-bit SYMBOL per cell, bit-sliced.  Plane k (0..5) holds bit k of the
+// symbols; a plane word covers the 16 individuals of one chunk at two consecutive sites: bit (i & 15) + 16 * (site & 1).
+//   block A = Philox(site / 2, i / 16, gen, CORE_L1):  (x, y, z, w) = planes 0, 1, 2, 3 of the sites 2 * (site / 2) + {0, 1}
+//   block B = Philox(site / 4, i / 16, gen, CORE_L1B): x / y = plane 4 of the sites 4 * (site / 4) + {0, 1} / {2, 3},
+//                                                      z / w = plane 5 of the same
+// i.e. three Philox blocks per 4 sites x 16 individuals -- 6 bits per cell, every bit used once -- and a lane of the sweeps,
+// which owns 16 individuals of 4 consecutive sites per trip, computes exactly the blocks it consumes.
+PS_HD ps_u4 ps_philox_l1a(uint32_t site2, uint32_t chunk, uint32_t gen, uint32_t k0, uint32_t k1)
 {
-    return ps_philox_r<PS_L1_ROUNDS>(site, chunk, gen, PS_STREAM_CORE_L1, k0, k1);
+    return ps_philox(site2, chunk, gen, PS_STREAM_CORE_L1, k0, k1);
+}
+PS_HD ps_u4 ps_philox_l1b(uint32_t site4, uint32_t chunk, uint32_t gen, uint32_t k0, uint32_t k1)
+{
+    return ps_philox(site4, chunk, gen, PS_STREAM_CORE_L1B, k0, k1);
 }
 
 // n-th f64 of a seeded host stream: two per Philox block, top 53 bits x 2^-53
@@ -80,19 +87,48 @@ PS_HD double ps_hs_f64(uint32_t k0, uint32_t k1, uint32_t stream, uint32_t gen, 
     return (double)(x >> 11) * (1.0 / 9007199254740992.0);
 }
 
-// Core cell plan: cumulative 32-bit thresholds over one uniform word u
-//   u < T[0],T[1],T[2] : mutate to 2,4,8            (population.rs:511-540)
-//   u < T[3],T[4],T[5] : mutate to 2,4,8 AND receive a donor allele
-//   u < T[6]           : receive a donor allele only (population.rs:544-751)
+// Core cell plan.  Symbol s = 4 * n + t, n = planes 0-3 (bit k of n = plane k), t = planes 4-5:
+//   s < k, < 2k, < 3k    : mutate to 2, 4, 8 -- decided by the symbol alone          (population.rs:511-540)
+//   3k <= s < 3k + R     : RESIDUAL -- one 32-bit word u (level 2) against seven cumulative thresholds:
+//       u < T[0],T[1],T[2] : mutate to 2,4,8
+//       u < T[3],T[4],T[5] : mutate to 2,4,8 AND receive a donor allele
+//       u < T[6]           : receive a donor allele only                              (population.rs:544-751)
+//   otherwise            : nothing happens to the cell
+// k = floor(64 a) symbols carry 1/64 each of an allele's mutate-only mass a; what is left of the event mass lives, scaled by
+// 64 / R, in the R residual symbols.  A cell whose n has a bit at or above cshift cannot hold an event (3k + R <= 4 << cshift).
 struct ps_core_plan {
     uint32_t T[7];
     uint32_t has_events;
-    uint32_t bC;          // largest level-1 byte that can still hold an event
+    uint32_t k, R;
+    uint32_t cshift;      // 0..4 (4: every cell is a candidate)
+    uint32_t lut8;        // 4-bit code per symbol s < 8: the allele (2 / 4 / 8), 1 = residual, 0 = nothing
 };
+
+// what a symbol decides: 2 / 4 / 8 = that allele, 1 = residual, 0 = nothing
+PS_HD uint32_t ps_sym_code(uint32_t s, const ps_core_plan &pl)
+{
+    if (s < pl.k) return 2u;
+    if (s < 2u * pl.k) return 4u;
+    if (s < 3u * pl.k) return 8u;
+    return (s < 3u * pl.k + pl.R) ? 1u : 0u;
+}
+
+// the symbol of cell (site, individual) out of its two blocks
+PS_HD uint32_t ps_cell_nibble(const ps_u4 &A, uint32_t site, uint32_t ind)
+{
+    const uint32_t pos = (ind & 15u) + 16u * (site & 1u);
+    return ((A.x >> pos) & 1u) | (((A.y >> pos) & 1u) << 1) | (((A.z >> pos) & 1u) << 2) | (((A.w >> pos) & 1u) << 3);
+}
+PS_HD uint32_t ps_cell_pair(const ps_u4 &B, uint32_t site, uint32_t ind)
+{
+    const uint32_t pos = (ind & 15u) + 16u * (site & 1u);
+    const uint32_t p4 = (site & 2u) ? B.y : B.x, p5 = (site & 2u) ? B.w : B.z;
+    return ((p4 >> pos) & 1u) | (((p5 >> pos) & 1u) << 1);
+}
 
 struct ps_cell { uint32_t mut; uint32_t hr; };
 
-// classify a refined word against the plan
+// classify the level-2 word of a residual cell against the plan
 PS_HD ps_cell ps_classify(uint32_t u, const ps_core_plan &pl)
 {
     ps_cell o = { 0u, 0u };

@@ -74,15 +74,19 @@ def run(trials, seed=1, log=print):
         L = int(rng.choice([1, 3, 10, 40]))
         LG = int(rng.choice([L, 50 * L, 1200000]))
         off = int(rng.integers(0, LG - L + 1))
-        lm = float(rng.choice([0.0, 0.2, 0.05 * LG, 0.2 * LG]))
+        # (per-site rates on every side of the plan's limits: no symbol-decided mutations (k = 0), the default plan, plans
+        # that reach the symbols of n = 1 (cshift 1) and plans the queued sweeps do not take (cshift >= 2))
+        lm = float(rng.choice([0.0, 0.2, 0.03 * LG, 0.05 * LG, 0.11 * LG, 0.2 * LG]))
         lh = float(rng.choice([0.0, 0.1, 0.02 * LG, 0.2 * LG])) if N > 1 else 0.0
         m = (1 << rng.integers(0, 4, (N, L))).astype(np.uint8)
         if rng.random() < 0.2:
             # a loaded matrix may hold any byte (ps_load_matrix): the sweeps must carry bytes above 15 through
-            # gather, mutation and HR unchanged (the STASH forms, which borrow bits 4-7, are not used then)
+            # gather, mutation and HR unchanged
             for _ in range(int(rng.integers(1, 8))):
                 m[rng.integers(0, N), rng.integers(0, L)] = int(rng.choice([0, 3, 16, 17, 128, 200, 255]))
         sample = rng.integers(0, N, N).astype(np.uint32)
+        if rng.random() < 0.4:
+            sample = np.sort(sample)          # ascending parents: the window sweep above 1024 individuals
         seed, gen = int(rng.integers(0, 2**40)), int(rng.integers(0, 2**31))
         plan = o.core_plan(lm, lh, LG)
         want = o.next_generation(m, sample)
@@ -133,7 +137,7 @@ def run(trials, seed=1, log=print):
             acc = pa.Population(N, G, 2, False, 0.3, 0, cg)
             acc.load_matrix(a)
             acc.set_tuning("davg_form", int(rng.integers(0, 4)))
-            acc.set_tuning("davg_nb", int(rng.integers(0, 3)))
+            acc.set_tuning("davg_nb", int(rng.choice([0, 1, 2, 4])))
             got = acc.average_distance()
             K = int(rng.integers(1, min(N, 5) + 1))
             rows = np.concatenate([acc.average_distance_rows(N * r // K, N * (r + 1) // K - N * r // K) for r in range(K)])

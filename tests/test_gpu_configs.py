@@ -148,13 +148,15 @@ def test_average_distance_large_populations(pa, orc, N, G, cg):
 
 @pytest.mark.parametrize("N,G,cg,nb", [(2, 9, 0, 0), (33, 65, 0, 1), (130, 257, 3, 2), (1000, 4000, 2000, 1), (2100, 130, 7, 2),
                                        (4100, 4000, 2000, 0), (9000, 64, 0, 0), (20000, 300, 11, 0),
-                                       (300, 5000, 17, 1), (700, 9000, 5, 2), (1000, 4000, 2000, 4), (333, 700, 1, 4)])
+                                       (300, 5000, 17, 1), (700, 9000, 5, 2), (1000, 4000, 2000, 4), (333, 700, 1, 4),
+                                       (390, 300, 3, 4), (130, 900, 2, 4), (600, 400, 9, 4)])
 def test_average_distance_on_the_matrix_cores(pa, orc, N, G, cg, nb):
     # D-avg with the intersections as a {0, 1} X X^T on the FP4 matrix cores and the ordered f64 fold in the accumulator
     # layout (acc_average_distance_mfma_kernel; population.rs:753-784, :114-151): ragged populations and gene counts (fewer
     # and more 256-gene chunks than the sixteen epilogue groups that ride behind them), both
     # fragment counts per wave, a zero distance and an empty row inside the fold, cg = 0 (an empty union is NaN and must
-    # stay out of the fold only where j == i), and row shards against slices of the whole
+    # stay out of the fold only where j == i), and row shards against slices of the whole; nb = 4 (a wave of phase 1 stores
+    # 128 whole rows) with shards of 130 / 43 / 200 rows, i.e. bands that 64-row rounding would leave short
     rng = np.random.default_rng(N * 7 + G)
     m = (rng.random((N, G)) < 0.3).astype(np.uint8)
     if N > 6:
@@ -280,7 +282,7 @@ def _shard_counts_sum(pa, kw, gens, P, n_shards, seed=0):
 
 
 def test_config3_full_size_properties(pa):
-    # BASELINE configs[2]: HR_rate = HGT_rate = 0.5 at the full 1.2 M sites (bC = 18: the wave sweep's STASH = 2 build;
+    # BASELINE configs[2]: HR_rate = HGT_rate = 0.5 at the full 1.2 M sites (cshift = 1: the wave sweep's second build;
     # the binned HGT taking turns with the sweep)
     kw = dict(pop_size=1000, core_size=1200000, pan_genes=6000, core_genes=2000, HR_rate=0.5, HGT_rate=0.5)
     P, gens = 50000, 4
@@ -291,7 +293,7 @@ def test_config3_full_size_properties(pa):
         (cnt,) = sim.core_genome.pairwise_counts(sim.range1, sim.range2)
         runs.append((sim.last_parents(), cnt, sim.pan_genome.gene_frequencies(), sim.pan_genome.read_matrix()))
         if len(runs) == 1:
-            assert sim.core_genome.last_sweep_form() == 2                # PS_SWEEP_FORM_WAVE_STASH (here: bit 4 of the byte in the queue entry)
+            assert sim.core_genome.last_sweep_form() == 1                # PS_SWEEP_FORM_WAVE
             assert (cnt % 2 == 0).all() and cnt.max() > 0                # alleles stay one-hot
             # HGT never clears a gene (population.rs:632): one more recombination on the same state only adds bits
             before = runs[0][3]

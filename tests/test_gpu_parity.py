@@ -612,9 +612,8 @@ def test_block_sweep_geometries(pa, orc, N, L, tune):
                                       (1000, 50, {"force_block_sweep": 1}), (9000, 24, {"block_batch": 2}),
                                       (2048, 30, {"force_inline_sweep": 1})])
 def test_sweeps_carry_bytes_above_15(pa, orc, N, L, tune):
-    # ps_load_matrix accepts any byte; at the default rates (bC <= 15) the sweeps use their STASH forms, which
-    # borrow bits 4-7 of the child byte in LDS -- only for matrices whose bytes are all below 16.  A matrix with
-    # bytes 16 / 200 / 255 must come through gather, mutation and HR like in the oracle.
+    # ps_load_matrix accepts any byte: a matrix with bytes 16 / 200 / 255 must come through gather, mutation and HR
+    # like in the oracle (a former build of the sweeps borrowed bits 4-7 of the child byte in LDS).
     rng = np.random.default_rng(N * 13 + L)
     m0 = _rand_core(rng, N, L)
     for v in (16, 17, 128, 200, 255, 0, 3):
@@ -622,7 +621,7 @@ def test_sweeps_carry_bytes_above_15(pa, orc, N, L, tune):
             m0[rng.integers(0, N), rng.integers(0, L)] = v
     sample = rng.integers(0, N, N).astype(np.uint32)
     LG = 1200000
-    lm, lh = 0.05 * LG, 0.0025 * LG          # cfg2's per-site rates: bC = 12
+    lm, lh = 0.05 * LG, 0.0025 * LG          # cfg2's per-site rates
     plan = orc.core_plan(lm, lh, LG)
     want = orc.next_generation(m0, sample)
     orc.mutate_core(want, 100, 21, 5, plan)
@@ -643,31 +642,32 @@ def test_sweeps_carry_bytes_above_15(pa, orc, N, L, tune):
     pop.close()
 
 
-@pytest.mark.parametrize("total,bC", [(0.0640, 15), (0.0650, 16), (0.0039, 0), (0.1200, 28), (0.1350, 32)])
-@pytest.mark.parametrize("N,rows,ascending", [(1000, 3, False), (1024, 2, False), (777, 4, False), (17, 3, False),
-                                              (5000, 3, True), (4097, 3, True)])
-def test_candidate_push_on_both_sides_of_the_stash_limit(pa, orc, N, rows, ascending, total, bC):
-    # The candidate push of the wave / window sweeps has three builds (core_kernels.h, STASH): one wave prefix sum + lane-private
-    # writes when every candidate byte is below 16 (bC <= 15: the level-1 nibble rides in the child byte), the same with bit 4
-    # of the byte in the queue entry and two more mask words for 15 < bC <= 31 (cfg3's rates), the ballot loop above that.
-    # Per-site event rates on both sides of both limits (bC = 15 / 16, 28 / 32; the last is a wave sweep only where its queue
-    # admits it, i.e. N = 17), a very sparse plan (most lanes without a candidate) and dense ones, for 2 / 3 / 4 rows per
-    # wave trip (two rows share a mask word; the third / fourth row pair takes the second word), ragged last lanes (N = 777,
-    # 17, 4097) and both sweeps (ascending parents + N > 1024 = the window sweep).
+@pytest.mark.parametrize("total,krc", [(0.0640, (1, 1, 0)), (0.0650, (1, 2, 1)), (0.0039, (0, 1, 0)), (0.0485, (0, 4, 0)),
+                                       (0.1300, (2, 2, 1)), (0.1350, (2, 3, 2))])
+@pytest.mark.parametrize("N,offset,ascending", [(1000, 40, False), (1024, 41, False), (777, 42, False), (17, 43, False),
+                                                (5000, 40, True), (4097, 43, True), (2100, 42, False)])
+def test_candidate_push_on_both_sides_of_the_plan_limits(pa, orc, N, offset, ascending, total, krc):
+    # The wave / window / block sweeps have two builds of their candidate push and dense pass (core_kernels.h): plans whose
+    # events all sit in symbols with n = 0 (cshift = 0: one candidate word per row pair) and plans that reach n = 1
+    # (cshift = 1, cfg3's rates: two more mask words, bit 0 of n in the queue entry); above that (cshift >= 2) the
+    # queue-free inline kernel runs.  Per-site event rates on both sides of both limits, a very sparse plan (most lanes
+    # without a candidate), a plan without symbol-decided mutations (k = 0: every event through the residual symbols),
+    # shards that start at every position inside a 4-site block group (offset mod 4: the first and the last batch of the
+    # wave / window sweeps then lie partly outside the shard), ragged last lanes (N = 777, 17, 4097) and all three sweeps
+    # (ascending parents + N > 1024 = the window sweep, unsorted = the block sweep).
     LG, L = 1200000, 26
-    rng = np.random.default_rng(N * 31 + rows + int(total * 1e4))
+    rng = np.random.default_rng(N * 31 + offset + int(total * 1e4))
     m0 = _rand_core(rng, N, L)
     sample = rng.integers(0, N, N).astype(np.uint32)
     if ascending:
         sample = np.sort(sample)
     lm, lh = (total - 0.002) * LG, 0.002 * LG
     plan = orc.core_plan(lm, lh, LG)
-    assert plan.bC == bC
+    assert (plan.k, plan.R, plan.cshift) == krc
     want = orc.next_generation(m0, sample)
-    orc.mutate_core(want, 40, 77, 11, plan)
-    orc.recombine_core(want, 40, 77, 11, plan)
-    pop = pa.Population(N, L, 4, True, 0.0, 77, 0, col_offset=40, global_cols=LG)
-    pop.set_tuning("sweep_rows", rows)
+    orc.mutate_core(want, offset, 77, 11, plan)
+    orc.recombine_core(want, offset, 77, 11, plan)
+    pop = pa.Population(N, L, 4, True, 0.0, 77, 0, col_offset=offset, global_cols=LG)
     pop.set_rates([lm], [lh])
     pop.load_matrix(m0)
     pop.step(11, sample, True)

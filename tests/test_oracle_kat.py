@@ -124,21 +124,35 @@ def test_derived_parameters(orc):
     assert d.avg_gene_freq_adj == 0.0 and d.avg_gene_num == 0
 
 
+def _plan_masses(plan):
+    """total mass of (mutate to one allele only, mutate to one allele AND receive, receive only) under a plan"""
+    T = [t / 2.0**32 for t in plan.T]
+    res = plan.R / 64.0
+    return plan.k / 64.0 + res * T[0], res * (T[3] - T[2]), res * (T[6] - T[5])
+
+
 def test_plan_probabilities(orc):
     pr = KAT["probabilities"]
     v = pr["core_hit_p"]
     plan = orc.core_plan(v["lam"], 0.0, v["L"])
     assert plan.T[2] == plan.T[6] and plan.has_events == 1
-    assert abs(plan.T[2] / 2.0**32 - v["p"]) < 2.0**-31
-    assert abs(plan.T[0] / 2.0**32 - v["p"] / 3) < 2.0**-31
+    a, b, c = _plan_masses(plan)
+    assert abs(3 * a - v["p"]) < 2.0**-31 and b == 0 and c == 0
     for f in pr["acc_flip"]:
         assert abs(orc.lib().orc_acc_flip_threshold(f["lam"], f["n"]) / 2.0**32 - f["p"]) < 2.0**-31
-    # joint plan: mass of "receives a donor allele" is q, independent of mutation
-    plan = orc.core_plan(60000.0, 30000.0, 1200000)
-    p, q = -math.expm1(-0.05), -math.expm1(-0.025)
-    T = [t / 2.0**32 for t in plan.T]
-    assert abs(T[2] - p * (1 - q)) < 1e-9 and abs((T[5] - T[2]) - p * q) < 1e-9
-    assert abs((T[6] - T[5]) - (1 - p) * q) < 1e-9 and plan.bC == int((plan.T[6] - 1) >> 24)
+    # joint plans: mass of "receives a donor allele" is q, independent of mutation; the symbol-decided part of an allele's
+    # mass is k / 64, the residual symbols carry the rest of every class
+    for lam_mut, lam_hr, L, krc in ((60000.0, 30000.0, 1200000, (1, 2, 1)), (60000.0, 3000.0, 1200000, (1, 1, 0)),
+                                    (60000.0, 0.0, 1200000, (1, 1, 0)), (12000.0, 0.0, 1200000, (0, 1, 0)),
+                                    (600000.0, 0.0, 1200000, (8, 2, 3)), (60000.0, 60000.0, 1200000, (0, 7, 1))):
+        plan = orc.core_plan(lam_mut, lam_hr, L)
+        p, q = -math.expm1(-lam_mut / L), -math.expm1(-lam_hr / L)
+        a, b, c = _plan_masses(plan)
+        assert abs(a - p * (1 - q) / 3) < 1e-9 and abs(b - p * q / 3) < 1e-9 and abs(c - (1 - p) * q) < 1e-9
+        assert (plan.k, plan.R, plan.cshift) == krc and 3 * plan.k + plan.R <= (4 << plan.cshift)
+        assert plan.k == math.floor(64 * p * (1 - q) / 3)
+        T = list(plan.T)
+        assert T == sorted(T) and T[1] - T[0] in (T[0], T[0] + 1, T[0] - 1)
     assert orc.core_plan(0.0, 0.0, 100).has_events == 0
 
 
