@@ -201,7 +201,7 @@ typedef struct { uint8_t mut; uint8_t hr; uint32_t donor; } cell_outcome;
  *   A = Philox(site / 2, ind / 16, gen, CORE_L1):  word j = plane j (j = 0..3) of the sites 2 (site / 2) + {0, 1}
  *   B = Philox(site / 4, ind / 16, gen, CORE_L1B): words 0 / 1 = plane 4 of the sites 4 (site / 4) + {0, 1} / {2, 3},
  *                                                  words 2 / 3 = plane 5 of the same
- * and inside a plane word the cell is bit (ind % 16) + 16 (site % 2).  Symbol = 4 n + t, bit j of n = plane j, bit 0 / 1
+ * and inside a plane word the cell is bit 8 (ind % 4) + (ind / 4) % 4 + 4 (site % 2).  Symbol = 4 n + t, bit j of n = plane j, bit 0 / 1
  * of t = plane 4 / 5. */
 static void core_blocks(uint64_t seed, uint32_t gen, uint32_t site, uint32_t chunk, uint32_t A[4], uint32_t B[4])
 {
@@ -215,7 +215,7 @@ static void core_blocks(uint64_t seed, uint32_t gen, uint32_t site, uint32_t chu
 /* (A, B = core_blocks(site, ind / 16): the row loops below compute them once per 16 cells) */
 static uint32_t core_symbol(const uint32_t A[4], const uint32_t B[4], uint32_t site, uint32_t ind)
 {
-    uint32_t pos = (ind & 15u) + 16u * (site & 1u);
+    uint32_t pos = 8u * (ind & 3u) + ((ind >> 2) & 3u) + 4u * (site & 1u);
     uint32_t n = ((A[0] >> pos) & 1u) | (((A[1] >> pos) & 1u) << 1) | (((A[2] >> pos) & 1u) << 2) | (((A[3] >> pos) & 1u) << 3);
     uint32_t p4 = (site & 2u) ? B[1] : B[0], p5 = (site & 2u) ? B[3] : B[2];
     uint32_t t = ((p4 >> pos) & 1u) | (((p5 >> pos) & 1u) << 1);

@@ -80,10 +80,26 @@ __device__ __forceinline__ uint32_t ps_noncand_word(const ps_u4 &A, uint32_t csh
     return (cshift <= 0u ? A.x : 0u) | (cshift <= 1u ? A.y : 0u) | (cshift <= 2u ? A.z : 0u) | (cshift <= 3u ? A.w : 0u);
 }
 
-// 16-bit mask (bit k = cell 16 * chunk + k) of the cells of one site that may hold an event
-__device__ __forceinline__ uint32_t ps_cand16(const ps_u4 &A, uint32_t site, uint32_t cshift)
+// Plane-word geometry (ps_plane_pos): bit 8b + s of a word = cell 4 (s % 4) + b of the chunk at site parity s / 4.
+// the bits of one site of the pair
+__device__ __forceinline__ uint32_t ps_site_bits(uint32_t site) { return 0x0F0F0F0Fu << (4u * (site & 1u)); }
+// cell (0..15) of a plane bit
+__device__ __forceinline__ uint32_t ps_bit_cell(uint32_t p) { return ((p & 3u) << 2) | (p >> 3); }
+// the bits (both sites) of the cells k < nvalid
+__device__ __forceinline__ uint32_t ps_valid_word(uint32_t nvalid)
 {
-    return (~ps_noncand_word(A, cshift) >> (16u * (site & 1u))) & 0xFFFFu;
+    if (nvalid >= 16u) return 0xFFFFFFFFu;
+    uint32_t m = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < 16u; k++)
+        if (k < nvalid) m |= 0x11u << (8u * (k & 3u) + (k >> 2));
+    return m;
+}
+
+// plane-word mask of the cells of one site that may hold an event (candidates: no bit of n at or above cshift)
+__device__ __forceinline__ uint32_t ps_cand_word(const ps_u4 &A, uint32_t site, uint32_t cshift)
+{
+    return ~ps_noncand_word(A, cshift) & ps_site_bits(site);
 }
 
 // Queue-free evaluation of one candidate cell from its two blocks: the allele it mutates to (0 = none) and whether it
@@ -150,9 +166,9 @@ __global__ void __launch_bounds__(1024) core_sweep_inline_kernel(core_sweep_args
             uint32_t hm = 0;
             if (events) {
                 const ps_u4 A = ps_philox_l1a(site >> 1, c, a.gen, a.k0, a.k1), B = ps_philox_l1b(site >> 2, c, a.gen, a.k0, a.k1);
-                uint32_t cm = ps_cand16(A, site, pl.cshift);
+                uint32_t cm = ps_cand_word(A, site, pl.cshift);
                 while (cm) {
-                    const uint32_t k = __builtin_ctz(cm);
+                    const uint32_t k = ps_bit_cell(__builtin_ctz(cm));
                     cm &= cm - 1u;
                     const uint32_t i = c * 16u + k;
                     if (i >= a.N) continue;
@@ -239,16 +255,19 @@ __device__ __forceinline__ uint32_t ps_wave_scan_incl(uint32_t x)
     return x;
 }
 
-// Event words of a row pair: bit k + 16 * (row & 1) set iff the symbol of the lane's cell k can hold an event, i.e.
-// s < 3k + R =: nE.  For the plans the queued sweeps take (cshift <= 1: nE <= 8) that is n <= 1 and the 3-bit number
-// (plane 0, plane 5, plane 4) below nE -- ONE v_bitop3_b32 whose truth table is the constant (1 << nE) - 1 in the order
-// (P0, P5, P4) = (a, b, c), picked by a wave-uniform switch.
-__device__ __forceinline__ uint32_t ps_event_word(uint32_t p0, uint32_t p1, uint32_t p2, uint32_t p3, uint32_t p4, uint32_t p5,
-                                                 uint32_t nE, uint32_t vm)
+// Class words of a row pair for the plans the queued sweeps take (k <= 1, 3k + R =: nE <= 8): every symbol that can
+// hold an event has n <= 1, so the class of a cell is a function of the 3-bit number s3 = (plane 0, plane 5, plane 4):
+//   ev  = s3 < nE  -- ONE v_bitop3_b32 whose truth table is the constant (1 << nE) - 1 in the order (P0, P5, P4) = (a, b, c),
+//                     picked by a wave-uniform switch (a truth table is an immediate)
+//   dec = s3 < 3k  -- k = 1: plane 0 clear and planes 4, 5 not both set; the allele index is then (plane 5, plane 4)
+//   res = ev & ~dec
+struct ps_class_words { uint32_t dec, res; };
+__device__ __forceinline__ ps_class_words ps_classes(uint32_t p0, uint32_t p1, uint32_t p2, uint32_t p3, uint32_t p4, uint32_t p5,
+                                                     uint32_t k, uint32_t nE, uint32_t vm)
 {
     const uint32_t c1 = __builtin_amdgcn_bitop3_b32(p1, p2, p3, 0x01) & vm;       // ~(p1 | p2 | p3): n <= 1
     // bitop3 truth table: bit (a << 2 | b << 1 | c) of the immediate is the result for inputs (a, b, c); with a = P0,
-    // b = P5, c = P4 that index is the low three bits of the symbol
+    // b = P5, c = P4 that index is s3
     uint32_t lt;
     switch (nE) {
     case 1: lt = __builtin_amdgcn_bitop3_b32(p0, p5, p4, 0x01); break;
@@ -260,18 +279,56 @@ __device__ __forceinline__ uint32_t ps_event_word(uint32_t p0, uint32_t p1, uint
     case 7: lt = __builtin_amdgcn_bitop3_b32(p0, p5, p4, 0x7F); break;
     default: lt = 0xFFFFFFFFu; break;
     }
-    return c1 & lt;
+    ps_class_words o;
+    o.dec = k ? c1 & __builtin_amdgcn_bitop3_b32(p0, p5, p4, 0x07) : 0u;
+    o.res = c1 & lt & ~o.dec;
+    return o;
 }
 
-// Candidate push (phase 2 of the wave and window sweeps).  w0 / w1 are the event words of the batch's row pairs (bit
-// k + 16 * (row & 1) = cell k of the lane: the plane layout itself).  A lane counts its events, ONE prefix sum over the
-// wave gives every lane its own stretch of the queue, and the lane writes its entries there in a loop of its own, each
-// with the low three bits of its symbol (planes 4, 5 and 0 at the entry's bit position): nothing else of level 1 is needed
-// later.  Nothing is written when the batch does not fit (the caller redoes it queue-free).
-// Entry (15 bits): bit position p (0-31) | row pair << 5 | lane << 6 | (plane 4, plane 5, plane 0) << 12; returns the
-// wave-uniform number of entries of the batch.
-__device__ __forceinline__ uint32_t ps_push_scan(uint32_t w0, uint32_t w1, const ps_u4 &A0, const ps_u4 &A1, const ps_u4 &B,
-                                                 uint16_t *q, uint32_t lane, uint32_t qcap)
+// Symbol-decided mutations in registers.  dec / p4 / p5 are plane words of one row pair (p4, p5 already masked by dec):
+// for the dword of cells 4j .. 4j + 3 at site parity h the three flags of a cell sit at bit s = j + 4h of its byte in
+// each word.  Five merged words put (p4, p5, dec) of a slot side by side -- value 4 + allele index in the mutated bytes,
+// 0 elsewhere -- so that per dword one shift and one mask give a byte-wise selector, two v_perm_b32 look up the allele
+// and the byte mask, and one v_bfi_b32 writes the alleles into the child dword: no per-cell work, no queue.
+struct ps_apply_words { uint32_t y0, y1, ya, yb, yc; };
+__device__ __forceinline__ uint32_t ps_bfi(uint32_t m, uint32_t a, uint32_t b) { return (a & m) | (b & ~m); }
+__device__ __forceinline__ ps_apply_words ps_apply_prepare(uint32_t dec, uint32_t p4, uint32_t p5)
+{
+    const uint32_t r1 = p5 >> 1, r2 = p4 >> 2, l1 = p5 << 1, l2 = dec << 2;
+    ps_apply_words o;
+    o.y0 = ps_bfi(0x01010101u, p4, ps_bfi(0x02020202u, l1, l2));      // slot 0: bits 0-2
+    o.y1 = ps_bfi(0x02020202u, p4, ps_bfi(0x04040404u, l1, l2));      // slot 1: bits 1-3
+    o.ya = ps_bfi(0x09090909u, r2, ps_bfi(0x12121212u, r1, dec));     // slots 2, 5: bits 0-2, 3-5
+    o.yb = ps_bfi(0x12121212u, r2, ps_bfi(0x24242424u, r1, dec));     // slots 3, 6: bits 1-3, 4-6
+    o.yc = ps_bfi(0x24242424u, r2, ps_bfi(0x48484848u, r1, dec));     // slots 4, 7: bits 2-4, 5-7
+    return o;
+}
+template <uint32_t SLOT>
+__device__ __forceinline__ uint32_t ps_apply_dword(const ps_apply_words &y, uint32_t d)
+{
+    constexpr uint32_t sh = SLOT == 0u ? 0u : SLOT == 1u ? 1u : SLOT == 2u ? 0u : SLOT == 3u ? 1u : SLOT == 4u ? 2u : SLOT == 5u ? 3u : SLOT == 6u ? 4u : 5u;
+    const uint32_t src = SLOT == 0u ? y.y0 : SLOT == 1u ? y.y1 : (SLOT == 2u || SLOT == 5u) ? y.ya : (SLOT == 3u || SLOT == 6u) ? y.yb : y.yc;
+    const uint32_t f = (src >> sh) & 0x07070707u;                          // 4 + allele index in the mutated bytes, else 0
+    const uint32_t allele = __builtin_amdgcn_perm(0x00080402u, 0u, f);     // selector 4, 5, 6 -> 2, 4, 8; 0 -> 0
+    const uint32_t mask = __builtin_amdgcn_perm(0x00FFFFFFu, 0u, f);       // ... -> 0xFF; 0 -> 0
+    return ps_bfi(mask, allele, d);
+}
+// all four dwords of the child row at site parity H of the pair
+template <uint32_t H>
+__device__ __forceinline__ void ps_apply_row(const ps_apply_words &y, uint4 &d)
+{
+    d.x = ps_apply_dword<4u * H + 0u>(y, d.x);
+    d.y = ps_apply_dword<4u * H + 1u>(y, d.y);
+    d.z = ps_apply_dword<4u * H + 2u>(y, d.z);
+    d.w = ps_apply_dword<4u * H + 3u>(y, d.w);
+}
+
+// Residual push (phase 2 of the wave and window sweeps).  w0 / w1 are the residual words of the batch's row pairs (plane
+// layout).  A lane counts its residual cells, ONE prefix sum over the wave gives every lane its own stretch of the queue,
+// and the lane writes its entries there in a loop of its own.  Nothing is written when the batch does not fit (the caller
+// redoes it queue-free).  Entry (12 bits): bit position p (0-31) | row pair << 5 | lane << 6; returns the wave-uniform
+// number of entries of the batch.
+__device__ __forceinline__ uint32_t ps_push_scan(uint32_t w0, uint32_t w1, uint16_t *q, uint32_t lane, uint32_t qcap)
 {
     const uint32_t c0 = (uint32_t)__popc(w0), c = c0 + (uint32_t)__popc(w1);
     const uint32_t incl = ps_wave_scan_incl(c);
@@ -281,18 +338,17 @@ __device__ __forceinline__ uint32_t ps_push_scan(uint32_t w0, uint32_t w1, const
         // i.e. no register copy per trip)
         uint16_t *qp = q + (incl - c) - 1, *qp1 = qp + c0;
         const uint32_t tag = lane << 6;
-        for (uint32_t m = w0; m; m &= m - 1u) {
-            const uint32_t p = (uint32_t)__builtin_ctz(m);
-            const uint32_t sym = ((B.x >> p) & 1u) | (((B.z >> p) & 1u) << 1) | (((A0.x >> p) & 1u) << 2);
-            *++qp = (uint16_t)(tag | p | (sym << 12));
-        }
-        for (uint32_t m = w1; m; m &= m - 1u) {
-            const uint32_t p = (uint32_t)__builtin_ctz(m);
-            const uint32_t sym = ((B.y >> p) & 1u) | (((B.w >> p) & 1u) << 1) | (((A1.x >> p) & 1u) << 2);
-            *++qp1 = (uint16_t)(tag | 32u | p | (sym << 12));
-        }
+        for (uint32_t m = w0; m; m &= m - 1u) *++qp = (uint16_t)(tag | (uint32_t)__builtin_ctz(m));
+        for (uint32_t m = w1; m; m &= m - 1u) *++qp1 = (uint16_t)(tag | 32u | (uint32_t)__builtin_ctz(m));
     }
     return qn;
+}
+// ... and the cell such an entry names: (cell of the row | row << 10), cell = 16 * lane + 4 (s % 4) + b for p = 8b + s,
+// row = 2 * pair + s / 4
+__device__ __forceinline__ uint32_t ps_entry_cell(uint32_t ent)
+{
+    const uint32_t cell = ((ent & 3u) << 2) | ((ent >> 3) & 3u), row = ((ent >> 2) & 1u) | ((ent >> 4) & 2u);
+    return (row << 10) | ((ent >> 2) & 0x3F0u) | cell;
 }
 
 // four zero-extended bytes -> one dword (two v_perm + v_or; the compiler's own form masks every byte again)
@@ -342,8 +398,7 @@ __global__ void __launch_bounds__(256, PS_WAVE_LB) core_sweep_wave_kernel(core_s
     const uint32_t i0 = lane * 16u;
     const uint32_t ld_off = has_chunk ? i0 : 0u;      // lanes past the row load its first bytes; nothing of theirs is stored
     const uint32_t nvalid = (i0 >= a.N) ? 0u : min(16u, a.N - i0);
-    const uint32_t vm = ((1u << nvalid) - 1u) * 0x10001u;     // the lane's cells that exist, in both halves of a plane word
-    const uint32_t lut = pl.lut8;
+    const uint32_t vm = ps_valid_word(nvalid);        // the lane's cells that exist, at both sites of a plane word
 
     uint32_t pidx[16];
     if (DO_GATHER) {
@@ -395,16 +450,22 @@ __global__ void __launch_bounds__(256, PS_WAVE_LB) core_sweep_wave_kernel(core_s
 
         // Phase 1: the symbol planes of the batch (three Philox calls per lane for 4 x 16 cells), then, row by row, the child
         // bytes.  (Interleaving the rows' gathers needs more registers than 8 waves per SIMD leave.)
-        uint32_t wl[2] = { 0u, 0u };      // the event words of ps_push_scan, one per row pair
-        ps_u4 A0 = { 0u, 0u, 0u, 0u }, A1 = A0, B = A0;
+        uint32_t wl[2] = { 0u, 0u };      // the residual words of ps_push_scan, one per row pair
+        ps_apply_words y[2] = {};
         if (events) {
-            A0 = ps_philox_l1a(2u * sg, lane, a.gen, a.k0, a.k1);
-            A1 = ps_philox_l1a(2u * sg + 1u, lane, a.gen, a.k0, a.k1);
-            B = ps_philox_l1b(sg, lane, a.gen, a.k0, a.k1);
-            wl[0] = ps_event_word(A0.x, A0.y, A0.z, A0.w, B.x, B.z, nE, vm);
-            wl[1] = ps_event_word(A1.x, A1.y, A1.z, A1.w, B.y, B.w, nE, vm);
+            const ps_u4 A0 = ps_philox_l1a(2u * sg, lane, a.gen, a.k0, a.k1);
+            const ps_u4 A1 = ps_philox_l1a(2u * sg + 1u, lane, a.gen, a.k0, a.k1);
+            const ps_u4 B = ps_philox_l1b(sg, lane, a.gen, a.k0, a.k1);
+            const ps_class_words c0 = ps_classes(A0.x, A0.y, A0.z, A0.w, B.x, B.z, pl.k, nE, vm);
+            const ps_class_words c1 = ps_classes(A1.x, A1.y, A1.z, A1.w, B.y, B.w, pl.k, nE, vm);
+            wl[0] = c0.res;
+            wl[1] = c1.res;
+            if (DO_MUT) {
+                y[0] = ps_apply_prepare(c0.dec, B.x & c0.dec, B.z & c0.dec);
+                y[1] = ps_apply_prepare(c1.dec, B.y & c1.dec, B.w & c1.dec);
+            }
         }
-        PS_T(2);   // level-1 Philox + detection
+        PS_T(2);   // level-1 Philox + class words
 #pragma unroll
         for (uint32_t rr = 0; rr < PS_ROWS; rr++) {
             uint8_t *row = rowbuf + rr * 1024u;
@@ -415,48 +476,31 @@ __global__ void __launch_bounds__(256, PS_WAVE_LB) core_sweep_wave_kernel(core_s
                 for (int j = 0; j < 4; j++)
                     w[j] = ps_pack4(row[pidx[4 * j]], row[pidx[4 * j + 1]], row[pidx[4 * j + 2]], row[pidx[4 * j + 3]]);
                 d = make_uint4(w[0], w[1], w[2], w[3]);
-                // the LDS row becomes the child row; every gather read precedes this store
-                ps_wave_sync();
             }
+            // the mutations the symbols decide, in registers (population.rs:511-540)
+            if (events && DO_MUT) {
+                if (rr & 1u) ps_apply_row<1u>(y[rr >> 1], d);
+                else ps_apply_row<0u>(y[rr >> 1], d);
+            }
+            // the LDS row becomes the child row; every gather read precedes this store
+            if (DO_GATHER) ps_wave_sync();
             if (DO_GATHER || events) *(uint4 *)(row + i0) = d;
             __builtin_amdgcn_sched_barrier(0);      // keep the rows apart (see above)
         }
-        PS_T(1);   // gather
+        PS_T(1);   // gather + symbol-decided mutations
         const uint32_t qcap = a.qcap_limit ? min(a.qcap, a.qcap_limit) : a.qcap;
-        uint32_t qn = 0;        // wave-uniform number of queued candidate cells
-        // Phase 2: every event cell of the batch into the wave queue (one prefix sum, then lane-private writes)
-        if (events) qn = ps_push_scan(wl[0], wl[1], A0, A1, B, q, lane, qcap);
+        uint32_t qn = 0;        // wave-uniform number of queued residual cells
+        // Phase 2: every residual cell of the batch into the wave queue (one prefix sum, then lane-private writes)
+        if (events) qn = ps_push_scan(wl[0], wl[1], q, lane, qcap);
         PS_T(3);   // queue push
         ps_wave_sync();
-
-        bool redo = events && qn > qcap;       // wave-uniform
-        uint32_t n2 = 0;
-        if (events && !redo) {
-            // dense pass: an entry whose symbol decides an allele gets it; the residual cells are compacted in place
-            // to the front of the queue (the write index never passes the read index) as (cell | row << 10), which is
-            // also the cell's byte address in rowbuf
-            for (uint32_t base = 0; base < qn; base += 64u) {
-                const uint32_t e = base + lane;
-                const bool valid = e < qn;
-                const uint32_t ent = valid ? (uint32_t)q[e] : 0u;
-                const uint32_t addr = ((ent & 0x30u) << 6) | ((ent >> 2) & 0x3F0u) | (ent & 15u);
-                const uint32_t code = valid ? (lut >> ((ent >> 10) & 28u)) & 15u : 0u;      // 4 bits per symbol < 8
-                if (DO_MUT && (code & 14u)) rowbuf[addr] = (uint8_t)code;
-                const bool amb = (code & 1u) != 0u;
-                const uint64_t bal = __builtin_amdgcn_ballot_w64(amb);
-                if (amb) q[n2 + ps_lane_prefix(bal)] = (uint16_t)addr;
-                n2 += (uint32_t)__popcll(bal);
-            }
-            ps_wave_sync();
-            // (HR parks a second 16-bit word per residual cell in the queue's upper half, mirrored: entry e at qcap - 1 - e)
-            if (DO_HR && 2u * n2 > qcap) redo = true;
-        }
-        PS_T(4);   // dense symbol classification
+        // (HR parks a second 16-bit word per residual cell in the queue's upper half, mirrored: entry e at qcap - 1 - e)
+        const bool redo = events && (qn > qcap || (DO_HR && 2u * qn > qcap));       // wave-uniform
         // Queue overflow (the host sizes the queue for mean + 10 sigma of the entry count, so this is a
         // once-in-the-age-of-the-universe event at the rates it admits -- and every batch under the test hook
         // `sweep_queue_cap`): nothing is dropped; the batch is redone by the queue-free method of
-        // core_sweep_inline_kernel, every candidate handled by its owner lane (cells the dense pass has already
-        // mutated get the same allele again).
+        // core_sweep_inline_kernel, every candidate handled by its owner lane (the cells whose symbol decides an allele
+        // have it already and get it again).
         if (redo) {
 #pragma unroll 1
             for (uint32_t rr = 0; rr < PS_ROWS; rr++) {
@@ -464,10 +508,10 @@ __global__ void __launch_bounds__(256, PS_WAVE_LB) core_sweep_wave_kernel(core_s
                 const uint32_t site = 4u * sg + rr;
                 const ps_u4 Ar = ps_philox_l1a(site >> 1, lane, a.gen, a.k0, a.k1);
                 const ps_u4 Br = ps_philox_l1b(sg, lane, a.gen, a.k0, a.k1);
-                uint32_t cmr = ps_cand16(Ar, site, pl.cshift) & vm;
+                uint32_t cmr = ps_cand_word(Ar, site, pl.cshift) & vm;
                 uint32_t hm = 0;
                 while (cmr) {
-                    const uint32_t k = __builtin_ctz(cmr), cellidx = i0 + k;
+                    const uint32_t k = ps_bit_cell(__builtin_ctz(cmr)), cellidx = i0 + k;
                     cmr &= cmr - 1u;
                     uint32_t l2y = 0;
                     const ps_cell cell = ps_cell_events(Ar, Br, site, cellidx, a.gen, a.k0, a.k1, pl, l2y);
@@ -497,10 +541,10 @@ __global__ void __launch_bounds__(256, PS_WAVE_LB) core_sweep_wave_kernel(core_s
         } else if (events) {
             // exact pass over the residual cells: level-2 Philox, 32-bit thresholds
             uint16_t *qh = q + qcap - 1u;       // HR: donor | 0x8000, later the donor's allele | 0x8000, of entry e at qh[-e]
-            for (uint32_t base = 0; base < n2; base += 64u) {
+            for (uint32_t base = 0; base < qn; base += 64u) {
                 const uint32_t e = base + lane;
-                if (e < n2) {
-                    const uint32_t ent = q[e];
+                if (e < qn) {
+                    const uint32_t ent = ps_entry_cell(q[e]);      // cell | row << 10 = the cell's byte address in rowbuf
                     const uint32_t cellidx = ent & 1023u, rr = ent >> 10;
                     const ps_u4 l2 = ps_philox(4u * sg + rr, cellidx, a.gen, PS_STREAM_CORE_L2, a.k0, a.k1);
                     const ps_cell cell = ps_classify(l2.x, pl);
@@ -518,19 +562,19 @@ __global__ void __launch_bounds__(256, PS_WAVE_LB) core_sweep_wave_kernel(core_s
             }
             if (DO_HR) {
                 ps_wave_sync();   // the LDS rows are now the post-mutation snapshot (population.rs:693-695)
-                for (uint32_t base = 0; base < n2; base += 64u) {
+                for (uint32_t base = 0; base < qn; base += 64u) {
                     const uint32_t e = base + lane;
-                    if (e < n2) {
+                    if (e < qn) {
                         const uint32_t h = *(qh - e);
-                        if (h >> 15) *(qh - e) = (uint16_t)((uint32_t)rowbuf[((uint32_t)q[e] & 3072u) | (h & 1023u)] | 0x8000u);
+                        if (h >> 15) *(qh - e) = (uint16_t)((uint32_t)rowbuf[(ps_entry_cell(q[e]) & 3072u) | (h & 1023u)] | 0x8000u);
                     }
                 }
                 ps_wave_sync();   // all donor reads are done; now apply the copies
-                for (uint32_t base = 0; base < n2; base += 64u) {
+                for (uint32_t base = 0; base < qn; base += 64u) {
                     const uint32_t e = base + lane;
-                    if (e < n2) {
+                    if (e < qn) {
                         const uint32_t h = *(qh - e);
-                        if (h >> 15) rowbuf[q[e]] = (uint8_t)(h & 0xFFu);
+                        if (h >> 15) rowbuf[ps_entry_cell(q[e])] = (uint8_t)(h & 0xFFu);
                     }
                 }
             }
@@ -596,8 +640,9 @@ __global__ void __launch_bounds__(256, PS_WAVE_LB) core_sweep_wave_kernel(core_s
 #define PS_WINDOW_NT_LOADS 0   // window sweep: 1 = the window loads nt as well; 0 = default cache policy (neighbouring windows share lines, HR donors read the rows), stores nt: 4.107 vs 4.142 ms
 #endif
 #define PS_WSTRIDE (PS_WCAP + 16u)   // row buffer stride in LDS: 16 zero bytes behind the window (what cells past N gather)
-// LDS of one wave: 4 row buffers and the queue (a.qcap 16-bit entries)
-__host__ __device__ constexpr uint32_t ps_window_lds(uint32_t qcap) { return PS_BATCH_ROWS * PS_WSTRIDE + ps_queue_bytes(qcap); }
+// LDS of one wave: 4 row buffers, the queue (a.qcap 16-bit entries) and the batch's HR list (64 x (donor, cell))
+#define PS_WHR 64u
+__host__ __device__ constexpr uint32_t ps_window_lds(uint32_t qcap) { return PS_BATCH_ROWS * PS_WSTRIDE + ps_queue_bytes(qcap) + PS_WHR * 6u; }
 
 // post-mutation, pre-recombination value of cell (site row, individual donor), from the old generation
 __device__ __forceinline__ uint32_t ps_donor_value(const core_sweep_args &a, const ps_core_plan &pl, const uint8_t *old_row,
@@ -637,6 +682,8 @@ __global__ void __launch_bounds__(256, PS_WLB) core_sweep_window_kernel(core_swe
     // (1024 bytes) overwrites its start once the gather has read it -- and the candidate queue
     uint8_t *rowbuf = lds + wave * ps_window_lds(a.qcap);
     uint16_t *q = (uint16_t *)(rowbuf + PS_ROWS * PS_WSTRIDE);
+    uint32_t *hr_d = (uint32_t *)(rowbuf + PS_ROWS * PS_WSTRIDE + ps_queue_bytes(a.qcap));     // HR list: donors ...
+    uint16_t *hr_e = (uint16_t *)(hr_d + PS_WHR);                                              // ... and cells (cell | row << 10)
     if (lane < PS_ROWS) *(uint4 *)(rowbuf + lane * PS_WSTRIDE + PS_WCAP) = make_uint4(0, 0, 0, 0);     // the zero bytes (never rewritten)
     const ps_core_plan pl = a.plan;
     // the wave's segment, fixed for the launch
@@ -664,8 +711,7 @@ __global__ void __launch_bounds__(256, PS_WLB) core_sweep_window_kernel(core_swe
     const bool has_chunk = chunk < a.cpr;
     const uint32_t i0 = lane * 16u, c0 = c_first + i0;      // cell offset inside the segment / global index of the first cell
     const uint32_t nvalid = (c0 >= a.N) ? 0u : min(16u, a.N - c0);
-    const uint32_t vm = ((1u << nvalid) - 1u) * 0x10001u;   // the lane's cells that exist, in both halves of a plane word
-    const uint32_t lut = pl.lut8;
+    const uint32_t vm = ps_valid_word(nvalid);              // the lane's cells that exist, at both sites of a plane word
     const uint32_t nE = 3u * pl.k + pl.R;                   // symbols below nE can hold an event (<= 8 here)
     // the parents' window [w_lo, w_hi] of the parent row, staged from its 16-byte aligned start
     const uint32_t w_lo = __builtin_amdgcn_readfirstlane(a.idx[c_first]) & ~15u;
@@ -711,11 +757,21 @@ __global__ void __launch_bounds__(256, PS_WLB) core_sweep_window_kernel(core_swe
             if (ld1) ps_dma16(src + 1024u + i0, rowbuf + rr * PS_WSTRIDE + 1024u, NT && PS_WINDOW_NT_LOADS);
         }
         // the symbol planes of the batch while the windows are in flight (see the wave sweep)
-        const ps_u4 A0 = ps_philox_l1a(2u * sg, chunk, a.gen, a.k0, a.k1);
-        const ps_u4 A1 = ps_philox_l1a(2u * sg + 1u, chunk, a.gen, a.k0, a.k1);
-        const ps_u4 B = ps_philox_l1b(sg, chunk, a.gen, a.k0, a.k1);
-        const uint32_t wl0 = ps_event_word(A0.x, A0.y, A0.z, A0.w, B.x, B.z, nE, vm);
-        const uint32_t wl1 = ps_event_word(A1.x, A1.y, A1.z, A1.w, B.y, B.w, nE, vm);
+        uint32_t wl0, wl1;
+        ps_apply_words y[2] = {};
+        {
+            const ps_u4 A0 = ps_philox_l1a(2u * sg, chunk, a.gen, a.k0, a.k1);
+            const ps_u4 A1 = ps_philox_l1a(2u * sg + 1u, chunk, a.gen, a.k0, a.k1);
+            const ps_u4 B = ps_philox_l1b(sg, chunk, a.gen, a.k0, a.k1);
+            const ps_class_words c0 = ps_classes(A0.x, A0.y, A0.z, A0.w, B.x, B.z, pl.k, nE, vm);
+            const ps_class_words c1 = ps_classes(A1.x, A1.y, A1.z, A1.w, B.y, B.w, pl.k, nE, vm);
+            wl0 = c0.res;
+            wl1 = c1.res;
+            if (DO_MUT) {
+                y[0] = ps_apply_prepare(c0.dec, B.x & c0.dec, B.z & c0.dec);
+                y[1] = ps_apply_prepare(c1.dec, B.y & c1.dec, B.w & c1.dec);
+            }
+        }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // (the compiler does not track LDS-DMA)
         ps_wave_sync();
 #pragma unroll
@@ -736,13 +792,19 @@ __global__ void __launch_bounds__(256, PS_WLB) core_sweep_window_kernel(core_swe
                     w[j] = ps_pack4(bsel[0], bsel[1], bsel[2], bsel[3]);
                 }
             }
+            uint4 d = make_uint4(w[0], w[1], w[2], w[3]);
+            // the mutations the symbols decide, in registers (population.rs:511-540)
+            if (DO_MUT) {
+                if (rr & 1u) ps_apply_row<1u>(y[rr >> 1], d);
+                else ps_apply_row<0u>(y[rr >> 1], d);
+            }
             ps_wave_sync();                                     // the row buffer becomes the child row: every gather read precedes
-            *(uint4 *)(win + i0) = make_uint4(w[0], w[1], w[2], w[3]);
+            *(uint4 *)(win + i0) = d;
             __builtin_amdgcn_sched_barrier(0);      // keep the rows apart (see the wave sweep)
         }
         // the push of the wave sweep: one prefix sum and lane-private writes
         const uint32_t qcap = a.qcap_limit ? min(a.qcap, a.qcap_limit) : a.qcap;
-        const uint32_t qn = ps_push_scan(wl0, wl1, A0, A1, B, q, lane, qcap);
+        const uint32_t qn = ps_push_scan(wl0, wl1, q, lane, qcap);
         ps_wave_sync();
 
         if (qn > qcap) {
@@ -754,9 +816,9 @@ __global__ void __launch_bounds__(256, PS_WLB) core_sweep_window_kernel(core_swe
                 const uint8_t *old_row = a.state + (size_t)lrow(rr) * a.pitch;
                 const ps_u4 Ar = ps_philox_l1a(site >> 1, chunk, a.gen, a.k0, a.k1);
                 const ps_u4 Br = ps_philox_l1b(sg, chunk, a.gen, a.k0, a.k1);
-                uint32_t cmr = ps_cand16(Ar, site, pl.cshift) & vm;
+                uint32_t cmr = ps_cand_word(Ar, site, pl.cshift) & vm;
                 while (cmr) {
-                    const uint32_t k = __builtin_ctz(cmr), cell = c0 + k;
+                    const uint32_t k = ps_bit_cell(__builtin_ctz(cmr)), cell = c0 + k;
                     cmr &= cmr - 1u;
                     uint32_t l2y = 0;
                     const ps_cell cl = ps_cell_events(Ar, Br, site, cell, a.gen, a.k0, a.k1, pl, l2y);
@@ -770,44 +832,53 @@ __global__ void __launch_bounds__(256, PS_WLB) core_sweep_window_kernel(core_swe
             }
             ps_wave_sync();
         } else {
-            // dense pass (the wave sweep's): symbol-decided mutations; the residual cells compacted in place
-            uint32_t n2 = 0;
+            // exact pass: level-2 Philox.  A cell that receives a donor allele recomputes the donor's post-mutation value
+            // from the old generation (two dependent global loads and the donor's own level-1 / level-2 words) -- not inside
+            // the pass, where a handful of lanes would run that code once per trip, but from a list the whole batch
+            // shares: ONE trip of it per batch (until 64 such cells have met).  Measured in round 3 against parking such
+            // cells in records and patching the stored rows a batch later: the patch stores and the later, cache-cold donor
+            // reads cost more than the latency they hide.
+            uint32_t nh = 0;        // wave-uniform length of the HR list
+            auto hr_flush = [&]() {
+                ps_wave_sync();
+                if (lane < nh) {
+                    const uint32_t ent = hr_e[lane], donor = hr_d[lane], rr = ent >> 10;
+                    const uint32_t rg = (uint32_t)min(max(lr0 + (int)rr, 0), (int)a.rows - 1);
+                    rowbuf[cell_addr(ent)] = (uint8_t)ps_donor_value(a, pl, a.state + (size_t)rg * a.pitch, 4u * sg + rr, donor, DO_MUT);
+                }
+                nh = 0;
+                ps_wave_sync();
+            };
             for (uint32_t base = 0; base < qn; base += 64u) {
                 const uint32_t e = base + lane;
-                const bool valid = e < qn;
-                const uint32_t ent = valid ? (uint32_t)q[e] : 0u;
-                const uint32_t e2 = ((ent & 0x30u) << 6) | ((ent >> 2) & 0x3F0u) | (ent & 15u);      // cell | row << 10
-                const uint32_t code = valid ? (lut >> ((ent >> 10) & 28u)) & 15u : 0u;      // 4 bits per symbol < 8
-                if (DO_MUT && (code & 14u)) rowbuf[cell_addr(e2)] = (uint8_t)code;
-                const bool amb = (code & 1u) != 0u;
-                const uint64_t bal = __builtin_amdgcn_ballot_w64(amb);
-                if (amb) q[n2 + ps_lane_prefix(bal)] = (uint16_t)e2;
-                n2 += (uint32_t)__popcll(bal);
-            }
-            ps_wave_sync();
-            // exact pass: level-2 Philox; a cell that receives a donor allele recomputes the donor's post-mutation value
-            // from the old generation (two dependent global loads and the donor's own level-1 / level-2 words).  Measured
-            // against parking such cells in records and patching the stored rows a batch later (donor loads in flight during
-            // the next batch's window DMA): 4.28 against 4.54 ms per 9.8e9 cells -- the patch stores and the later,
-            // cache-cold donor reads cost more than the latency they hide at 24 waves per CU.
-            for (uint32_t base = 0; base < n2; base += 64u) {
-                const uint32_t e = base + lane;
-                if (e < n2) {
-                    const uint32_t ent = q[e];
-                    const uint32_t rr = (ent >> 10) & 3u;
+                bool hr = false;
+                uint32_t ent = 0, donor = 0;
+                if (e < qn) {
+                    ent = ps_entry_cell(q[e]);      // cell | row << 10
+                    const uint32_t rr = ent >> 10;
                     const uint32_t cell = c_first + (ent & 1023u);
-                    const uint32_t site = 4u * sg + rr;
-                    const ps_u4 l2 = ps_philox(site, cell, a.gen, PS_STREAM_CORE_L2, a.k0, a.k1);
+                    const ps_u4 l2 = ps_philox(4u * sg + rr, cell, a.gen, PS_STREAM_CORE_L2, a.k0, a.k1);
                     const ps_cell cl = ps_classify(l2.x, pl);
                     if (DO_MUT && cl.mut) rowbuf[cell_addr(ent)] = (uint8_t)cl.mut;
                     if (DO_HR && cl.hr) {
-                        uint32_t donor = ps_mulhi(l2.y, a.N - 1u);
+                        hr = true;
+                        donor = ps_mulhi(l2.y, a.N - 1u);
                         donor += (donor >= cell) ? 1u : 0u;                      // population.rs:618
-                        const uint32_t rg = (uint32_t)min(max(lr0 + (int)rr, 0), (int)a.rows - 1);
-                        rowbuf[cell_addr(ent)] = (uint8_t)ps_donor_value(a, pl, a.state + (size_t)rg * a.pitch, site, donor, DO_MUT);
                     }
                 }
+                if (DO_HR) {
+                    const uint64_t bal = __builtin_amdgcn_ballot_w64(hr);
+                    const uint32_t cnt = (uint32_t)__popcll(bal);
+                    if (nh + cnt > PS_WHR) hr_flush();
+                    if (hr) {
+                        const uint32_t pos = nh + ps_lane_prefix(bal);
+                        hr_e[pos] = (uint16_t)ent;
+                        hr_d[pos] = donor;
+                    }
+                    nh += cnt;
+                }
             }
+            if (DO_HR && nh) hr_flush();
             ps_wave_sync();
         }
 
@@ -857,10 +928,10 @@ struct core_block_geom {
     uint32_t ovf_off;  // LDS byte offset of the workgroup's "a queue or an HR list was full" word (the last 4 bytes)
 };
 
-// 16-bit mask of the cells i0 .. i0+15 that exist (< N)
+// plane-word mask (both sites) of the cells i0 .. i0+15 that exist (< N)
 __device__ __forceinline__ uint32_t ps_valid_cells(uint32_t i0, uint32_t N)
 {
-    return i0 + 16u <= N ? 0xFFFFu : i0 >= N ? 0u : (1u << (N - i0)) - 1u;
+    return ps_valid_word(i0 >= N ? 0u : min(16u, N - i0));
 }
 
 template <uint32_t PS_SB, bool PRE, bool DO_GATHER, bool DO_MUT, bool DO_HR>
@@ -948,7 +1019,7 @@ __global__ void __launch_bounds__(1024) core_sweep_block_kernel(core_sweep_args 
             uint32_t s_base[PS_SB], s_site[PS_SB];   // wave-uniform per slot: LDS offset of the row, site
             uint32_t s_seg[PS_SB];                   // LDS offset of the slot's segment
             uint32_t cmv[PS_SB];                     // candidate masks of the batch (one push loop for all slots)
-            uint32_t tv[PS_SB], nv[PS_SB];           // planes 4 | 5 << 16 and plane 0 of the slot's 16 cells
+            uint32_t p4v[PS_SB], p5v[PS_SB], nv[PS_SB];   // plane words 4, 5 and 0 of the slot's site pair
             uint32_t qn = 0;
             uint32_t rr = rr0, sg = sg0;
             // FULL (wave-uniform): every slot of the batch exists and every lane of every segment holds a chunk
@@ -961,7 +1032,7 @@ __global__ void __launch_bounds__(1024) core_sweep_block_kernel(core_sweep_args 
                 s_seg[s] = rr * a.pitch + sg * 1024u;
                 s_site[s] = a.site_offset + r0 + rr;
                 cmv[s] = 0u;
-                tv[s] = nv[s] = 0u;
+                p4v[s] = p5v[s] = nv[s] = 0u;
                 if (FULL || item0 + s < items) {
                     // lanes past the row (chunk >= cpr) compute on the row's last chunk and only their LDS store is
                     // masked; their candidate mask is empty (no valid cells)
@@ -992,13 +1063,14 @@ __global__ void __launch_bounds__(1024) core_sweep_block_kernel(core_sweep_args 
                         if (has_chunk) *(uint4 *)(row + i0) = make_uint4(w[0], w[1], w[2], w[3]);
                     }
                     if (events) {
-                        const uint32_t vcell = FULL ? 0xFFFFu : PRE ? vperm_pre[s] : ps_valid_cells(i0, a.N);
-                        const uint32_t site = s_site[s], sh = 16u * (site & 1u);
+                        const uint32_t vcell = FULL ? 0xFFFFFFFFu : PRE ? vperm_pre[s] : ps_valid_cells(i0, a.N);
+                        const uint32_t site = s_site[s];
                         const ps_u4 A = ps_philox_l1a(site >> 1, chunk, a.gen, a.k0, a.k1);
                         const ps_u4 B = ps_philox_l1b(site >> 2, chunk, a.gen, a.k0, a.k1);
-                        cmv[s] = ps_cand16(A, site, pl.cshift) & vcell;
-                        nv[s] = (A.x >> sh) & 0xFFFFu;
-                        tv[s] = ((((site & 2u) ? B.y : B.x) >> sh) & 0xFFFFu) | ((((site & 2u) ? B.w : B.z) >> sh) << 16);
+                        cmv[s] = ps_cand_word(A, site, pl.cshift) & vcell;
+                        nv[s] = A.x;
+                        p4v[s] = (site & 2u) ? B.y : B.x;
+                        p5v[s] = (site & 2u) ? B.w : B.z;
                     }
                 }
                 if (++sg == g.segs) { sg = 0; rr++; }
@@ -1027,8 +1099,8 @@ __global__ void __launch_bounds__(1024) core_sweep_block_kernel(core_sweep_args 
                             const uint32_t p = __builtin_ctz(cmv[s]);
                             cmv[s] &= cmv[s] - 1u;
                             const uint32_t pos = qn + ps_lane_prefix(bal);
-                            const uint32_t sym = ((tv[s] >> p) & 1u) | (((tv[s] >> (16u + p)) & 1u) << 1) | (((nv[s] >> p) & 1u) << 2);
-                            if (pos < g.QW) q[pos] = (s_seg[s] + lane * 16u + p) | (sym << 20) | (s << 28);
+                            const uint32_t sym = ((p4v[s] >> p) & 1u) | (((p5v[s] >> p) & 1u) << 1) | (((nv[s] >> p) & 1u) << 2);
+                            if (pos < g.QW) q[pos] = (s_seg[s] + lane * 16u + ps_bit_cell(p)) | (sym << 20) | (s << 28);
                         }
                         qn += (uint32_t)__popcll(bal);
                     }
@@ -1142,9 +1214,9 @@ __global__ void __launch_bounds__(1024) core_sweep_block_kernel(core_sweep_args 
                     d[0] = cur.x; d[1] = cur.y; d[2] = cur.z; d[3] = cur.w;
                 }
                 const ps_u4 A = ps_philox_l1a(site >> 1, chunk, a.gen, a.k0, a.k1), B = ps_philox_l1b(site >> 2, chunk, a.gen, a.k0, a.k1);
-                uint32_t cm = ps_cand16(A, site, pl.cshift), hm = 0;
+                uint32_t cm = ps_cand_word(A, site, pl.cshift), hm = 0;
                 while (cm) {
-                    const uint32_t k = __builtin_ctz(cm);
+                    const uint32_t k = ps_bit_cell(__builtin_ctz(cm));
                     cm &= cm - 1u;
                     const uint32_t i = i0 + k;
                     if (i >= a.N) continue;

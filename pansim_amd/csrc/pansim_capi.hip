@@ -686,23 +686,25 @@ extern "C" int ps_set_rates(ps_population *p, int n_comp, const double *lam_mut,
 // ---------------------------------------------------------------------------
 // core sweep launch
 // ---------------------------------------------------------------------------
-// candidate queue of a wave of the wave / window sweeps: every cell of one batch (4 rows x `cells` cells) whose symbol
-// can hold an event (s < 3k + R), with 10 standard deviations to spare (a full queue only sends the batch to the
-// queue-free redo; with HR a batch whose residual cells fill more than half of it as well); 0 = the plan is not one
-// the queued sweeps take (cshift > 1: symbols of 8 and above hold events)
-static uint32_t sweep_queue_entries(const ps_core_plan &pl, uint32_t cells)
+// queue of a wave of the wave / window sweeps: every RESIDUAL cell of one batch (4 rows x `cells` cells, R / 64 of them),
+// with 10 standard deviations to spare (a full queue only sends the batch to the queue-free redo); `twice`: the wave
+// sweep with HR parks a second word per entry in the queue's upper half.  0 = the plan is not one the queued sweeps
+// take: they need every event symbol below 8 (cshift <= 1) and at most one symbol-decided allele class each (k <= 1: the
+// allele index is then planes 4-5 as they stand)
+static uint32_t sweep_queue_entries(const ps_core_plan &pl, uint32_t cells, bool twice)
 {
     if (!pl.has_events) return 16u;
-    if (pl.cshift > 1u) return 0u;
-    const double m = (double)PS_BATCH_ROWS * (double)cells * (double)(3u * pl.k + pl.R) / 64.0;
-    return ((uint32_t)std::ceil(m + 10.0 * std::sqrt(m) + 16.0) + 15u) & ~15u;
+    if (pl.cshift > 1u || pl.k > 1u) return 0u;
+    const double m = (double)PS_BATCH_ROWS * (double)cells * (double)pl.R / 64.0;
+    const uint32_t n = ((uint32_t)std::ceil(m + 10.0 * std::sqrt(m) + 16.0) + 15u) & ~15u;
+    return twice ? 2u * n : n;
 }
 
 template <bool GA, bool MU, bool HR>
 static int launch_core_sweep_wave(ps_population *p, core_sweep_args a, hipStream_t st)
 {
     const uint32_t block = 256u, wpb = block / 64u;
-    a.qcap = sweep_queue_entries(a.plan, std::min(1024u, (uint32_t)p->cfg.pop_size));
+    a.qcap = sweep_queue_entries(a.plan, std::min(1024u, (uint32_t)p->cfg.pop_size), HR);
     // (the two sets of chunk counters alternate among the launches that USE them: a launch zeroes the other set)
     a.launch_parity = (uint32_t)(p->sweep_launches++ & 1u);
     const uint32_t lds = wpb * ps_wave_lds(a.qcap);
@@ -717,14 +719,14 @@ static int launch_core_sweep_wave(ps_population *p, core_sweep_args a, hipStream
     return PS_OK;
 }
 
-// The wave-per-row sweep queues every cell of a batch whose symbol can hold an event; it is selected only when those
-// fit a queue (cshift <= 1: at most an eighth of the cells) that fits the LDS beside the rows.
+// The wave-per-row sweep applies the symbol-decided mutations in registers and queues the residual cells of a batch; it
+// is selected for the plans sweep_queue_entries admits, when the queue fits the LDS beside the rows.
 static bool wave_sweep_eligible(ps_population *p, bool mu, bool hr)
 {
     if (p->pitch > 1024 || p->force_block_sweep) return false;
     const ps_core_plan &pl = p->cplan;
     if (!pl.has_events || (!mu && !hr)) return true;
-    const uint32_t qe = sweep_queue_entries(pl, std::min(1024u, (uint32_t)p->cfg.pop_size));
+    const uint32_t qe = sweep_queue_entries(pl, std::min(1024u, (uint32_t)p->cfg.pop_size), hr);
     return qe != 0u && 4u * ps_wave_lds(qe) <= p->lds_limit;
 }
 
@@ -830,7 +832,7 @@ static int launch_core_sweep_block(ps_population *p, const core_sweep_args &a, c
 // window sweep (core_kernels.h): N > 1024, fused gather + mutate (+ HR), parents in ascending order, out of place
 static uint32_t window_sweep_lds(const ps_core_plan &pl)
 {
-    const uint32_t qe = sweep_queue_entries(pl, 1024u);
+    const uint32_t qe = sweep_queue_entries(pl, 1024u, false);
     return qe ? 4u * ps_window_lds(qe) : 0u;
 }
 
@@ -848,7 +850,7 @@ static int launch_core_sweep_window(ps_population *p, const core_sweep_args &a, 
     // first launch sets and that the first launch of the generation before cleared -- core_kernels.h).  They alternate the
     // counter sets like any two consecutive launches (a parity of their own among the launches that use them).
     core_sweep_args a0 = a, b = a;
-    a0.qcap = b.qcap = sweep_queue_entries(a.plan, 1024u);
+    a0.qcap = b.qcap = sweep_queue_entries(a.plan, 1024u, false);
     a0.launch_parity = (uint32_t)(p->window_launches++ & 1u);
     b.launch_parity = (uint32_t)(p->window_launches++ & 1u);
 #define PS_WLAUNCH(NT_)                                                                                                    \
@@ -3154,8 +3156,10 @@ static void sim_exchange_schedule(ps_sim *s)
     const char *e = getenv("PANSIM_EXCHANGE_BESIDE_SWEEP");
     const bool on = e && atoi(e) != 0 && s->acc->exchange != nullptr;
     s->acc->exchange_beside_sweep = on;
-    // (room for the exchange: a sixth of every CU, or -- PANSIM_SWEEP_FREE_CUS -- whole CUs the sweep's stream cannot use)
-    if (on && s->core->window_blocks_per_cu == 0 && s->core->free_cus_per_xcd == 0) s->core->window_blocks_per_cu = 6;
+    // A donor-sharded run has a longer chain between two sweeps (LDS-image pass, reduce, exchange, merge): the window sweep
+    // leaves it more of every CU -- 5 workgroups per CU instead of 6 (round 6, one rank of 8 at cfg4: the sweep 3.60 against
+    // 3.56 ms, the period 3.93 against 4.05 ms; profiles/r06_d_ab_cfg4_shard8.json)
+    if (s->acc->exchange != nullptr && s->core->window_blocks_per_cu == 0 && !getenv("PANSIM_WINDOW_BPC")) s->core->window_blocks_per_cu = 5;
 }
 
 extern "C" int ps_sim_set_exchange(ps_sim *s, ps_exchange_fn fn, void *ctx)

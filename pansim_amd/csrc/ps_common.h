@@ -63,12 +63,15 @@ PS_HD ps_u4 ps_philox(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32
 }
 
 // Level 1 of the core cell plan: a 6-bit SYMBOL per cell, bit-sliced.  Plane k (0..5) holds bit k of the
-// symbols; a plane word covers the 16 individuals of one chunk at two consecutive sites: bit (i & 15) + 16 * (site & 1).
+// symbols; a plane word covers the 16 individuals of one chunk at two consecutive sites, cell (i, site) at bit
+// ps_plane_pos = 8 * (i % 4) + (i / 4) % 4 + 4 * (site % 2): the four individuals 4j .. 4j + 3 -- one dword of a site row --
+// sit at the same bit of the four BYTES of the word, so that a shift and a mask turn plane bits into byte-lane flags.
 //   block A = Philox(site / 2, i / 16, gen, CORE_L1):  (x, y, z, w) = planes 0, 1, 2, 3 of the sites 2 * (site / 2) + {0, 1}
 //   block B = Philox(site / 4, i / 16, gen, CORE_L1B): x / y = plane 4 of the sites 4 * (site / 4) + {0, 1} / {2, 3},
 //                                                      z / w = plane 5 of the same
 // i.e. three Philox blocks per 4 sites x 16 individuals -- 6 bits per cell, every bit used once -- and a lane of the sweeps,
 // which owns 16 individuals of 4 consecutive sites per trip, computes exactly the blocks it consumes.
+PS_HD uint32_t ps_plane_pos(uint32_t ind, uint32_t site) { return 8u * (ind & 3u) + ((ind >> 2) & 3u) + 4u * (site & 1u); }
 PS_HD ps_u4 ps_philox_l1a(uint32_t site2, uint32_t chunk, uint32_t gen, uint32_t k0, uint32_t k1)
 {
     return ps_philox(site2, chunk, gen, PS_STREAM_CORE_L1, k0, k1);
@@ -116,12 +119,12 @@ PS_HD uint32_t ps_sym_code(uint32_t s, const ps_core_plan &pl)
 // the symbol of cell (site, individual) out of its two blocks
 PS_HD uint32_t ps_cell_nibble(const ps_u4 &A, uint32_t site, uint32_t ind)
 {
-    const uint32_t pos = (ind & 15u) + 16u * (site & 1u);
+    const uint32_t pos = ps_plane_pos(ind, site);
     return ((A.x >> pos) & 1u) | (((A.y >> pos) & 1u) << 1) | (((A.z >> pos) & 1u) << 2) | (((A.w >> pos) & 1u) << 3);
 }
 PS_HD uint32_t ps_cell_pair(const ps_u4 &B, uint32_t site, uint32_t ind)
 {
-    const uint32_t pos = (ind & 15u) + 16u * (site & 1u);
+    const uint32_t pos = ps_plane_pos(ind, site);
     const uint32_t p4 = (site & 2u) ? B.y : B.x, p5 = (site & 2u) ? B.w : B.z;
     return ((p4 >> pos) & 1u) | (((p5 >> pos) & 1u) << 1);
 }
