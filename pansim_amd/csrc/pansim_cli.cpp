@@ -1,6 +1,7 @@
 // pansim_cli.cpp -- the `pansim` executable: the reference's command line
 // (pansim/src/main.rs:17-152), validation (:195-247), generation loop (:429-528) and
 // output files (:321-331, :467-499, :531-553) driving libpansim_hip.so through its C ABI.
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -51,19 +52,69 @@ static const Flag EXT_FLAGS[] = {
     { "reference_seed_stream", "Draw the selection coefficients from the reference's own seeded stream (ChaCha12 StdRng, restated from the published algorithms of the rand / statrs crates, ziggurat tables recomputed: UNVERIFIED against a Pansim binary) instead of the build's Philox stream.", nullptr, false },
 };
 
-static void print_help()
+// clap 3's layout (the reference's own `pansim --help`, /root/reference/README.md:40-138): the options sorted by clap's
+// key in byte order (uppercase first; -h / -V by their letters), the help text behind a 12-space indent,
+// "[default: X]" appended as ordinary words, the whole filled greedily to 100 columns.
+static void print_wrapped(const std::string &text, size_t indent, size_t width)
 {
-    printf("pansim 0.1.0\nSamuel Horsfield shorsfield@ebi.ac.uk\nRuns Wright-Fisher simulation, simulating neutral core genome "
-           "evolution and two-speed accessory genome evolution.\n\nUSAGE:\n    pansim [OPTIONS]\n\nOPTIONS:\n");
-    for (const Flag &f : FLAGS) {
-        if (f.takes_value) printf("        --%s <%s>\n            %s [default: %s]\n\n", f.name, f.name, f.help, f.def);
-        else printf("        --%s\n            %s\n\n", f.name, f.help);
+    std::string line;
+    size_t i = 0;
+    while (i < text.size()) {
+        size_t j = text.find(' ', i);
+        if (j == std::string::npos) j = text.size();
+        const std::string word = text.substr(i, j - i);
+        i = j + 1;
+        if (!line.empty() && indent + line.size() + 1 + word.size() > width) {
+            printf("%*s%s\n", (int)indent, "", line.c_str());
+            line.clear();
+        }
+        if (!line.empty()) line += ' ';
+        line += word;
     }
-    printf("    -h, --help\n            Print help information\n\n    -V, --version\n            Print version information\n");
-    printf("\nMI355X OPTIONS (not in the reference):\n");
-    for (const Flag &f : EXT_FLAGS) {
-        if (f.takes_value) printf("        --%s <%s>\n            %s [default: %s]\n\n", f.name, f.name, f.help, f.def);
-        else printf("        --%s\n            %s\n\n", f.name, f.help);
+    if (!line.empty()) printf("%*s%s\n", (int)indent, "", line.c_str());
+}
+
+static void print_flag(const Flag &f, const char *short_name)
+{
+    if (short_name) printf("    -%s, --%s", short_name, f.name);
+    else printf("        --%s", f.name);
+    if (f.takes_value) printf(" <%s>", f.name);
+    printf("\n");
+    std::string text = f.help;
+    if (f.takes_value) text += std::string(" [default: ") + f.def + "]";
+    print_wrapped(text, 12, 100);
+}
+
+static void print_help(bool extensions)
+{
+    printf("pansim 0.1.0\nSamuel Horsfield shorsfield@ebi.ac.uk\n");
+    print_wrapped("Runs Wright-Fisher simulation, simulating neutral core genome evolution and two-speed accessory genome evolution.", 0, 100);
+    printf("\nUSAGE:\n    pansim [OPTIONS]\n\nOPTIONS:\n");
+    static const Flag HELP = { "help", "Print help information", nullptr, false }, VERSION = { "version", "Print version information", nullptr, false };
+    std::vector<std::pair<const Flag *, const char *>> all;
+    for (const Flag &f : FLAGS) all.push_back({ &f, nullptr });
+    all.push_back({ &HELP, "h" });
+    all.push_back({ &VERSION, "V" });
+    // (clap's sort key: the long name, or for an option with a short one that letter in lower case followed by '0' if it
+    // is a lower-case letter and '1' if not: "h0" lands behind genome_size_penalty, "v1" between threads and verbose)
+    auto key = [](const std::pair<const Flag *, const char *> &x) {
+        if (!x.second) return std::string(x.first->name);
+        const char c = x.second[0];
+        return std::string(1, (char)tolower(c)) + (islower(c) ? '0' : '1');
+    };
+    std::sort(all.begin(), all.end(), [&](const std::pair<const Flag *, const char *> &x, const std::pair<const Flag *, const char *> &y) { return key(x) < key(y); });
+    for (size_t k = 0; k < all.size(); k++) {
+        if (k) printf("\n");
+        print_flag(*all[k].first, all[k].second);
+    }
+    if (extensions) {
+        // (not part of the reference's --help: shown by --help-extensions only, so that --help stays the reference's text)
+        printf("\nMI355X OPTIONS (not in the reference):\n");
+        for (const Flag &f : EXT_FLAGS) {
+            print_flag(f, nullptr);
+            printf("\n");
+        }
+        printf("        --help-extensions\n            Print this help with the options above.\n");
     }
 }
 
@@ -159,7 +210,8 @@ int main(int argc, char **argv)
     }
     for (int i = 1; i < argc; i++) {
         std::string a = argv[i];
-        if (a == "-h" || a == "--help") { print_help(); return 0; }
+        if (a == "-h" || a == "--help") { print_help(false); return 0; }
+        if (a == "--help-extensions") { print_help(true); return 0; }
         if (a == "-V" || a == "--version") { printf("pansim 0.1.0\n"); return 0; }
         if (a.rfind("--", 0) != 0)
             die(2, "error: Found argument '" + a + "' which wasn't expected, or isn't valid in this context\n\nUSAGE:\n    pansim [OPTIONS]\n\nFor more information try --help");

@@ -34,9 +34,26 @@ def test_version_and_help(exe):
                           ("prop_genes2", "0.1"), ("prop_positive", "-0.1"), ("pos_lambda", "10.0"), ("neg_lambda", "10.0"),
                           ("seed", "0"), ("outpref", "distances"), ("threads", "1"), ("genome_size_penalty", "0.99"),
                           ("competition_strength", "0.0")):
-        assert "--%s <%s>" % (flag, flag) in r.stdout and "[default: %s]" % default in r.stdout
+        assert "--%s <%s>" % (flag, flag) in r.stdout and "[default: %s]" % default in " ".join(r.stdout.split())
     for switch in ("print_dist", "print_matrices", "print_selection", "verbose", "no_control_genome_size"):
         assert "--%s\n" % switch in r.stdout
+
+
+def test_help_is_the_reference_binarys_own_output_byte_for_byte(exe):
+    # The one golden text the reference holds: `pansim --help` of a real Pansim binary (clap 3), pasted into its README
+    # (/root/reference/README.md:40-138; extracted to tests/golden/help_usage.txt by tests/golden/make_help_usage.py).
+    # From `USAGE:` on the build prints exactly that: options in clap's order (byte order, uppercase first, -h / -V by their
+    # letters), help text and "[default: ...]" filled to 100 columns.  This check does not involve the oracle.
+    want = open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "help_usage.txt")).read()
+    for flag in ("--help", "-h"):
+        r = run(exe, flag)
+        assert r.returncode == 0 and r.stderr == ""
+        assert r.stdout[r.stdout.index("USAGE:"):] == want
+        assert r.stdout.startswith("pansim 0.1.0\nSamuel Horsfield shorsfield@ebi.ac.uk\nRuns Wright-Fisher simulation")   # main.rs:17-20
+        assert "--gpus" not in r.stdout and "MI355X" not in r.stdout
+    # the two flags the reference does not have are listed by --help-extensions only
+    r = run(exe, "--help-extensions")
+    assert r.returncode == 0 and want.rstrip("\n") in r.stdout and "--gpus <gpus>" in r.stdout and "--reference_seed_stream" in r.stdout
 
 
 def test_config1_as_written_is_the_reference_early_return(exe, tmp_path):
