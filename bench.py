@@ -197,6 +197,7 @@ class Ctx:
         self.torch, self.dist, self.world, self.rank, self.local_rank, self.backend = torch, dist, world, rank, local_rank, backend
         self.data_group = None                  # None: the default (gloo) group
         self.data_plane = "none (one rank)" if world == 1 else "gloo (host copies)"
+        self.rccl_ranks_seen = 0                # ranks that answered the probe collective of the nccl (= RCCL) group
         self.notes = []
 
     def probe_data_plane(self):
@@ -211,7 +212,10 @@ class Ctx:
             dist.all_reduce(t, group=g)
             o = torch.empty_like(t)
             dist.all_to_all_single(o, t, group=g)
+            ones = torch.ones(1, device="cuda")
+            dist.all_reduce(ones, group=g)
             torch.cuda.synchronize()
+            self.rccl_ranks_seen = int(round(float(ones.item())))
             want = self.world * (self.world + 1) / 2.0
             if abs(float(o[0].item()) - want) > 1e-6:
                 raise RuntimeError("probe all-reduce returned %r, expected %r" % (float(o[0].item()), want))
@@ -534,6 +538,38 @@ def sweep_roofline(r, with_traffic):
             "algorithmic_bytes_per_launch": r["bytes_per_launch"]}
 
 
+def measure_print_dist(ctx, kw, P, gens, warm=10):
+    """--print_dist as a workload (main.rs:502-519): after EVERY generation the run's P sampled distances of
+    both matrices and their mean / population sigma -- what turns the distance phase into a per-generation cost.  One
+    generation at a time, as the CLI does it; returns generations/s and the distance phase's share."""
+    import numpy as np
+    import pansim_amd as pa
+    sim = pa.Simulation(pa.make_params(seed=0, n_gen=gens + warm, max_distances=P, device=ctx.local_rank, print_dist=1, **kw))
+    for _ in range(warm):
+        sim.run(1)
+        sim.final_distances()
+    ctx.barrier()
+    t0 = time.perf_counter()
+    t_dist, per_gen = 0.0, []
+    for _ in range(gens):
+        sim.run(1)
+        t1 = time.perf_counter()
+        cd, ad = sim.final_distances()
+        per_gen.append((float(cd.mean()), float(cd.std()), float(ad.mean()), float(ad.std())))
+        t_dist += time.perf_counter() - t1
+    ctx.barrier()
+    dt = time.perf_counter() - t0
+    core_ms, acc_ms = sim.distance_timing()
+    form = sim.core_genome.last_pair_form()
+    sim.close()
+    return {"workload": "BASELINE configs[1] + --print_dist: --pop_size %d --core_size %d --pan_genes %d, P = %d sampled distances and their "
+                        "mean / sigma after every generation (main.rs:502-519)" % (kw["pop_size"], kw["core_size"], kw["pan_genes"], P),
+            "generations_per_s": gens / dt, "ms_per_generation": 1e3 * dt / gens, "steps": gens, "warmup": warm,
+            "distance_phase_ms_per_generation_host_clock": 1e3 * t_dist / gens,
+            "distance_kernel_ms_last_generation": {"core": core_ms, "accessory": acc_ms}, "pair_form": form,
+            "last_generation_mean_core_distance": per_gen[-1][0]}
+
+
 def host_half(r):
     host_n, host_wait, host_weights, host_draw = r["host"]
     return {"generations": host_n, "wait_for_device": host_wait / max(host_n, 1),
@@ -611,12 +647,15 @@ def launch(args, argv):
     import signal
     import subprocess
     import threading
-    budget = float(os.environ.get("PANSIM_BENCH_LAUNCH_TIMEOUT", "1500"))
+    # budgets that fit the driver's 1800-s limit for one bench.py call whatever happens: first attempt <= 700 s, the gloo
+    # retry <= 500 s, and inside a run each of the two north-star workloads under a 300-s watchdog (rank_main)
+    budgets = [float(os.environ.get("PANSIM_BENCH_LAUNCH_TIMEOUT", "700")), float(os.environ.get("PANSIM_BENCH_RETRY_TIMEOUT", "500"))]
     attempts = []
     backends = [os.environ.get("PANSIM_BENCH_BACKEND", "nccl")]
     if backends[0] != "gloo":
         backends.append("gloo")
-    for backend in backends:
+    for attempt_no, backend in enumerate(backends):
+        budget = budgets[min(attempt_no, 1)]
         env = dict(os.environ)
         env["PANSIM_BENCH_BACKEND"] = backend
         env["PANSIM_BENCH_LAUNCHED"] = "1"
@@ -665,7 +704,8 @@ def launch(args, argv):
             if rc != 0 or timed_out:
                 out["launcher"]["note"] += "; the ranks ended abnormally after this line was printed"
             print(json.dumps(out), flush=True)
-            return 0
+            # the line stands (a parser of stdout is served), the exit code tells CI that something behind it went wrong
+            return 0 if rc == 0 and not timed_out else 4
         print("bench.py launcher: %d ranks over %s produced no line (rc %s%s)" % (args.gpus, backend, rc, ", timed out" if timed_out else ""),
               file=sys.stderr, flush=True)
     return 1
@@ -674,7 +714,8 @@ def launch(args, argv):
 class Watchdog:
     """A rank that sits in a collective its peers never enter cannot be interrupted from Python.  Armed around the
     optional second workload: when it fires, rank 0 prints the line it was given (the contract line, already complete)
-    with the reason, and every rank leaves with os._exit(0) -- so a hang costs the extras, never the measurement."""
+    with the reason, and every rank leaves with os._exit(3) -- so a hang costs the extras, never the measurement, and the
+    non-zero exit code says that a workload was cut short (the launcher passes it on as its own 4)."""
 
     def __init__(self, seconds, rank, line_fn):
         import threading
@@ -687,7 +728,7 @@ class Watchdog:
             if self.rank == 0:
                 print(json.dumps(self.line_fn("timed out after %.0f s (watchdog)" % self.seconds)), flush=True)
         finally:
-            os._exit(0)
+            os._exit(3)
 
     def __enter__(self):
         self.t.start()
@@ -810,6 +851,8 @@ def rank_main(args):
             "exchange": r["exchange"],
             "roofline": roof,
             "data_plane": ctx.data_plane, "control_plane": "gloo" if world > 1 else "none (one rank)",
+            # ranks that answered the probe collective of the RCCL group (0: no such group -- one rank, or the gloo data plane)
+            "rccl_ranks_seen": ctx.rccl_ranks_seen,
         }
         if ctx.notes:
             out["notes"] = list(ctx.notes)
@@ -841,6 +884,10 @@ def rank_main(args):
                 others[name]["wall_s_incl_setup"] = time.perf_counter() - t0
             except Exception as e:      # (a configuration that does not fit this GPU must not void the contract line)
                 others[name] = {"error": str(e)[:300]}
+        try:
+            others["cfg2_print_dist"] = measure_print_dist(ctx, dict(CONFIGS["cfg2"][0]), CONFIGS["cfg2"][1], 100)
+        except Exception as e:
+            others["cfg2_print_dist"] = {"error": str(e)[:300]}
         out["other_configs"] = others
 
     # ---- the north-star's scaling workload at this world size: --pop_size 65536, 1.2 M core sites split over the ranks.
@@ -858,7 +905,7 @@ def rank_main(args):
             return dict(out, line="final", north_star_scaling={"error": why}, north_star_generations_per_s=None)
 
         ro, ns_chain = None, None
-        with Watchdog(float(os.environ.get("PANSIM_BENCH_NS_TIMEOUT", "600")), rank, on_timeout):
+        with Watchdog(float(os.environ.get("PANSIM_BENCH_NS_TIMEOUT", "300")), rank, on_timeout):
             err = None
             try:
                 if xchg is None:
@@ -885,10 +932,46 @@ def rank_main(args):
             out["north_star_exposed_non_sweep_ms"] = ns["exposed_non_sweep_ms"]
             out["north_star_collective_bytes_per_generation"] = ns["collective_bytes_per_generation"]
             out["north_star_exchange"] = ro["exchange"]["mode"]
+            out["north_star_exchange_world_size"] = getattr(xchg, "world", world) if xchg is not None else 0
             ns["collectives"] = ("per generation: HGT donors sharded over the ranks, the delta bit matrices (N x G bits) ORed with one "
                                  "all-to-all + one all-gather (bytes above: sent + received per rank); every rank draws the same "
                                  "parents; distance phase: one all-reduce of %d u32 numerators" % oP)
             out["north_star_scaling"] = ns
+
+        # ---- BASELINE configs[4] at this world size: --pop_size 8192 --max_distances 33554432, all 1.2 M core sites split over
+        # the ranks.  Distance phase as SURVEY 8(e) puts it: every rank counts the mismatches of ALL requested pairs over ITS
+        # sites (the all-pairs matrix-core form + lookup), ONE all-reduce (sum, u32) of the P = 2^25 partial counts -- 134 MB --
+        # over the data plane, the accessory Jaccard from the replicated matrix (population.rs:787-837).  Under its own
+        # watchdog; the line printed so far stands whatever happens here.
+        if rank == 0:
+            print(json.dumps(dict(out, line="contract + north_star_scaling (north_star_distance still running)")), flush=True)
+        dkw, dP, _e, _s, _w, dlabel = CONFIGS["cfg5pop"]
+        if os.environ.get("PANSIM_BENCH_NS_CORE_SIZE"):
+            dkw = dict(dkw, core_size=int(os.environ["PANSIM_BENCH_NS_CORE_SIZE"]))
+        if os.environ.get("PANSIM_BENCH_NS_PAIRS"):          # (smoke runs of the launch path)
+            dP = int(os.environ["PANSIM_BENCH_NS_PAIRS"])
+
+        def on_timeout_d(why):
+            return dict(out, line="final", north_star_distance={"error": why})
+
+        rd = None
+        with Watchdog(float(os.environ.get("PANSIM_BENCH_NS_TIMEOUT", "300")), rank, on_timeout_d):
+            err = None
+            try:
+                rd = measure(ctx, dict(dkw), dP, 5, 1, rank, world)
+            except Exception as e:
+                err = "%s: %s" % (type(e).__name__, str(e)[:300])
+            if err is not None and rank == 0:
+                out["north_star_distance"] = {"error": err}
+        if rank == 0 and rd is not None:
+            nd = summary(rd, "BASELINE configs[4] / north_star distance phase: --pop_size 8192 --max_distances %d, %d core sites split "
+                             "over %d ranks" % (dP, dkw["core_size"], world))
+            nd["n_gpus"] = world
+            nd["collective"] = "one all-reduce (sum, u32) of the %d partial Hamming numerators per distance phase over the data plane (%s)" % (dP, ctx.data_plane)
+            nd["collective_bytes_per_rank"] = 4 * dP
+            nd["pair_form"] = rd["pair_form"]
+            out["north_star_distance"] = nd
+            out["north_star_distance_mpairs_per_s"] = nd["mpairs_per_s"]
 
     if rank == 0:
         out["line"] = "final"

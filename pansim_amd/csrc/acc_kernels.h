@@ -508,7 +508,7 @@ __global__ void acc_fitness_kernel(const uint64_t *accI, const double *log1p_s, 
 // generation in ascending parent order, so the draws are counted per parent here (cnt zeroed by the
 // caller) and laid out by idx_scan_kernel / idx_fill_kernel: a counting sort.
 __global__ void __launch_bounds__(256) acc_draw_parents_kernel(const double *cum, double total, uint32_t N,
-                                                               uint32_t k0, uint32_t k1, uint32_t gen, uint32_t *cnt)
+                                                               uint32_t k0, uint32_t k1, uint32_t gen, uint32_t *cnt, uint32_t *draws)
 {
     const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= N) return;
@@ -518,6 +518,7 @@ __global__ void __launch_bounds__(256) acc_draw_parents_kernel(const double *cum
         const uint32_t mid = lo + ((hi - lo) >> 1);
         if (cum[mid] <= x) lo = mid + 1u; else hi = mid;
     }
+    draws[k] = lo;          // (draw order, host-mapped: what the outputs' row order is derived from)
     atomicAdd(&cnt[lo], 1u);
 }
 

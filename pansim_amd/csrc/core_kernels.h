@@ -1393,17 +1393,21 @@ __global__ void __launch_bounds__(256) core_transpose_kernel(uint8_t *state, uin
 // individuals [i0, i0+ni) -- letters A/C/G/T/N (population.rs:154-162) joined by ',' and ended by
 // '\n', 2*L bytes per individual -- produced from the site-major state through a 64x64 LDS tile so
 // that both the state reads and the text writes are coalesced.
+// (row_slot: line k is the individual stored at column row_slot[k] -- a ps_sim's children sit in ascending parent order,
+// its lines come in draw order; nullptr = column k)
 __global__ void __launch_bounds__(256) core_csv_kernel(const uint8_t *state, uint8_t *text, uint32_t pitch,
-                                                       uint64_t L, uint32_t i0, uint32_t ni, uint8_t last_char)
+                                                       uint64_t L, uint32_t i0, uint32_t ni, uint8_t last_char,
+                                                       const uint32_t *row_slot)
 {
     __shared__ uint8_t tile[64][65];
     const uint32_t tx = threadIdx.x & 63u, ty = threadIdx.x >> 6;
     const uint64_t s0 = (uint64_t)blockIdx.x * 64u;
     const uint32_t ib = blockIdx.y * 64u;
+    const uint32_t col = (ib + tx < ni) ? (row_slot ? row_slot[i0 + ib + tx] : i0 + ib + tx) : 0u;
     for (uint32_t r = ty; r < 64; r += 4) {
         const uint64_t s = s0 + r;
         const uint32_t i = ib + tx;
-        tile[r][tx] = (s < L && i < ni) ? state[s * pitch + i0 + i] : 0;
+        tile[r][tx] = (s < L && i < ni) ? state[s * pitch + col] : 0;
     }
     __syncthreads();
     // 128 text bytes per individual and tile: thread tx writes bytes 2*tx' .. for two halves

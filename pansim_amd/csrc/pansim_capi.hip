@@ -287,6 +287,15 @@ struct ps_population {
     bool exchange_beside_sweep = false; // donor-sharded HGT: the next sweep waits for the LDS-image pass only (ps_sim sets it)
     int last_sweep_form = 0;            // PS_SWEEP_FORM_* of the last core sweep launch (ps_last_sweep_form)
     int window_sweep = -1;              // window sweep for N > 1024 when the parents are sorted: -1 = choose, 0 = never, 1 = whenever possible
+    // Row order at the boundary.  A ps_sim stores the children of a generation in ascending parent order;
+    // the reference's row k is the child of draw k (population.rs:443, main.rs:445-447).  row_slot[k] = the internal row
+    // of output row k (empty = they coincide); rows_refresh (set by the owning ps_sim) brings it up to date before an
+    // output.  A direct ps_load_matrix / ps_next_generation / ps_step on the handle makes the two orders coincide again.
+    int (*rows_refresh)(void *ctx) = nullptr;
+    void *rows_ctx = nullptr;
+    std::vector<uint32_t> row_slot;
+    uint32_t *d_row_slot = nullptr;
+    bool rows_overridden = false;
     uint32_t *h_flag = nullptr, *d_flag = nullptr;   // host-mapped sticky device error word
     unsigned long long *h_stamps = nullptr, *d_stamps = nullptr;   // diagnostic phase stamps
 };
@@ -297,12 +306,30 @@ static int use_device(const ps_population *p)
     return PS_OK;
 }
 
+// output rows in the reference's order: row_slot current (see struct ps_population), nullptr = internal order
+static int rows_current(ps_population *p, const uint32_t **slot_out)
+{
+    if (p->rows_overridden) p->row_slot.clear();
+    else if (p->rows_refresh) PSCHK(p->rows_refresh(p->rows_ctx));
+    *slot_out = p->row_slot.empty() ? nullptr : p->row_slot.data();
+    return PS_OK;
+}
+
+// v[k] <- v[slot[k]] for a per-individual result
+template <typename T>
+static void rows_permute(T *v, const uint32_t *slot, uint64_t n)
+{
+    if (!slot) return;
+    std::vector<T> tmp(v, v + n);
+    for (uint64_t k = 0; k < n; k++) v[k] = tmp[slot[k]];
+}
+
 extern "C" void ps_population_destroy(ps_population *p)
 {
     if (!p) return;
     (void)hipSetDevice(p->device);
     if (p->stream) (void)hipStreamSynchronize(p->stream);
-    void *ptrs[] = { p->state, p->state2, p->d_delta, p->hgt_ovf_img, p->G[0], p->G[1], p->I[0], p->I[1], p->I_snap, p->d_ptab[0], p->d_ptab[1], p->hgt_scratch, p->cnt, p->d_idx, p->d_idxT, p->d_work,
+    void *ptrs[] = { p->d_row_slot, p->state, p->state2, p->d_delta, p->hgt_ovf_img, p->G[0], p->G[1], p->I[0], p->I[1], p->I_snap, p->d_ptab[0], p->d_ptab[1], p->hgt_scratch, p->cnt, p->d_idx, p->d_idxT, p->d_work,
                      p->d_log1p, p->d_num_genes, p->d_logw, p->d_pairs, p->d_H, p->d_Dt, p->d_davg, p->d_davg_in, p->d_pack2, p->d_pair_part };
     for (void *q : ptrs)
         if (q) (void)hipFree(q);
@@ -607,6 +634,7 @@ extern "C" int ps_load_matrix(ps_population *p, const uint8_t *rows)
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(p->stream));
     HIPCHK(hipFree(d_rows));
+    p->rows_overridden = true;       // (of a ps_sim's handle: the loaded order is the order of every output until its next generation)
     return PS_OK;
 }
 
@@ -627,9 +655,16 @@ extern "C" int ps_read_matrix(ps_population *p, uint8_t *rows)
             p->I[p->cur], d_rows, p->d);
     }
     HIPCHK(hipGetLastError());
+    const uint32_t *slot = nullptr;
+    PSCHK(rows_current(p, &slot));
     HIPCHK(hipMemcpyAsync(rows, d_rows, N * C, hipMemcpyDeviceToHost, p->stream));
     HIPCHK(hipStreamSynchronize(p->stream));
     HIPCHK(hipFree(d_rows));
+    if (slot) {
+        // row k of the output = the child of draw k (a ps_sim's handle: population.rs:443, main.rs:445-447)
+        std::vector<uint8_t> tmp(rows, rows + N * C);
+        for (uint64_t k = 0; k < N; k++) memcpy(rows + k * C, tmp.data() + (uint64_t)slot[k] * C, C);
+    }
     return PS_OK;
 }
 
@@ -1302,6 +1337,7 @@ extern "C" int ps_next_generation(ps_population *p, const uint32_t *sample)
     PSCHK(use_device(p));
     PSCHK(upload_idx(p, sample));
     PSCHK(step_device(p, p->d_idx, 0, true, false, false, p->stream));
+    p->rows_overridden = true;
     return sync_checked(p);
 }
 
@@ -1332,6 +1368,7 @@ extern "C" int ps_step(ps_population *p, uint32_t generation, const uint32_t *sa
     // an ascending sample lets a wide core population take the window sweep (what ps_sim_run's own generations do)
     const bool sorted = p->cfg.core && std::is_sorted(sample, sample + p->cfg.pop_size);
     PSCHK(step_device(p, p->d_idx, generation, true, true, do_recombine != 0, p->stream, nullptr, sorted));
+    p->rows_overridden = true;
     return sync_checked(p);
 }
 
@@ -1370,7 +1407,12 @@ extern "C" int ps_fitness_terms(ps_population *acc, const double *sel, int32_t *
     if (acc->cfg.core) return ps_fail(PS_ERR_INVALID, "sample_indices runs on the accessory matrix (main.rs:442)");
     if (acc->cfg.ncols && !sel) return ps_fail(PS_ERR_INVALID, "null selection coefficients");
     PSCHK(use_device(acc));
-    return fitness_terms_device(acc, sel, num_genes, logw, acc->stream);
+    PSCHK(fitness_terms_device(acc, sel, num_genes, logw, acc->stream));
+    const uint32_t *slot = nullptr;
+    PSCHK(rows_current(acc, &slot));
+    rows_permute(num_genes, slot, acc->cfg.pop_size);
+    rows_permute(logw, slot, acc->cfg.pop_size);
+    return PS_OK;
 }
 
 // Host threads for the element-wise libm calls of the softmaxes (the sums stay sequential)
@@ -1784,6 +1826,9 @@ static int ensure_pairs(ps_population *p, uint64_t P)
 // LDS row: a broadcast instead of a bank conflict) together with the permutation that
 // restores the caller's order.  The list is fixed for a whole run (main.rs:413-427), so the
 // device copy is reused while the caller keeps passing the same list.
+struct core_pair_plan;
+static bool core_pairs_take_a_tiled_kernel(const ps_population *p, uint64_t P);
+
 static int upload_pairs(ps_population *p, uint64_t P, const uint32_t *r1, const uint32_t *r2, bool trusted = false)
 {
     PSCHK(ensure_pairs(p, P));
@@ -1791,7 +1836,9 @@ static int upload_pairs(ps_population *p, uint64_t P, const uint32_t *r1, const 
     // the sorted order and the thread table only serve the tiled kernel: the core matrix with a
     // population that fits its LDS tile (elsewhere -- accessory pairs, cfg5's all-pairs tiles -- the
     // caller's order is uploaded as it is)
-    const bool tiled_possible = p->cfg.core && (uint64_t)N * (4 + 4) * 4 <= p->lds_limit;
+    // (... and only when the launch will take one of those kernels: a ps_sim with --print_dist uploads a re-mapped list
+    // every generation, and the sort + thread table + bank schedule of 100 000 pairs is host time the all-pairs form never uses)
+    const bool tiled_possible = p->cfg.core && (uint64_t)N * (4 + 4) * 4 <= p->lds_limit && core_pairs_take_a_tiled_kernel(p, P);
     // (a ps_sim passes its own immutable list: same pointers as the cached copy was built from)
     if (p->pairs_cached == P && p->pairs_tiled == tiled_possible && p->h_r1.size() == P
         && ((trusted && p->pairs_src1 == r1 && p->pairs_src2 == r2)
@@ -1889,14 +1936,13 @@ static int pair_partials(ps_population *p, uint64_t words, uint32_t **out)
     return PS_OK;
 }
 
-static int pair_counts_device(ps_population *p, uint64_t P, const uint32_t *d_r1, const uint32_t *d_r2,
-                              const uint32_t *d_perm, uint32_t *d_a, uint32_t *d_b, hipStream_t st)
+// which form the core pair counts of P pairs take (one decision, shared by the launch below and by upload_pairs, which
+// only sorts the list and builds the thread table when a tiled sampled kernel will read them)
+struct core_pair_plan { uint32_t W; bool use_rows, use_all, mfma_ok; };
+static core_pair_plan plan_core_pairs(const ps_population *p, uint64_t P)
 {
     const uint32_t N = (uint32_t)p->cfg.pop_size;
-    if (p->cfg.core) {
-        HIPCHK(hipMemsetAsync(d_a, 0, P * sizeof(uint32_t), st));
-        const uint32_t rows = (uint32_t)p->cfg.ncols;
-        if (rows == 0) return PS_OK;
+    const uint32_t rows = (uint32_t)p->cfg.ncols;
         // tiled kernel: LDS holds N * (W+4) dwords; prefer a tile that lets two workgroups share
         // a CU so that one packs its next tile (HBM) while the other compares (LDS)
         uint32_t W = 0;
@@ -1924,6 +1970,28 @@ static int pair_counts_device(ps_population *p, uint64_t P, const uint32_t *d_r1
         const bool all_wins = mfma_ok ? mf_tiles / 5.5e14 < (double)P / 6.4e13 : (double)P * 2.0 > all_pairs;
         const bool use_all = !use_rows && all_fits && p->pair_mode != 1 && p->pair_mode != 3
                              && (force_all || all_wins || !W);
+    core_pair_plan o = { W, use_rows, use_all, mfma_ok };
+    return o;
+}
+
+static bool core_pairs_take_a_tiled_kernel(const ps_population *p, uint64_t P)
+{
+    if (!p->cfg.core || p->cfg.ncols == 0) return false;
+    const core_pair_plan pp = plan_core_pairs(p, P);
+    return !pp.use_rows && !pp.use_all && pp.W != 0u;
+}
+
+static int pair_counts_device(ps_population *p, uint64_t P, const uint32_t *d_r1, const uint32_t *d_r2,
+                              const uint32_t *d_perm, uint32_t *d_a, uint32_t *d_b, hipStream_t st)
+{
+    const uint32_t N = (uint32_t)p->cfg.pop_size;
+    if (p->cfg.core) {
+        HIPCHK(hipMemsetAsync(d_a, 0, P * sizeof(uint32_t), st));
+        const uint32_t rows = (uint32_t)p->cfg.ncols;
+        if (rows == 0) return PS_OK;
+        const core_pair_plan pp = plan_core_pairs(p, P);
+        const uint32_t W = pp.W;
+        const bool use_rows = pp.use_rows, use_all = pp.use_all, mfma_ok = pp.mfma_ok;
         if (use_rows) {
             p->last_pair_form = PS_PAIR_FORM_ROWS;
             const bool nib = !p->onehot_safe;
@@ -2129,7 +2197,16 @@ extern "C" int ps_pairwise_counts(ps_population *p, uint64_t P, const uint32_t *
         if (range1[k] >= N || range2[k] >= N)
             return ps_fail(PS_ERR_INVALID, "pair %llu out of range", (unsigned long long)k);
     PSCHK(use_device(p));
-    PSCHK(upload_pairs(p, P, range1, range2));
+    const uint32_t *slot = nullptr;
+    PSCHK(rows_current(p, &slot));
+    if (slot) {
+        // individuals are named by their output row (the child of draw k): their internal rows
+        std::vector<uint32_t> m1(P), m2(P);
+        for (uint64_t k = 0; k < P; k++) { m1[k] = slot[range1[k]]; m2[k] = slot[range2[k]]; }
+        PSCHK(upload_pairs(p, P, m1.data(), m2.data()));
+    } else {
+        PSCHK(upload_pairs(p, P, range1, range2));
+    }
     uint32_t *d_r1 = (uint32_t *)p->d_pairs, *d_r2 = d_r1 + P, *d_perm = d_r2 + P, *d_a = d_perm + P, *d_b = d_a + P;
     uint32_t *ka = out_is_device ? out_a : d_a;
     uint32_t *kb = out_is_device ? out_b : d_b;
@@ -2182,6 +2259,9 @@ extern "C" int ps_average_distance(ps_population *p, double *out)
     HIPCHK(hipMemcpyAsync(out, d_out, N * sizeof(double), hipMemcpyDeviceToHost, p->stream));
     HIPCHK(hipStreamSynchronize(p->stream));
     HIPCHK(hipFree(d_out));
+    const uint32_t *slot = nullptr;
+    PSCHK(rows_current(p, &slot));
+    rows_permute(out, slot, N);
     return PS_OK;
 }
 
@@ -2386,10 +2466,12 @@ extern "C" int ps_write(ps_population *p, const char *outpref)
             rc = ps_fail(PS_ERR_OOM, "cannot allocate the text buffers of ps_write");
         uint64_t pending = 0;
         int pending_buf = -1, k = 0;
+        const uint32_t *slot = nullptr;
+        if (rc == PS_OK) rc = rows_current(p, &slot);
         for (uint64_t i0 = 0; rc == PS_OK && i0 < N; i0 += chunk, k ^= 1) {
             const uint32_t ni = (uint32_t)std::min<uint64_t>(chunk, N - i0);
             dim3 grid((uint32_t)((C + 63) / 64), (ni + 63) / 64);
-            core_csv_kernel<<<grid, 256, 0, p->stream>>>(p->state, d_text, p->pitch, C, (uint32_t)i0, ni, (uint8_t)'\n');
+            core_csv_kernel<<<grid, 256, 0, p->stream>>>(p->state, d_text, p->pitch, C, (uint32_t)i0, ni, (uint8_t)'\n', slot ? p->d_row_slot : nullptr);
             if (hipMemcpyAsync(h_text[k], d_text, (uint64_t)ni * row_bytes, hipMemcpyDeviceToHost, p->stream) != hipSuccess)
                 rc = ps_fail(PS_ERR_NO_DEVICE, "D2H copy failed in ps_write");
             if (pending_buf >= 0 && fwrite(h_text[pending_buf], 1, pending, f) != pending)
@@ -2704,6 +2786,14 @@ struct ps_sim {
     hipEvent_t ev_hgt = nullptr;
     hipEvent_t ev_gap[PS_RING][2] = {};   // timestamped events around the sweep when timing is off
     std::vector<uint32_t> h_kids;       // children per parent (host counting sort of the drawn parents)
+    // The draws of each ring slot's generation IN DRAW ORDER (parents named by their internal row): the reference's child k
+    // is the child of draw k (population.rs:443, main.rs:445-447), the engine stores the children in ascending parent order
+    // -- a stable counting sort of the draws -- so row k of every output is the internal row rank(k) (sim_refresh_rows)
+    uint32_t *h_draw[PS_RING] = {};        // pinned, host-mapped (the device draw writes it)
+    uint32_t *m_draw[PS_RING] = {};        // device alias of h_draw
+    int prev_slot = -1;                    // ring slot of the generation before the last one (-1: none)
+    std::vector<uint32_t> sigma, sigma_prev_inv;   // last generation: output row -> internal row; the one before: internal row -> output row
+    uint64_t sigma_step = ~0ull;           // step_count the two were computed for
     bool heavy_hgt = false;             // expected HGT events per generation >= 1e7: HGT and sweep take turns
     bool slot_used[PS_RING] = {};
     int32_t *h_num_genes = nullptr, *m_num_genes = nullptr;   // pinned + its device alias
@@ -2759,6 +2849,7 @@ extern "C" void ps_sim_destroy(ps_sim *s)
     for (int k = 0; k < PS_RING; k++) {
         if (s->d_idx[k]) (void)hipFree(s->d_idx[k]);
         if (s->h_idx[k]) (void)hipHostFree(s->h_idx[k]);
+        if (s->h_draw[k]) (void)hipHostFree(s->h_draw[k]);
         if (s->ev_idx[k]) (void)hipEventDestroy(s->ev_idx[k]);
         if (s->ev_core[k]) (void)hipEventDestroy(s->ev_core[k]);
         if (k == 0 && s->ev_hgt) (void)hipEventDestroy(s->ev_hgt);
@@ -2784,6 +2875,8 @@ extern "C" void ps_sim_destroy(ps_sim *s)
     ps_population_destroy(s->acc);
     delete s;
 }
+
+static int sim_refresh_rows(void *ctx);
 
 static int sim_create_impl(const ps_sim_params *p, ps_sim *s)
 {
@@ -2822,6 +2915,9 @@ static int sim_create_impl(const ps_sim_params *p, ps_sim *s)
         PSCHK(ps_init_vector(p->seed, 0, 0, G, d.avg_gene_freq_adj, v.data()));
         PSCHK(ps_population_create(&ca, v.data(), &s->acc));        // main.rs:382-391
     }
+    // rows of every output of the two handles in the reference's order (the child of draw k), whatever the engine's own
+    s->core->rows_refresh = s->acc->rows_refresh = sim_refresh_rows;
+    s->core->rows_ctx = s->acc->rows_ctx = s;
     {
         const uint64_t b0 = 0, e0 = L;
         const double lm = d.n_core_mutations;
@@ -2839,6 +2935,8 @@ static int sim_create_impl(const ps_sim_params *p, ps_sim *s)
         HIPCHK(hipMalloc(&s->d_idx[k], N * sizeof(uint32_t)));
         HIPCHK(hipHostMalloc(&s->h_idx[k], N * sizeof(uint32_t), hipHostMallocMapped));
         HIPCHK(hipHostGetDevicePointer((void **)&s->m_idx[k], s->h_idx[k], 0));
+        HIPCHK(hipHostMalloc(&s->h_draw[k], N * sizeof(uint32_t), hipHostMallocMapped));
+        HIPCHK(hipHostGetDevicePointer((void **)&s->m_draw[k], s->h_draw[k], 0));
         HIPCHK(hipEventCreateWithFlags(&s->ev_idx[k], hipEventDisableTiming));
         HIPCHK(hipEventCreateWithFlags(&s->ev_core[k], hipEventDisableTiming));
     }
@@ -3026,7 +3124,9 @@ static int sim_one_generation(ps_sim *s, uint32_t gen)
     if (s->weights_hook) PSCHK(s->weights_hook(s->weights_ctx, s, gen, w.data()));
     else PSCHK(sim_host_weights(s, gen, w.data()));
     th0 = clk::now();
+    s->prev_slot = s->step_count ? s->last_slot : -1;
     s->last_slot = slot;
+    core->rows_overridden = acc->rows_overridden = false;      // (rows in the order of THIS generation's draws from here on)
     // the step leaves the pre-recombination snapshot only for the light HGT form, the one that reads it (the binned form of
     // cfg3 / cfg4 / cfg5 does not: a third N x GW x 8-byte buffer written per generation with no reader)
     const bool want_snap = p.HGT_rate > 0.0 && !hgt_takes_binned_form(acc);
@@ -3040,7 +3140,7 @@ static int sim_one_generation(ps_sim *s, uint32_t gen)
         // the N draws, then a counting sort: children are stored in ascending parent order
         // (the counts are zero: zeroed at creation, and by idx_zero_kernel after every use)
         acc_draw_parents_kernel<<<(uint32_t)((N + 255) / 256), 256, 0, sa>>>(s->d_cum, total, (uint32_t)N, (uint32_t)p.seed,
-                                                                         (uint32_t)(p.seed >> 32), gen, s->d_idx_cnt);
+                                                                         (uint32_t)(p.seed >> 32), gen, s->d_idx_cnt, s->m_draw[slot]);
         {
             const uint32_t tiles = (uint32_t)((N + 1023) / 1024);
             idx_tile_sums_kernel<<<tiles, 256, 0, sa>>>(s->d_idx_cnt, (uint32_t)N, s->d_idx_tsum);
@@ -3055,6 +3155,7 @@ static int sim_one_generation(ps_sim *s, uint32_t gen)
         PSCHK(launch_acc_step(acc, s->d_idx[slot], gen, true, true, sa, nullptr, want_snap));
     } else {
     PSCHK(ps_draw_parents(w.data(), N, p.seed, gen, s->h_idx[slot]));
+    memcpy(s->h_draw[slot], s->h_idx[slot], N * sizeof(uint32_t));      // (draw order: sim_refresh_rows, ps_sim_last_parents)
     {
         // children in ascending parent order: a counting sort, as on the device
         s->h_kids.assign(N, 0u);
@@ -3295,14 +3396,58 @@ extern "C" const double *ps_sim_selection(ps_sim *s) { return s ? s->sel.data() 
 extern "C" const uint32_t *ps_sim_range1(ps_sim *s) { return s ? s->r1.data() : nullptr; }
 extern "C" const uint32_t *ps_sim_range2(ps_sim *s) { return s ? s->r2.data() : nullptr; }
 
+// rank[k] = position of draw k after a stable sort of the draws by parent = the internal row of the child of draw k
+static void stable_rank(const uint32_t *draw, uint64_t N, std::vector<uint32_t> &start, uint32_t *rank)
+{
+    start.assign(N + 1, 0u);
+    for (uint64_t k = 0; k < N; k++) start[draw[k] + 1]++;
+    for (uint64_t i = 0; i < N; i++) start[i + 1] += start[i];
+    for (uint64_t k = 0; k < N; k++) rank[k] = start[draw[k]]++;
+}
+
+// rows_refresh of the simulation's two handles: output row k = the child of draw k of the last generation
+static int sim_refresh_rows(void *ctx)
+{
+    ps_sim *s = (ps_sim *)ctx;
+    if (s->sigma_step == s->step_count) return PS_OK;
+    const uint64_t N = s->prm.pop_size;
+    PSCHK(use_device(s->core));
+    HIPCHK(hipStreamSynchronize(s->acc->stream));       // (with the draw on the device the slot is written by a kernel of that stream)
+    std::vector<uint32_t> start;
+    s->sigma.clear();
+    s->sigma_prev_inv.clear();
+    if (s->step_count) {
+        s->sigma.resize(N);
+        stable_rank(s->h_draw[s->last_slot], N, start, s->sigma.data());
+        if (s->prev_slot >= 0) {
+            std::vector<uint32_t> sp(N);
+            stable_rank(s->h_draw[s->prev_slot], N, start, sp.data());
+            s->sigma_prev_inv.resize(N);
+            for (uint64_t k = 0; k < N; k++) s->sigma_prev_inv[sp[k]] = (uint32_t)k;
+        }
+    }
+    for (ps_population *p : { s->core, s->acc }) {
+        p->row_slot = s->sigma;
+        if (p->cfg.core && !s->sigma.empty()) {
+            if (!p->d_row_slot) HIPCHK(hipMalloc(&p->d_row_slot, N * sizeof(uint32_t)));
+            HIPCHK(hipMemcpyAsync(p->d_row_slot, s->sigma.data(), N * sizeof(uint32_t), hipMemcpyHostToDevice, p->stream));
+            HIPCHK(hipStreamSynchronize(p->stream));
+        }
+    }
+    s->sigma_step = s->step_count;
+    return PS_OK;
+}
+
+// the draws of the last generation in draw order, every parent named by ITS output row of the generation before (the
+// reference's sample_indices: population.rs:443) -- child k of this generation's outputs descends from row out_idx[k] of
+// the previous generation's
 extern "C" int ps_sim_last_parents(ps_sim *s, uint32_t *out_idx)
 {
     if (!s || !out_idx) return ps_fail(PS_ERR_INVALID, "null argument");
     if (s->step_count == 0) { memset(out_idx, 0, s->prm.pop_size * sizeof(uint32_t)); return PS_OK; }
-    // (with the draw on the device the slot is written by a kernel of the accessory stream)
-    PSCHK(use_device(s->core));
-    HIPCHK(hipStreamSynchronize(s->acc->stream));
-    memcpy(out_idx, s->h_idx[s->last_slot], s->prm.pop_size * sizeof(uint32_t));
+    PSCHK(sim_refresh_rows(s));
+    const uint32_t *d = s->h_draw[s->last_slot];
+    for (uint64_t k = 0; k < s->prm.pop_size; k++) out_idx[k] = s->sigma_prev_inv.empty() ? d[k] : s->sigma_prev_inv[d[k]];
     return PS_OK;
 }
 
@@ -3324,8 +3469,18 @@ static int sim_pair_counts(ps_sim *s, uint32_t **core_cnt, uint32_t **acc_in, ui
     }
     for (auto &e : s->ev_dist)
         if (!e) HIPCHK(hipEventCreate(&e));
-    PSCHK(upload_pairs(core, P, s->r1.data(), s->r2.data(), true));
-    PSCHK(upload_pairs(acc, P, s->r1.data(), s->r2.data(), true));
+    // the pair list names individuals by their output row (main.rs:413-427 draws it once, over the labels 0 .. N - 1)
+    const uint32_t *slot = nullptr;
+    PSCHK(rows_current(core, &slot));
+    if (slot) {
+        std::vector<uint32_t> m1(P), m2(P);
+        for (uint64_t k = 0; k < P; k++) { m1[k] = slot[s->r1[k]]; m2[k] = slot[s->r2[k]]; }
+        PSCHK(upload_pairs(core, P, m1.data(), m2.data()));
+        PSCHK(upload_pairs(acc, P, m1.data(), m2.data()));
+    } else {
+        PSCHK(upload_pairs(core, P, s->r1.data(), s->r2.data(), true));
+        PSCHK(upload_pairs(acc, P, s->r1.data(), s->r2.data(), true));
+    }
     uint32_t *c1 = (uint32_t *)core->d_pairs, *a1 = (uint32_t *)acc->d_pairs;
     // everything the generation loop queued on either stream precedes the distance kernels of both
     HIPCHK(hipStreamSynchronize(acc->stream));
@@ -3887,8 +4042,10 @@ extern "C" int ps_multi_write(ps_multi *m, const char *outpref)
             const uint64_t C = c->cfg.ncols;
             PSCHK(use_device(c));
             dim3 grid((uint32_t)((C + 63) / 64), (ni + 63) / 64);
+            const uint32_t *slot = nullptr;
+            PSCHK(rows_current(c, &slot));
             core_csv_kernel<<<grid, 256, 0, c->stream>>>(c->state, d_text[k], c->pitch, C, (uint32_t)i0, ni,
-                                                         (uint8_t)(k + 1 == K ? '\n' : ','));
+                                                         (uint8_t)(k + 1 == K ? '\n' : ','), slot ? c->d_row_slot : nullptr);
             HIPCHK(hipGetLastError());
             HIPCHK(hipMemcpyAsync(h_text[k], d_text[k], (uint64_t)ni * 2 * C, hipMemcpyDeviceToHost, c->stream));
             HIPCHK(hipStreamSynchronize(c->stream));

@@ -8,6 +8,9 @@ exchange providers by CPU doubles over gloo.  PANSIM_BENCH_STUB_MODE selects a f
   raise_ns  the second workload raises on every rank                      -> the final line carries the error
   die_ns    rank 1 dies (os._exit(9)) inside the second workload          -> the launcher relays the contract line
   no_torch  the "torch" provider fails its probe                          -> the chain ends in "none (fallback: ...)"
+  hang_nd   the third (configs[4] distance) workload never returns on rank 1 -> the watchdog prints the line with both
+            earlier workloads in it
+  hang_all  rank 1 hangs before any line exists                           -> the launcher's first-attempt budget ends it
 """
 import ctypes
 import os
@@ -46,7 +49,10 @@ def providers(ctx, rank, world):
 
 def measure(ctx, kw, P, steps, warmup, shard_rank, shard_count, exchange=None, want_pairs=False):
     second = kw["pop_size"] == 65536            # (bench.py's north-star workload)
-    if second and MODE == "hang_ns" and ctx.rank == 1:
+    third = kw["pop_size"] == 8192              # (... and its configs[4] distance workload)
+    if MODE == "hang_all" and ctx.rank == 1 and os.environ.get("PANSIM_BENCH_BACKEND") != "gloo":
+        time.sleep(3600)
+    if (second and MODE == "hang_ns" or third and MODE == "hang_nd") and ctx.rank == 1:
         time.sleep(3600)
     if second and MODE == "raise_ns":
         raise RuntimeError("stub: the second workload failed")
@@ -62,7 +68,7 @@ def measure(ctx, kw, P, steps, warmup, shard_rank, shard_count, exchange=None, w
     r = {"dt": dt, "steps": steps, "warmup": warmup, "launches": steps, "sweep_avg_ms": ms,
          "sweep_avg_ms_max_over_ranks": ctx.reduce(ms, "max"), "sweep_avg_ms_min_over_ranks": ctx.reduce(ms, "min"),
          "bytes_per_launch": 2.0 * kw["pop_size"] * L_local, "host": (steps, 0.0, 0.0, 0.0), "settle": [ms], "dist_dt": 0.002,
-         "dist_kernel_ms": None, "pair_form": 0, "L_local": L_local, "sweep_form": 2 if kw["pop_size"] <= 1024 else 3,
+         "dist_kernel_ms": None, "pair_form": 0, "L_local": L_local, "sweep_form": 1 if kw["pop_size"] <= 1024 else 3,
          "G_acc": kw["pan_genes"] - 2000, "P": P, "N": kw["pop_size"], "kw": kw,
          "exchange": {"mode": exchange or "none (accessory chain replicated on every rank)", "calls": 0,
                       "bytes_sent_plus_received_per_generation": 0.0}}

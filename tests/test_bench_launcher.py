@@ -38,6 +38,12 @@ def test_bare_form_launches_its_own_ranks():
     assert [c["provider"] for c in chain] == ["rccl", "torch"] and not chain[0]["ok"] and chain[1]["ok"]
     assert d["north_star_exchange"] == "torch" and d["control_plane"] == "gloo"
     assert d["roofline"]["traffic_measured_in_this_run"] is False
+    # round 6: the third workload (BASELINE configs[4]: the distance phase of --pop_size 8192, P = 2^25, sites split over the
+    # ranks, one all-reduce of the partial counts), what the probes saw at the top level
+    nd = d["north_star_distance"]
+    assert nd["n_gpus"] == 2 and nd["pairs"] == 1 << 25 and nd["collective_bytes_per_rank"] == 4 << 25 and nd["mpairs_per_s"] > 0
+    assert d["north_star_distance_mpairs_per_s"] == nd["mpairs_per_s"]
+    assert d["rccl_ranks_seen"] == 0 and d["north_star_exchange_world_size"] == 2       # (no RCCL on a CPU box)
 
 
 def test_three_ranks_and_every_provider_failing():
@@ -63,6 +69,33 @@ def test_second_workload_hanging_is_cut_by_the_watchdog():
     d = json.loads(lines[0])
     assert d["value"] > 0 and d["n_gpus"] == 2
     assert d["line"].startswith("contract") or "watchdog" in d["north_star_scaling"]["error"]
+    # a run cut short is not a success -- the line stands, the exit code says so
+    assert p.returncode != 0
+
+
+def test_third_workload_hanging_keeps_the_first_two():
+    p, lines = _run({"PANSIM_BENCH_STUB_MODE": "hang_nd", "PANSIM_BENCH_NS_TIMEOUT": "6"}, "--gpus", "2", "--steps", "5", "--warmup", "1")
+    assert len(lines) == 1, (p.returncode, p.stderr[-2000:])
+    d = json.loads(lines[0])
+    assert d["value"] > 0 and d["north_star_generations_per_s"] > 0 and d["north_star_scaling"]["scaling"] == "strong"
+    assert d["line"].startswith("contract + north_star_scaling") or "watchdog" in d["north_star_distance"]["error"]
+    assert p.returncode != 0
+
+
+def test_budgets_fit_the_drivers_limit():
+    # first attempt <= 700 s, the gloo retry <= 500 s, each north-star workload <= 300 s: 1200 s + start-up < 1800 s even
+    # when the first attempt hangs before a line exists (here with the budgets scaled down: 8 s, then a retry that works)
+    import re
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert re.search(r'PANSIM_BENCH_LAUNCH_TIMEOUT", "700"', src) and re.search(r'PANSIM_BENCH_RETRY_TIMEOUT", "500"', src)
+    assert len(re.findall(r'PANSIM_BENCH_NS_TIMEOUT", "300"', src)) == 2
+    p, lines = _run({"PANSIM_BENCH_STUB_MODE": "hang_all", "PANSIM_BENCH_LAUNCH_TIMEOUT": "8", "PANSIM_BENCH_RETRY_TIMEOUT": "120"},
+                    "--gpus", "2", "--steps", "5", "--warmup", "1")
+    assert len(lines) == 1, (p.returncode, p.stderr[-2000:])
+    d = json.loads(lines[0])
+    att = d["launcher"]["attempts"]
+    assert [a["backend"] for a in att] == ["nccl", "gloo"] and att[0]["timed_out"] and att[0]["json_lines"] == 0 and att[0]["wall_s"] < 40
+    assert att[1]["rc"] == 0 and d["line"] == "final" and p.returncode == 0
 
 
 def test_a_rank_dying_in_the_second_workload_keeps_the_contract_line():
@@ -86,7 +119,9 @@ def test_under_torchrun_rank0_prints_the_contract_line_first():
                        env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=240)
     assert p.returncode == 0, p.stderr[-2000:]
     lines = [json.loads(ln) for ln in p.stdout.splitlines() if ln.startswith("{")]
-    assert len(lines) == 2 and lines[0]["line"].startswith("contract") and lines[1]["line"] == "final"
+    assert len(lines) == 3 and lines[0]["line"].startswith("contract") and lines[1]["line"].startswith("contract + north_star_scaling")
+    assert lines[2]["line"] == "final" and "north_star_distance" in lines[2]
+    lines = [lines[0], lines[2]]
     need = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
             "dtype", "data", "config", "roofline"}
     for d in lines:
