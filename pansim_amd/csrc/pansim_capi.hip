@@ -3760,6 +3760,9 @@ static int multi_weights(void *vctx, ps_sim *s, uint32_t gen, double *w)
         m->shared_rc = sim_host_weights(s, gen, m->shared_w.data(), avg_ready);
         if (m->shared_rc != PS_OK) m->shared_err = g_err;
     }
+    // the prefetched vector is consumed by this generation on EVERY shard (only shard 0 goes through sim_host_weights, which
+    // clears the flag too): a shard must never carry it into a later generation and skip a collective its peers enter
+    s->avg_prefetched = false;
     PSCHK(multi_barrier(m));                     // shard 0 has published the weights
     const int rc = m->shared_rc;
     if (rc == PS_OK) memcpy(w, m->shared_w.data(), N * sizeof(double));

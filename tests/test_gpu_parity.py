@@ -794,6 +794,33 @@ def test_step_with_ascending_parents_takes_the_window_sweep(pa, orc, N, L, lh, t
         pop.close()
 
 
+def test_wide_segments_at_any_generation_number(pa, orc):
+    # The window sweep's second ("wide") launch leaves at once unless the first launch of the SAME generation flagged a
+    # segment for it: one flag per generation parity, set by the first launch, cleared by the first launch of the generation
+    # before (core_kernels.h).  Generation numbers here are neither consecutive nor alternating in parity
+    # (7, 12, 14, 15, 15, 40), wide and narrow generations interleave, so a stale or a missing flag would leave the children
+    # of a wide segment unwritten -- every state is compared with the oracle's.
+    N, L, LG = 6000, 18, 1200000
+    rng = np.random.default_rng(77)
+    m = _rand_core(rng, N, L)
+    lm, lhr = 0.05 * LG, 0.02 * LG
+    plan = orc.core_plan(lm, lhr, LG)
+    pop = pa.Population(N, L, 4, True, 0.0, 9, 0, col_offset=5, global_cols=LG)
+    pop.set_rates([lm], [lhr])
+    pop.load_matrix(m)
+    narrow = np.sort(rng.integers(0, N, N)).astype(np.uint32)
+    # parents far apart inside one 1024-child segment: half of the children from the first 50 parents, half from the last 50
+    wide = np.sort(np.concatenate([rng.integers(0, 50, N // 2), rng.integers(N - 50, N, N - N // 2)])).astype(np.uint32)
+    for gen, sample in ((7, wide), (12, narrow), (14, wide), (15, wide), (15, narrow), (40, wide)):
+        pop.step(gen, sample, True)
+        assert pop.last_sweep_form() == 3
+        m = orc.next_generation(m, sample)
+        orc.mutate_core(m, 5, 9, gen, plan)
+        orc.recombine_core(m, 5, 9, gen, plan)
+        assert np.array_equal(pop.read_matrix(), m), gen
+    pop.close()
+
+
 # ----------------------------------------------------------------------------- BASELINE full sizes
 def _crc(a):
     import zlib
