@@ -294,15 +294,14 @@ int ps_sim_create(const ps_sim_params *p, ps_sim **out);
 void ps_sim_destroy(ps_sim *s);
 /* main.rs:429-464 for generations [first, first+count): select, gather x2,
  * mutate x2, HR, HGT.  Asynchronous on the device; ps_sim_sync() waits.
- * The loop stores the children of a generation in ASCENDING PARENT ORDER: the N draws of sample_indices
- * (population.rs:440-443) are sorted before both gathers.  The individuals of a Wright-Fisher generation
- * are exchangeable, so every MARGINAL the reference's outputs carry is unchanged -- but two things are not exchangeable any
- * more: the ROW ORDER of _core_genome.csv / _pangenome.csv encodes ancestry (neighbouring rows are siblings), and with
- * --print_dist the fixed pair list (main.rs:413-427) re-samples the same close-kin slot pairs every generation, so the
- * sampling noise of _per_gen.tsv is autocorrelated between generations when P << N^2.  It is what lets populations wider
- * than one wavefront gather from a ~1 KB window of the parent row.  The Population-level calls (ps_sample_indices,
- * ps_next_generation, ps_step) take and return any order, like the reference's methods: a host that needs the
- * reference's slot order drives those instead of ps_sim_run. */
+ * Row order.  INSIDE, the loop stores the children of a generation in ascending parent order (a stable sort of the N draws
+ * of sample_indices, population.rs:440-443: what lets populations wider than one wavefront gather from a ~1 KB window of the
+ * parent row).  AT THE BOUNDARY every output of the simulation comes in the reference's order: row k of
+ * ps_read_matrix / ps_write / ps_multi_write on the simulation's handles is the child of draw k (main.rs:445-447), the pair
+ * list (main.rs:413-427) and ps_pairwise_counts / _distances on those handles name individuals by that row,
+ * ps_fitness_terms / ps_average_distance return their vectors in it, ps_sim_last_parents returns the draws in draw order.
+ * A direct ps_load_matrix / ps_next_generation / ps_step on a simulation's handle makes the internal order the output order
+ * until the simulation's next generation. */
 int ps_sim_run(ps_sim *s, uint32_t first_generation, uint32_t count);
 int ps_sim_sync(ps_sim *s);
 /* Shard the HGT donors over the site shards of this run (shard_rank / shard_count of the parameters) and exchange the
@@ -338,7 +337,8 @@ ps_population *ps_sim_acc(ps_sim *s);
 const double *ps_sim_selection(ps_sim *s);                     /* pan_size values */
 const uint32_t *ps_sim_range1(ps_sim *s);
 const uint32_t *ps_sim_range2(ps_sim *s);
-/* parent indices of the most recent generation (N values, ascending: see ps_sim_run) */
+/* the draws of the most recent generation in draw order (population.rs:443): out_idx[k] = the output row, in the generation
+ * before, of the parent of this generation's output row k */
 int ps_sim_last_parents(ps_sim *s, uint32_t *out_idx);
 /* Device timing of the core sweep kernel, measured with HIP events on the
  * stream it is launched on, accumulated since the last reset: launches, total

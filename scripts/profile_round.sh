@@ -2,7 +2,7 @@
 # rocprofv3 summaries behind the round's numbers; usage (on the GPU box, from the repo root): scripts/profile_round.sh TAG
 # Leaves gpurun_out/prof_TAG/{cfg2,cfg3,cfg4,cfg4_shard8,cfg5pop,competition,cfg5cli}_kernel_stats.csv + the bench lines
 # of the same commands.  (PMC passes of the sweeps: scripts/pmc_block.sh)
-TAG=${1:-r03}
+TAG=${1:-r06}
 REPO=$(pwd)
 OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p $OUT
