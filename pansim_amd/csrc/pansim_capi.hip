@@ -1817,7 +1817,7 @@ static int ensure_pairs(ps_population *p, uint64_t P)
     p->pairs_cap = 0;
     p->pairs_cached = 0;
     p->pairs_src1 = p->pairs_src2 = nullptr;      // the pointer-identity shortcut of upload_pairs dies with the device copy
-    HIPCHK(hipMalloc(&p->d_pairs, P * 7 * sizeof(uint32_t)));   // r1 | r2 | perm | outA | outB | tstart | tcount
+    HIPCHK(hipMalloc(&p->d_pairs, P * 9 * sizeof(uint32_t)));   // r1 | r2 | perm | outA | outB | tstart | tcount | r1, r2 mapped to internal rows (ps_sim)
     p->pairs_cap = P;
     return PS_OK;
 }
@@ -2998,7 +2998,9 @@ static int sim_create_impl(const ps_sim_params *p, ps_sim *s)
         // Round 6 (bit-sliced level 1, 4-row batches; profiles/r06_sweep_experiments.md): light HGT 5 / 6 / 7 / 8 -> 1966 / 1843 /
         // 1841 / 1829 generations/s (the sweep itself 0.492-0.496 ms at every setting: from 6 on the chain no longer hides
         // behind it); the authors' run 1813 / 1779 / 1618 at 5 / 6 / 7; cfg3 1686 / 1685 / 1683 at 7 / 6 / 8.
-        const uint32_t light = s->heavy_hgt ? 7u : 5u;
+        // With the D-avg of --competition_strength in the chain 3 / 4 / 5 / 6 -> 2027 / 2107 / 1957 / 1786 (round 5's library 2058), the
+        // authors' run 1972 / 1954 at 4 / 5 (1891): 4 (profiles/r06_g_ab_*.json).
+        const uint32_t light = s->heavy_hgt ? 7u : p->competition_strength > 0.0 ? 4u : 5u;
         s->core->sweep_blocks_per_cu = list_lds <= 16 * 1024 ? light : std::min(light, 6u);
     }
     HIPCHK(hipHostMalloc(&s->h_num_genes, N * sizeof(int32_t), hipHostMallocMapped));
@@ -3428,7 +3430,7 @@ static int sim_refresh_rows(void *ctx)
     }
     for (ps_population *p : { s->core, s->acc }) {
         p->row_slot = s->sigma;
-        if (p->cfg.core && !s->sigma.empty()) {
+        if (!s->sigma.empty()) {
             if (!p->d_row_slot) HIPCHK(hipMalloc(&p->d_row_slot, N * sizeof(uint32_t)));
             HIPCHK(hipMemcpyAsync(p->d_row_slot, s->sigma.data(), N * sizeof(uint32_t), hipMemcpyHostToDevice, p->stream));
             HIPCHK(hipStreamSynchronize(p->stream));
@@ -3449,6 +3451,16 @@ extern "C" int ps_sim_last_parents(ps_sim *s, uint32_t *out_idx)
     const uint32_t *d = s->h_draw[s->last_slot];
     for (uint64_t k = 0; k < s->prm.pop_size; k++) out_idx[k] = s->sigma_prev_inv.empty() ? d[k] : s->sigma_prev_inv[d[k]];
     return PS_OK;
+}
+
+// the run's pair list, drawn over the output rows, as internal rows
+__global__ void __launch_bounds__(256) pairs_map_kernel(const uint32_t *r1, const uint32_t *r2, const uint32_t *slot, uint32_t *m1,
+                                                        uint32_t *m2, uint64_t P)
+{
+    const uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= P) return;
+    m1[k] = slot[r1[k]];
+    m2[k] = slot[r2[k]];
 }
 
 // main.rs:467-470 for this process's matrices: both distance kernels chains are enqueued before anything is
@@ -3472,7 +3484,10 @@ static int sim_pair_counts(ps_sim *s, uint32_t **core_cnt, uint32_t **acc_in, ui
     // the pair list names individuals by their output row (main.rs:413-427 draws it once, over the labels 0 .. N - 1)
     const uint32_t *slot = nullptr;
     PSCHK(rows_current(core, &slot));
-    if (slot) {
+    // (mapped on the device from the cached list -- one small kernel per matrix and phase -- unless a tiled sampled kernel
+    // will run, which wants the list sorted by first individual: then on the host, with its tables rebuilt)
+    const bool dev_map = slot && !core_pairs_take_a_tiled_kernel(core, P);
+    if (slot && !dev_map) {
         std::vector<uint32_t> m1(P), m2(P);
         for (uint64_t k = 0; k < P; k++) { m1[k] = slot[s->r1[k]]; m2[k] = slot[s->r2[k]]; }
         PSCHK(upload_pairs(core, P, m1.data(), m2.data()));
@@ -3482,15 +3497,22 @@ static int sim_pair_counts(ps_sim *s, uint32_t **core_cnt, uint32_t **acc_in, ui
         PSCHK(upload_pairs(acc, P, s->r1.data(), s->r2.data(), true));
     }
     uint32_t *c1 = (uint32_t *)core->d_pairs, *a1 = (uint32_t *)acc->d_pairs;
+    uint32_t *c_r1 = c1, *c_r2 = c1 + P, *a_r1 = a1, *a_r2 = a1 + P;
+    if (dev_map) {
+        c_r1 = c1 + 7 * P; c_r2 = c1 + 8 * P; a_r1 = a1 + 7 * P; a_r2 = a1 + 8 * P;
+        pairs_map_kernel<<<(uint32_t)((P + 255) / 256), 256, 0, core->stream>>>(c1, c1 + P, core->d_row_slot, c_r1, c_r2, P);
+        pairs_map_kernel<<<(uint32_t)((P + 255) / 256), 256, 0, acc->stream>>>(a1, a1 + P, acc->d_row_slot, a_r1, a_r2, P);
+        HIPCHK(hipGetLastError());
+    }
     // everything the generation loop queued on either stream precedes the distance kernels of both
     HIPCHK(hipStreamSynchronize(acc->stream));
     HIPCHK(hipStreamSynchronize(core->stream));
     HIPCHK(hipEventRecord(s->ev_dist[0], core->stream));
-    PSCHK(pair_counts_device(core, P, c1, c1 + P, c1 + 2 * P, c1 + 3 * P, c1 + 4 * P, core->stream));
+    PSCHK(pair_counts_device(core, P, c_r1, c_r2, c1 + 2 * P, c1 + 3 * P, c1 + 4 * P, core->stream));
     HIPCHK(hipEventRecord(s->ev_dist[1], core->stream));
     HIPCHK(hipMemcpyAsync(s->h_cnt, c1 + 3 * P, P * 4, hipMemcpyDeviceToHost, core->stream));
     HIPCHK(hipEventRecord(s->ev_dist[2], acc->stream));
-    if (acc->cfg.ncols) PSCHK(pair_counts_device(acc, P, a1, a1 + P, a1 + 2 * P, a1 + 3 * P, a1 + 4 * P, acc->stream));
+    if (acc->cfg.ncols) PSCHK(pair_counts_device(acc, P, a_r1, a_r2, a1 + 2 * P, a1 + 3 * P, a1 + 4 * P, acc->stream));
     else HIPCHK(hipMemsetAsync(a1 + 3 * P, 0, 2 * P * 4, acc->stream));
     HIPCHK(hipEventRecord(s->ev_dist[3], acc->stream));
     HIPCHK(hipMemcpyAsync(s->h_cnt + P, a1 + 3 * P, 2 * P * 4, hipMemcpyDeviceToHost, acc->stream));

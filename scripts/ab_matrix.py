@@ -10,6 +10,12 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 cfg, rounds = sys.argv[1], int(sys.argv[2])
+extra = []
+if "+" in cfg:                   # e.g. cfg2+competition_strength=10: further bench.py flags
+    cfg, rest = cfg.split("+", 1)
+    for kv in rest.split("+"):
+        k, v = kv.split("=", 1)
+        extra += ["--" + k, v]
 arms = []
 for spec in sys.argv[3:]:
     name, rest = spec.split("=", 1)
@@ -23,7 +29,7 @@ for r in range(rounds):
         if lib != "default":
             env["PANSIM_HIP_LIBRARY"] = os.path.join(ROOT, lib)
         out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--config", cfg, "--no-cpu-baseline", "--no-other-configs",
-                              "--steps", "200" if cfg in ("cfg2", "cfg3", "authors") else "20", "--warmup", "10", "--max_distances", "1000"],
+                              "--steps", "200" if cfg in ("cfg2", "cfg3", "authors") else "20", "--warmup", "10", "--max_distances", "1000"] + extra,
                              capture_output=True, text=True, env=env).stdout.strip().splitlines()
         try:
             d = json.loads(out[-1])
@@ -37,4 +43,4 @@ for name in res:
     for k in ("sweep_ms", "period_ms", "value"):
         if res[name][k]:
             res[name][k + "_median"] = statistics.median(res[name][k])
-print(json.dumps({"config": cfg, "rounds": rounds, "arms": res}))
+print(json.dumps({"config": cfg, "extra": extra, "rounds": rounds, "arms": res}))
