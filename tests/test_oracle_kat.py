@@ -245,3 +245,27 @@ def test_spec_regression_vectors(orc):
         assert [int(x) for x in sim.last_idx[:8]] == s["first_parents"]
         assert [int(x) for x in sim.core[0, :16]] == s["core_row0"]
         assert [int(x) for x in sim.acc[0, :16]] == s["acc_row0"]
+
+
+def test_oracle_loop_speaks_draw_order_at_its_boundary():
+    # tests/orc_sim.py keeps its rows in ascending parent order inside (like the library's engine) and presents them in the
+    # reference's order: with every rate at zero a generation is a pure gather, so row k must be row last_idx[k] of the
+    # generation before (population.rs:443, main.rs:445-447) -- the same property the GPU suite checks on the library
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from orc_sim import OracleSim
+    sim = OracleSim(seed=3, pop_size=60, core_size=40, pan_genes=50, core_genes=10, core_mu=0.0, HR_rate=0.0, HGT_rate=0.0,
+                    rate_genes1=0.0, rate_genes2=0.0)
+    rng = np.random.default_rng(1)
+    sim.core = (1 << rng.integers(0, 4, (60, 40))).astype(np.uint8)
+    sim.acc = (rng.random((60, 40)) < 0.5).astype(np.uint8)
+    core, acc = sim.core.copy(), sim.acc.copy()
+    unsorted_seen = False
+    for g in range(4):
+        sim.generation(g)
+        par = sim.last_idx
+        unsorted_seen |= bool((np.diff(par.astype(np.int64)) < 0).any())
+        assert (np.diff(sim.internal_idx.astype(np.int64)) >= 0).all()
+        assert np.array_equal(sim.core, core[par]) and np.array_equal(sim.acc, acc[par])
+        core, acc = sim.core.copy(), sim.acc.copy()
+    assert unsorted_seen
