@@ -367,6 +367,9 @@ __device__ __forceinline__ uint32_t ps_pack4(uint32_t b0, uint32_t b1, uint32_t 
 #ifndef PS_WAVE_LB
 #define PS_WAVE_LB 6      // waves per SIMD the wave sweep is built for (8 = 64 VGPRs, 7 = 72, 6 = 80)
 #endif
+#ifndef PS_WAVE_PREFETCH
+#define PS_WAVE_PREFETCH 0   // 1: the rows of a wave's next batch are requested behind the push of the current one (16 more registers)
+#endif
 // LDS of one wave: 4 child rows and the queue (a.qcap 16-bit entries)
 __host__ __device__ constexpr uint32_t ps_queue_bytes(uint32_t qcap) { return (qcap * 2u + 15u) & ~15u; }
 __host__ __device__ constexpr uint32_t ps_wave_lds(uint32_t qcap) { return PS_BATCH_ROWS * 1024u + ps_queue_bytes(qcap); }
@@ -425,6 +428,12 @@ __global__ void __launch_bounds__(256, PS_WAVE_LB) core_sweep_wave_kernel(core_s
     if (blockIdx.x < 8u && threadIdx.x == 0) a.work_ctr[((a.launch_parity ^ 1u) * 8u + blockIdx.x) * 32u] = 0u;
     uint32_t next_chunk = 0;
     if (lane == 0) next_chunk = __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#if PS_WAVE_PREFETCH
+    uint4 vn[PS_ROWS];                  // the next batch's rows, in flight
+    uint32_t pf_batch = 0xFFFFFFFFu;    // ... and which batch they belong to
+#pragma unroll
+    for (uint32_t rr = 0; rr < PS_ROWS; rr++) vn[rr] = make_uint4(0, 0, 0, 0);
+#endif
     for (;;) {
         const uint32_t chunk = __builtin_amdgcn_readfirstlane(next_chunk);
         if (b_lo + chunk * PS_CHUNK >= b_hi) break;
@@ -438,6 +447,13 @@ __global__ void __launch_bounds__(256, PS_WAVE_LB) core_sweep_wave_kernel(core_s
         const uint32_t sg = g0 + batch;                 // global site group: sites 4 sg .. 4 sg + 3
         auto lrow = [&](uint32_t rr) -> uint32_t { return (uint32_t)min(max(lr0 + (int)rr, 0), (int)a.rows - 1); };
         uint4 v[PS_ROWS];
+#if PS_WAVE_PREFETCH
+        // (rows of this batch were requested while the previous batch's residual cells were worked on)
+        if (pf_batch == batch) {
+#pragma unroll
+            for (uint32_t rr = 0; rr < PS_ROWS; rr++) v[rr] = vn[rr];
+        } else
+#endif
 #pragma unroll
         for (uint32_t rr = 0; rr < PS_ROWS; rr++)
             v[rr] = ps_load_row16(a.state + (size_t)lrow(rr) * a.pitch + ld_off, NT);
@@ -494,6 +510,21 @@ __global__ void __launch_bounds__(256, PS_WAVE_LB) core_sweep_wave_kernel(core_s
         if (events) qn = ps_push_scan(wl[0], wl[1], q, lane, qcap);
         PS_T(3);   // queue push
         ps_wave_sync();
+#if PS_WAVE_PREFETCH
+        {
+            // the rows of the wave's NEXT batch -- the next one of this chunk, or the first one of the chunk it has already
+            // been handed -- requested now, in flight behind the exact pass and the stores of this batch
+            uint32_t nb = batch + 1u;
+            if (cb + 1u >= PS_CHUNK || nb >= b_hi) nb = b_lo + (uint32_t)__builtin_amdgcn_readfirstlane(next_chunk) * PS_CHUNK;
+            pf_batch = nb < b_hi ? nb : 0xFFFFFFFFu;
+            if (nb < b_hi) {
+                const int nlr0 = (int)(nb * PS_ROWS) - (int)off;
+#pragma unroll
+                for (uint32_t rr = 0; rr < PS_ROWS; rr++)
+                    vn[rr] = ps_load_row16(a.state + (size_t)(uint32_t)min(max(nlr0 + (int)rr, 0), (int)a.rows - 1) * a.pitch + ld_off, NT);
+            }
+        }
+#endif
         // (HR parks a second 16-bit word per residual cell in the queue's upper half, mirrored: entry e at qcap - 1 - e)
         const bool redo = events && (qn > qcap || (DO_HR && 2u * qn > qcap));       // wave-uniform
         // Queue overflow (the host sizes the queue for mean + 10 sigma of the entry count, so this is a

@@ -2186,6 +2186,42 @@ static int pair_counts_device(ps_population *p, uint64_t P, const uint32_t *d_r1
     return PS_OK;
 }
 
+// the run's pair list, drawn over the output rows, as internal rows (DESIGN.md 3.5)
+__global__ void __launch_bounds__(256) pairs_map_kernel(const uint32_t *r1, const uint32_t *r2, const uint32_t *slot, uint32_t *m1,
+                                                        uint32_t *m2, uint64_t P)
+{
+    const uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= P) return;
+    m1[k] = slot[r1[k]];
+    m2[k] = slot[r2[k]];
+}
+
+// The device copy of a pair list whose individuals are named by OUTPUT rows (a ps_sim's handle after a generation), as the
+// kernels want it: internal rows.  Mapped on the device from the cached upload by one small kernel -- unless a tiled sampled
+// kernel will run, which wants the list sorted by first individual: then mapped on the host and uploaded with its tables.
+static int pairs_for_launch(ps_population *p, uint64_t P, const uint32_t *r1, const uint32_t *r2, bool trusted, const uint32_t *slot,
+                            uint32_t **d_r1, uint32_t **d_r2, hipStream_t st)
+{
+    const bool dev_map = slot && !core_pairs_take_a_tiled_kernel(p, P);
+    if (slot && !dev_map) {
+        std::vector<uint32_t> m1(P), m2(P);
+        for (uint64_t k = 0; k < P; k++) { m1[k] = slot[r1[k]]; m2[k] = slot[r2[k]]; }
+        PSCHK(upload_pairs(p, P, m1.data(), m2.data()));
+    } else {
+        PSCHK(upload_pairs(p, P, r1, r2, trusted));
+    }
+    uint32_t *d = (uint32_t *)p->d_pairs;
+    *d_r1 = d;
+    *d_r2 = d + P;
+    if (dev_map) {
+        *d_r1 = d + 7 * P;
+        *d_r2 = d + 8 * P;
+        pairs_map_kernel<<<(uint32_t)((P + 255) / 256), 256, 0, st>>>(d, d + P, p->d_row_slot, *d_r1, *d_r2, P);
+        HIPCHK(hipGetLastError());
+    }
+    return PS_OK;
+}
+
 extern "C" int ps_pairwise_counts(ps_population *p, uint64_t P, const uint32_t *range1, const uint32_t *range2,
                                   uint32_t *out_a, uint32_t *out_b, int out_is_device)
 {
@@ -2199,15 +2235,10 @@ extern "C" int ps_pairwise_counts(ps_population *p, uint64_t P, const uint32_t *
     PSCHK(use_device(p));
     const uint32_t *slot = nullptr;
     PSCHK(rows_current(p, &slot));
-    if (slot) {
-        // individuals are named by their output row (the child of draw k): their internal rows
-        std::vector<uint32_t> m1(P), m2(P);
-        for (uint64_t k = 0; k < P; k++) { m1[k] = slot[range1[k]]; m2[k] = slot[range2[k]]; }
-        PSCHK(upload_pairs(p, P, m1.data(), m2.data()));
-    } else {
-        PSCHK(upload_pairs(p, P, range1, range2));
-    }
-    uint32_t *d_r1 = (uint32_t *)p->d_pairs, *d_r2 = d_r1 + P, *d_perm = d_r2 + P, *d_a = d_perm + P, *d_b = d_a + P;
+    // (individuals are named by their output row -- the child of draw k -- on a ps_sim's handle: their internal rows)
+    uint32_t *d_r1 = nullptr, *d_r2 = nullptr;
+    PSCHK(pairs_for_launch(p, P, range1, range2, false, slot, &d_r1, &d_r2, p->stream));
+    uint32_t *d_perm = (uint32_t *)p->d_pairs + 2 * P, *d_a = d_perm + P, *d_b = d_a + P;
     uint32_t *ka = out_is_device ? out_a : d_a;
     uint32_t *kb = out_is_device ? out_b : d_b;
     PSCHK(pair_counts_device(p, P, d_r1, d_r2, d_perm, ka, kb, p->stream));
@@ -2995,12 +3026,12 @@ static int sim_create_impl(const ps_sim_params *p, ps_sim *s)
         // (cfg2) 4 / 5 / 6 / 7 -> 1993 / 2080 / 2093 / 1972 generations/s; with the D-avg of --competition_strength in the
         // chain 1957 / 2007 / 1921 / 1848 (the authors' run 1942 / 1897 / 1841 / 1692); sweep and HGT in turns (cfg3)
         // - / 1537 / 1617 / 1645.
-        // Round 6 (bit-sliced level 1, 4-row batches; profiles/r06_sweep_experiments.md): light HGT 5 / 6 / 7 / 8 -> 1966 / 1843 /
-        // 1841 / 1829 generations/s (the sweep itself 0.492-0.496 ms at every setting: from 6 on the chain no longer hides
-        // behind it); the authors' run 1813 / 1779 / 1618 at 5 / 6 / 7; cfg3 1686 / 1685 / 1683 at 7 / 6 / 8.
-        // With the D-avg of --competition_strength in the chain 3 / 4 / 5 / 6 -> 2027 / 2107 / 1957 / 1786 (round 5's library 2058), the
-        // authors' run 1972 / 1954 at 4 / 5 (1891): 4 (profiles/r06_g_ab_*.json).
-        const uint32_t light = s->heavy_hgt ? 7u : p->competition_strength > 0.0 ? 4u : 5u;
+        // Round 6 (bit-sliced level 1, symbol-decided mutations in registers, 4-row batches; profiles/r06_sweep_experiments.md
+        // 5): the sweep is bound by its access pattern, and the fewer of its workgroups sit on a CU the more of the chain runs beside
+        // it -- cfg2 3 / 4 / 5 -> 2070 / 2121 / 2093 generations/s (6 / 7 / 8 on another box: 1843 / 1841 / 1829 against 1966 at 5);
+        // cfg3 (sweep and HGT in turns) 3 / 4 / 5 / 6 / 7 -> 1693 / 1871 / 1836 / 1700 / 1725; with the D-avg of
+        // --competition_strength in the chain 3 / 4 / 5 / 6 -> 2027 / 2107 / 1957 / 1786; the authors' run 1972 / 1954 at 4 / 5.
+        const uint32_t light = 4u;
         s->core->sweep_blocks_per_cu = list_lds <= 16 * 1024 ? light : std::min(light, 6u);
     }
     HIPCHK(hipHostMalloc(&s->h_num_genes, N * sizeof(int32_t), hipHostMallocMapped));
@@ -3453,16 +3484,6 @@ extern "C" int ps_sim_last_parents(ps_sim *s, uint32_t *out_idx)
     return PS_OK;
 }
 
-// the run's pair list, drawn over the output rows, as internal rows (DESIGN.md 3.5)
-__global__ void __launch_bounds__(256) pairs_map_kernel(const uint32_t *r1, const uint32_t *r2, const uint32_t *slot, uint32_t *m1,
-                                                        uint32_t *m2, uint64_t P)
-{
-    const uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= P) return;
-    m1[k] = slot[r1[k]];
-    m2[k] = slot[r2[k]];
-}
-
 // main.rs:467-470 for this process's matrices: both distance kernels chains are enqueued before anything is
 // waited for (core on the core stream, accessory on its own), the numerators come back through pinned memory,
 // and the reference's f64 expressions run on the host.  With site shards the core numerators of this call
@@ -3484,26 +3505,10 @@ static int sim_pair_counts(ps_sim *s, uint32_t **core_cnt, uint32_t **acc_in, ui
     // the pair list names individuals by their output row (main.rs:413-427 draws it once, over the labels 0 .. N - 1)
     const uint32_t *slot = nullptr;
     PSCHK(rows_current(core, &slot));
-    // (mapped on the device from the cached list -- one small kernel per matrix and phase -- unless a tiled sampled kernel
-    // will run, which wants the list sorted by first individual: then on the host, with its tables rebuilt)
-    const bool dev_map = slot && !core_pairs_take_a_tiled_kernel(core, P);
-    if (slot && !dev_map) {
-        std::vector<uint32_t> m1(P), m2(P);
-        for (uint64_t k = 0; k < P; k++) { m1[k] = slot[s->r1[k]]; m2[k] = slot[s->r2[k]]; }
-        PSCHK(upload_pairs(core, P, m1.data(), m2.data()));
-        PSCHK(upload_pairs(acc, P, m1.data(), m2.data()));
-    } else {
-        PSCHK(upload_pairs(core, P, s->r1.data(), s->r2.data(), true));
-        PSCHK(upload_pairs(acc, P, s->r1.data(), s->r2.data(), true));
-    }
+    uint32_t *c_r1 = nullptr, *c_r2 = nullptr, *a_r1 = nullptr, *a_r2 = nullptr;
+    PSCHK(pairs_for_launch(core, P, s->r1.data(), s->r2.data(), true, slot, &c_r1, &c_r2, core->stream));
+    PSCHK(pairs_for_launch(acc, P, s->r1.data(), s->r2.data(), true, slot, &a_r1, &a_r2, acc->stream));
     uint32_t *c1 = (uint32_t *)core->d_pairs, *a1 = (uint32_t *)acc->d_pairs;
-    uint32_t *c_r1 = c1, *c_r2 = c1 + P, *a_r1 = a1, *a_r2 = a1 + P;
-    if (dev_map) {
-        c_r1 = c1 + 7 * P; c_r2 = c1 + 8 * P; a_r1 = a1 + 7 * P; a_r2 = a1 + 8 * P;
-        pairs_map_kernel<<<(uint32_t)((P + 255) / 256), 256, 0, core->stream>>>(c1, c1 + P, core->d_row_slot, c_r1, c_r2, P);
-        pairs_map_kernel<<<(uint32_t)((P + 255) / 256), 256, 0, acc->stream>>>(a1, a1 + P, acc->d_row_slot, a_r1, a_r2, P);
-        HIPCHK(hipGetLastError());
-    }
     // everything the generation loop queued on either stream precedes the distance kernels of both
     HIPCHK(hipStreamSynchronize(acc->stream));
     HIPCHK(hipStreamSynchronize(core->stream));
