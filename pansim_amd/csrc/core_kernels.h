@@ -215,12 +215,13 @@ __global__ void __launch_bounds__(1024) core_sweep_inline_kernel(core_sweep_args
 // A wave takes the 4 site rows of one GLOBAL site group (sites 4g .. 4g + 3: the unit the level-1 blocks are keyed by,
 // ps_common.h) per iteration; their loads are in flight together and the 16 parent indices of a lane are shared by all
 // rows.  Events are sparse (about 5 % of the cells at the default rates), so
-//   1. per batch, THREE Philox calls per lane give the six symbol planes of its 4 x 16 cells; the cells whose symbol can
-//      hold an event are three boolean operations on the plane words of a row pair (no per-cell arithmetic at all);
-//   2. one prefix sum over the wave pushes EVERY such cell of the 4 rows into a wave-private LDS queue, each entry with
-//      the low three bits of its symbol (ps_push_scan: nothing is decided at push time);
-//   3. a dense pass, 64 entries at a time with every lane busy, writes the alleles the symbols decide into the LDS rows
-//      and compacts the residual cells in place;
+//   1. per batch, THREE Philox calls per lane give the six symbol planes of its 4 x 16 cells; per row pair three boolean
+//      operations on the plane words give the DECIDED cells (the symbol names an allele) and the RESIDUAL ones (no
+//      per-cell arithmetic at all: ps_classes);
+//   2. the symbol-decided mutations -- three of four events -- are applied in registers to the gathered child dwords
+//      before they go back to LDS (ps_apply_prepare / ps_apply_dword: byte-lane flags, two v_perm_b32 look-ups, one v_bfi);
+//   3. one prefix sum over the wave pushes the residual cells of the 4 rows into a wave-private LDS queue of 16-bit
+//      entries (ps_push_scan);
 //   4. an exact pass over the residual cells: level-2 Philox, 32-bit thresholds, mutation bytes into the LDS rows; HR
 //      donors are read from the post-mutation rows and written back after all reads.
 // The host only selects this kernel when the queue cannot overflow in practice (mean + 10 sigma of the entry count

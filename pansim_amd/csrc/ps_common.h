@@ -56,7 +56,7 @@ PS_HD ps_u4 ps_philox_r(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint
     return o;
 }
 
-// Philox4x32-10: every stream of the build except the core level-1 bytes
+// Philox4x32-10: every stream of the build
 PS_HD ps_u4 ps_philox(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1)
 {
     return ps_philox_r<10>(c0, c1, c2, c3, k0, k1);
@@ -104,7 +104,7 @@ struct ps_core_plan {
     uint32_t has_events;
     uint32_t k, R;
     uint32_t cshift;      // 0..4 (4: every cell is a candidate)
-    uint32_t lut8;        // 4-bit code per symbol s < 8: the allele (2 / 4 / 8), 1 = residual, 0 = nothing
+    uint32_t lut8;        // 4-bit code per symbol s < 8: the allele (2 / 4 / 8), 1 = residual, 0 = nothing (the block sweep's dense pass)
 };
 
 // what a symbol decides: 2 / 4 / 8 = that allele, 1 = residual, 0 = nothing
