@@ -935,13 +935,13 @@ __global__ void __launch_bounds__(256, PS_WLB) core_sweep_window_kernel(core_swe
 // splits them into 1024-cell segments.  A wave takes PS_SB consecutive segments per
 // iteration and treats them like the wave-per-row sweep treats its rows: the symbol planes of
 // the slot (two Philox blocks per segment here: a slot is ONE site of a block pair's two / four),
-// ONE wave-private candidate queue for the whole batch, dense symbol classification, one exact
-// level-2 pass with (nearly) every lane busy.
+// the symbol-decided mutations in registers, ONE wave-private queue of the batch's residual cells,
+// one exact level-2 pass.
 // A mutation only touches cells of the wave's own segments, so it needs no block barrier;
 // cells that receive a donor allele are collected in a per-wave HR list, and the donor
 // reads / writes happen between block barriers once every segment of the row group has
 // been mutated (the donor may sit in any segment).
-// Queue entry: LDS byte offset of the cell in rowS (20 bits) | low three bits of the symbol << 20 | slot << 28.
+// Queue entry (residual cells only): LDS byte offset of the cell in rowS (20 bits) | slot << 28.
 // ---------------------------------------------------------------------------
 #define PS_PF 4u   // prefetch registers (uint4) per thread: pf0..pf3 in the kernel
 // Workgroup barrier that orders LDS traffic only: outstanding global loads (the prefetch of the
@@ -988,7 +988,7 @@ __global__ void __launch_bounds__(1024) core_sweep_block_kernel(core_sweep_args 
     // (the last entry of an HR list is never used: the last wave's holds the overflow word, see block_sweep_geometry)
     const uint32_t qcap = a.qcap_limit ? min(g.QW, a.qcap_limit) : g.QW, hcap = a.qcap_limit ? min(g.HW - 1u, a.qcap_limit) : g.HW - 1u;
     if (tid == 0) *ovf = 0u;        // (ordered before any use by the barrier that follows the first staging)
-    const uint32_t lut = pl.lut8;       // (the host launches this kernel for plans with cshift <= 1: symbols below 8)
+    const uint32_t nE = 3u * pl.k + pl.R;       // (the host launches this kernel for the plans of the wave sweep: cshift <= 1, k <= 1)
     // (row, segment) of the first item of this wave's first batch, and the batch-to-batch stride
     const uint32_t first_rr = (wave * PS_SB) / g.segs, first_sg = (wave * PS_SB) % g.segs;
     const uint32_t step_rr = (nw * PS_SB) / g.segs, step_sg = (nw * PS_SB) % g.segs;
@@ -1051,7 +1051,6 @@ __global__ void __launch_bounds__(1024) core_sweep_block_kernel(core_sweep_args 
             uint32_t s_base[PS_SB], s_site[PS_SB];   // wave-uniform per slot: LDS offset of the row, site
             uint32_t s_seg[PS_SB];                   // LDS offset of the slot's segment
             uint32_t cmv[PS_SB];                     // candidate masks of the batch (one push loop for all slots)
-            uint32_t p4v[PS_SB], p5v[PS_SB], nv[PS_SB];   // plane words 4, 5 and 0 of the slot's site pair
             uint32_t qn = 0;
             uint32_t rr = rr0, sg = sg0;
             // FULL (wave-uniform): every slot of the batch exists and every lane of every segment holds a chunk
@@ -1064,7 +1063,6 @@ __global__ void __launch_bounds__(1024) core_sweep_block_kernel(core_sweep_args 
                 s_seg[s] = rr * a.pitch + sg * 1024u;
                 s_site[s] = a.site_offset + r0 + rr;
                 cmv[s] = 0u;
-                p4v[s] = p5v[s] = nv[s] = 0u;
                 if (FULL || item0 + s < items) {
                     // lanes past the row (chunk >= cpr) compute on the row's last chunk and only their LDS store is
                     // masked; their candidate mask is empty (no valid cells)
@@ -1092,18 +1090,29 @@ __global__ void __launch_bounds__(1024) core_sweep_block_kernel(core_sweep_args 
                                 ip += 4u * a.cpr;
                             }
                         }
-                        if (has_chunk) *(uint4 *)(row + i0) = make_uint4(w[0], w[1], w[2], w[3]);
+                    } else if (events && DO_MUT) {
+                        const uint4 cur = *(const uint4 *)(row + chunkc * 16u);      // the row itself (staged)
+                        w[0] = cur.x; w[1] = cur.y; w[2] = cur.z; w[3] = cur.w;
                     }
                     if (events) {
+                        // the slot is ONE site of a block pair's two / four: both blocks, this site's half of the words
                         const uint32_t vcell = FULL ? 0xFFFFFFFFu : PRE ? vperm_pre[s] : ps_valid_cells(i0, a.N);
                         const uint32_t site = s_site[s];
                         const ps_u4 A = ps_philox_l1a(site >> 1, chunk, a.gen, a.k0, a.k1);
                         const ps_u4 B = ps_philox_l1b(site >> 2, chunk, a.gen, a.k0, a.k1);
-                        cmv[s] = ps_cand_word(A, site, pl.cshift) & vcell;
-                        nv[s] = A.x;
-                        p4v[s] = (site & 2u) ? B.y : B.x;
-                        p5v[s] = (site & 2u) ? B.w : B.z;
+                        const uint32_t p4w = (site & 2u) ? B.y : B.x, p5w = (site & 2u) ? B.w : B.z;
+                        const ps_class_words cw = ps_classes(A.x, A.y, A.z, A.w, p4w, p5w, pl.k, nE, vcell & ps_site_bits(site));
+                        cmv[s] = cw.res;
+                        if (DO_MUT) {
+                            // the symbol-decided mutations in registers (see the wave sweep)
+                            const ps_apply_words y = ps_apply_prepare(cw.dec, p4w & cw.dec, p5w & cw.dec);
+                            uint4 d = make_uint4(w[0], w[1], w[2], w[3]);
+                            if (site & 1u) ps_apply_row<1u>(y, d);
+                            else ps_apply_row<0u>(y, d);
+                            w[0] = d.x; w[1] = d.y; w[2] = d.z; w[3] = d.w;
+                        }
                     }
+                    if ((DO_GATHER || (events && DO_MUT)) && has_chunk) *(uint4 *)(row + i0) = make_uint4(w[0], w[1], w[2], w[3]);
                 }
                 if (++sg == g.segs) { sg = 0; rr++; }
             };
@@ -1117,7 +1126,7 @@ __global__ void __launch_bounds__(1024) core_sweep_block_kernel(core_sweep_args 
             PS_T(1);   // gather + level-1 Philox + child store (all slots)
             if (events) {
                 // ONE push loop for the batch: its trip count is the largest number of candidates any lane holds in
-                // one segment, not the sum over the segments.  The entry carries the low three bits of the symbol.
+                // one segment, not the sum over the segments.
                 for (;;) {
                     uint32_t any = cmv[0];
 #pragma unroll
@@ -1131,8 +1140,7 @@ __global__ void __launch_bounds__(1024) core_sweep_block_kernel(core_sweep_args 
                             const uint32_t p = __builtin_ctz(cmv[s]);
                             cmv[s] &= cmv[s] - 1u;
                             const uint32_t pos = qn + ps_lane_prefix(bal);
-                            const uint32_t sym = ((p4v[s] >> p) & 1u) | (((p5v[s] >> p) & 1u) << 1) | (((nv[s] >> p) & 1u) << 2);
-                            if (pos < g.QW) q[pos] = (s_seg[s] + lane * 16u + ps_bit_cell(p)) | (sym << 20) | (s << 28);
+                            if (pos < g.QW) q[pos] = (s_seg[s] + lane * 16u + ps_bit_cell(p)) | (s << 28);
                         }
                         qn += (uint32_t)__popcll(bal);
                     }
@@ -1149,21 +1157,8 @@ __global__ void __launch_bounds__(1024) core_sweep_block_kernel(core_sweep_args 
                 if (lane == 0) *ovf = 1u;
                 continue;
             }
-            // dense pass: symbol-decided mutations; the residual cells compacted in place
-            uint32_t n2 = 0;
-            for (uint32_t base = 0; base < qn; base += 64u) {
-                const uint32_t e = base + lane;
-                const bool valid = e < qn;
-                const uint32_t ent = valid ? q[e] : 0u;
-                const uint32_t code = valid ? (lut >> (4u * ((ent >> 20) & 7u))) & 15u : 0u;
-                const bool amb = (code & 1u) != 0u;
-                if (DO_MUT && (code & 14u)) rowS[ent & 0xFFFFFu] = (uint8_t)code;
-                const uint64_t bal = __builtin_amdgcn_ballot_w64(amb);
-                if (amb) q[n2 + ps_lane_prefix(bal)] = ent;
-                n2 += (uint32_t)__popcll(bal);
-            }
-            ps_wave_sync();
-            PS_T(3);   // dense pass
+            const uint32_t n2 = qn;      // (only residual cells are queued: the symbol-decided mutations were applied in registers)
+            PS_T(3);
             // exact pass
             for (uint32_t base = 0; base < n2; base += 64u) {
                 const uint32_t e = base + lane;

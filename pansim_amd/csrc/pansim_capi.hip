@@ -173,8 +173,6 @@ static void make_core_plan(double lam_mut, double lam_hr, uint64_t L, ps_core_pl
     uint32_t cs = 0;
     while (cs < 4u && 3u * k + R > (4u << cs)) cs++;
     plan->cshift = cs;
-    plan->lut8 = 0u;
-    for (uint32_t sy = 0; sy < 8u; sy++) plan->lut8 |= ps_sym_code(sy, *plan) << (4u * sy);
 }
 
 static uint32_t acc_flip_threshold(double lam, uint64_t n_genes)
@@ -772,7 +770,7 @@ static bool block_sweep_geometry(const ps_population *p, bool ga, bool mu, bool 
 {
     const ps_core_plan &pl = p->cplan;
     const bool events = pl.has_events && (mu || hr);
-    if (events && pl.cshift > 1u) return false;       // (its queue entries carry three symbol bits)
+    if (events && (pl.cshift > 1u || pl.k > 1u)) return false;       // (the plans of the wave sweep: sweep_queue_entries)
     g->segs = (p->cpr + 63u) / 64u;
     auto up16 = [](double x) { return (uint32_t)(((uint64_t)std::ceil(x) + 15u) & ~15ull); };
     const double hr_frac = (events && hr) ? (double)(pl.T[6] - pl.T[2]) / 4294967296.0 * (double)pl.R / 64.0 : 0.0;
@@ -785,7 +783,8 @@ static bool block_sweep_geometry(const ps_population *p, bool ga, bool mu, bool 
         if (p->block_waves) nw = p->block_waves;
         *waves = nw;
         g->SB = SB;
-        const double mq = events ? SB * 1024.0 * (pl.cshift ? 0.125 : 0.0625) : 0.0;
+        // (only the residual cells are queued -- R / 64 of the cells; a full queue only sends the row group to the queue-free redo)
+        const double mq = events ? SB * 1024.0 * (double)pl.R / 64.0 : 0.0;
         g->QW = std::max(64u, up16(mq + 10.0 * std::sqrt(mq)));
         for (uint32_t R = std::max(1u, nw * SB / std::max(1u, g->segs)); R >= 1; R >>= 1) {
             const uint32_t batches_per_wave = (R * g->segs + nw * SB - 1u) / (nw * SB);

@@ -104,7 +104,6 @@ struct ps_core_plan {
     uint32_t has_events;
     uint32_t k, R;
     uint32_t cshift;      // 0..4 (4: every cell is a candidate)
-    uint32_t lut8;        // 4-bit code per symbol s < 8: the allele (2 / 4 / 8), 1 = residual, 0 = nothing (the block sweep's dense pass)
 };
 
 // what a symbol decides: 2 / 4 / 8 = that allele, 1 = residual, 0 = nothing
