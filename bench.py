@@ -357,13 +357,17 @@ def distance_roofline(form, N, L_local, G_acc, P, core_ms, acc_ms):
         out.update({"regime": "i (matrix transposed once to 2-bit strings, two strings streamed per pair)", "bound": "hbm",
                     "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                     "algorithmic_bytes": alg})
-    elif form in (6, 7):
-        # all pairs on the matrix cores: N (N - 1) / 2 pairs x L sites x 4 one-hot products, 2 operations each
+    elif form in (6, 7, 8):
+        # all pairs on the matrix cores: N (N - 1) / 2 pairs x L sites x 4 one-hot products, 2 operations each.  Form 8 (round 6)
+        # gets the same counts from 3 products per site (+-1 features): it is priced on the SAME 4-product operation count, so
+        # that `frac` stays comparable across the forms -- `products_per_site_issued` says what the matrix cores really ran
         ops = float(N) * (N - 1) / 2.0 * L_local * 4.0 * 2.0
         ach = ops / kms / 1e12
         peak = MFMA_I8_PEAK_TOPS if form == 6 else MFMA_FP4_PEAK_TOPS
         out.update({"regime": ("all pairs, one-hot X X^T on v_mfma_i32_32x32x32_i8 (exact i32 counts), then lookup" if form == 6 else
-                               "all pairs, one-hot X X^T on v_mfma_scale_f32_32x32x64_f8f6f4 (E2M1 {0, 1}, scales 2^0; exact f32 counts), then lookup"),
+                               "all pairs, one-hot X X^T on v_mfma_scale_f32_32x32x64_f8f6f4 (E2M1 {0, 1}, scales 2^0; exact f32 counts), then lookup" if form == 7 else
+                               "all pairs, three +-1 features per site on v_mfma_scale_f32_32x32x64_f8f6f4 (E2M1 +-1, scales 2^0; S = 4 matches - sites, exact f32 sums), then lookup"),
+                    "products_per_site_issued": 3 if form == 8 else 4,
                     "bound": "mfma-i8" if form == 6 else "mfma-fp4", "achieved": ach, "peak": peak, "unit": "TOP/s", "frac": ach / peak,
                     "pair_sites_per_s": float(N) * (N - 1) / 2.0 * L_local / kms,
                     # the same time priced three ways: `frac` counts the N (N - 1) / 2 distinct pairs; the kernel computes whole

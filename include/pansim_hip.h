@@ -160,7 +160,8 @@ enum {
     PS_PAIR_FORM_ROWS = 4,       /* matrix transposed once to bit strings, two strings streamed per pair (HBM bound) */
     PS_PAIR_FORM_SIMPLE = 5,     /* one thread per pair on the byte matrix (matrices with bytes above 15) */
     PS_PAIR_FORM_ALLPAIRS_MFMA = 6, /* all-pairs one-hot X X^T on the i8 matrix cores (exact i32 counts), then lookup */
-    PS_PAIR_FORM_ALLPAIRS_MFMA_FP4 = 7 /* the same on the block-scaled FP4 path (E2M1 {0, 1}, scales 2^0; exact f32 counts) */
+    PS_PAIR_FORM_ALLPAIRS_MFMA_FP4 = 7, /* the same on the block-scaled FP4 path (E2M1 {0, 1}, scales 2^0; exact f32 counts) */
+    PS_PAIR_FORM_ALLPAIRS_MFMA_SIGNED = 8 /* FP4 path, three +-1 features per site instead of four {0, 1}: S = 4 matches - sites */
 };
 int ps_last_pair_form(ps_population *p);
 /* Which kernel the last core sweep of this handle (ps_step, ps_next_generation, ps_mutate_alleles, ps_recombine, a
@@ -191,7 +192,8 @@ int ps_sync(ps_population *p);
  * distances: 0 = choose by cost, 1 = sampled-pair kernel, 2 = all-pairs tiles + lookup, 3 = sampled-pair
  * kernel in its nibble form even for one-hot matrices, 4 = transposed bit strings streamed per pair -- the
  * sampled form of populations too wide for an LDS tile, 5 = all-pairs xor + popcount tiles even for one-hot matrices,
- * 6 = all pairs on the i8 matrix cores; one-hot matrices go to the matrix cores in modes 0 and 2 (FP4 form) and 6 (i8 form)), "pair_ranges" (site ranges of the tiled
+ * 6 = all pairs on the i8 matrix cores, 7 = all pairs on the FP4 path with three +-1 features per site; one-hot matrices go to the
+ * matrix cores in modes 0 and 2 (FP4 form on one-hot nibbles), 6 and 7), "pair_ranges" (site ranges of the tiled
  * sampled-pair kernels, 0 = choose; the 16-bit counter cap still applies),
  * "davg_form" (average_distance: 0 = choose, 1 = LDS-tile popcount kernels, 2 = intersections on the matrix cores in one kernel --
  * the choice above pop_size 24576 --, 3 = the same in two phases, u16 counts then division + ordered fold -- the choice for row

@@ -1014,8 +1014,8 @@ __global__ void __launch_bounds__(256, 8) acc_average_from_matrix_kernel(const d
 // and every individual's distances are added in ASCENDING j by ONE lane (the reference's sequential fold, :770): only the
 // counting is re-associated, and integer counts have no rounding.
 //   * acc_rows_pad_kernel: the individual-major bit rows copied to rows of WP dwords (a multiple of 8: whole 256-gene
-//     chunks) and Npad rows (a multiple of 128), zero padded, plus the row popcounts: the contraction kernel then has no
-//     edge cases in its loads.
+//     chunks) and Npad rows (a multiple of 128), zero padded, in the blocked order of ps_da_row_offset, plus the row
+//     popcounts: the contraction kernel then has no edge cases in its loads and every load is 1 KB of consecutive bytes.
 //   * acc_average_distance_mfma_kernel<NB>: a WAVE owns 32 NB individuals i (the B operand: columns of the 32 x 32
 //     accumulator blocks, i = lane & 31 of block b) and sweeps all j in steps of 128 (four A fragments: rows).  Lane
 //     (r, h) of a fragment takes the genes [256 c + 128 h, +128) of chunk c of individual base + r: one 16-byte load per
@@ -1028,6 +1028,15 @@ __global__ void __launch_bounds__(256, 8) acc_average_from_matrix_kernel(const d
 //     holds the live sum is ever passed on; v_permlane32_swap, no LDS round trip).
 // Sharding: a rank computes rows [i_lo, i_lo + i_cnt) against all N columns; the N doubles are all-gathered.
 // ---------------------------------------------------------------------------
+// Blocked rows: [group of 32 rows][chunk of 8 dwords][half h][row % 32][4 dwords] -- what one operand fragment loads for a
+// chunk (lane = h * 32 + r, 16 bytes each) is 1 KB of consecutive addresses.  Row-major rows gave every load instruction 32
+// bytes of 32 different 128-byte lines, each crossing the L2 -> L1 path four times: the contraction ran at 0.40 of the FP4 peak
+// on cache fills (round 6).  Offset of dword 0 of `row` (half 0, chunk 0); a chunk is 256 dwords further, half 1 128 dwords.
+__device__ __forceinline__ size_t ps_da_row_offset(uint32_t row, uint32_t nch)
+{
+    return (size_t)(row >> 5) * nch * 256u + (row & 31u) * 4u;
+}
+
 __global__ void __launch_bounds__(256) acc_rows_pad_kernel(const uint64_t *accI, uint32_t *rowsP, uint32_t *rowcnt, acc_dims d,
                                                            uint32_t WP, uint32_t Npad)
 {
@@ -1038,7 +1047,7 @@ __global__ void __launch_bounds__(256) acc_rows_pad_kernel(const uint64_t *accI,
     uint32_t cnt = 0;
     for (uint32_t w = lane; w < WP; w += 64u) {
         const uint32_t v = (row < d.N && w < 2u * d.GW) ? src[w] : 0u;
-        rowsP[(uint64_t)row * WP + w] = v;
+        rowsP[ps_da_row_offset(row, WP / 8u) + (size_t)(w >> 3) * 256u + ((w >> 2) & 1u) * 128u + (w & 3u)] = v;
         cnt += __popc(v);
     }
 #pragma unroll
@@ -1112,6 +1121,83 @@ __device__ __forceinline__ double ps_da_distance(uint32_t in, uint32_t un, doubl
 // Bit-equal to the one-kernel form (and to the CPU restatement the tests compare with): the counts are integers, the distance expression and the order of
 // the additions are unchanged.
 // ---------------------------------------------------------------------------
+// The contraction of one 128 x 32 NB block of pairs over all chunks, software-pipelined like core_allpairs_mfma_fp4_kernel: the
+// table reads of K-step t + 1 are issued before the MFMAs of step t (two operand sets, ping-pong by the parity of t; four
+// steps per chunk, so the parity carries over the chunk loop), the 16-byte loads of the next chunk are in flight during the
+// whole chunk.  (Left to the compiler, 26 of the loop's waits sat between its 32 MFMAs: round 6.)
+// PIPE = false leaves the order to the compiler: better where the registers are short (the one-kernel form at NB = 2: 11.1 ms
+// against 12.3 at N = 65536; NB = 4), worse elsewhere (phase 1 at NB = 2: 10.4 against 9.0 ms).
+template <uint32_t NB, bool PIPE>
+__device__ __forceinline__ void ps_da_contract(const uint32_t *const (&srcA)[4], const uint32_t *const (&srcB)[NB], uint32_t nch,
+                                               uint32_t colofs, ps_da_v16f (&acc)[4][NB])
+{
+    const int one = 0x7f7f7f7f;          // E8M0 block scale 2^0 in every byte
+    uint4 cur[4 + NB], nxt[4 + NB];
+    if (!PIPE) {
+#pragma unroll
+        for (uint32_t f = 0; f < 4u + NB; f++) cur[f] = *(const uint4 *)((f < 4u ? srcA[f] : srcB[f - 4u]));
+        for (uint32_t c = 0; c < nch; c++) {
+            const uint32_t cn = min(c + 1u, nch - 1u);
+#pragma unroll
+            for (uint32_t f = 0; f < 4u + NB; f++) nxt[f] = *(const uint4 *)((f < 4u ? srcA[f] : srcB[f - 4u]) + (size_t)cn * 256u);
+#pragma unroll
+            for (uint32_t t = 0; t < 4u; t++) {
+                ps_da_v8i op[4 + NB];
+#pragma unroll
+                for (uint32_t f = 0; f < 4u + NB; f++) {
+                    const uint32_t raw = t == 0u ? cur[f].x : t == 1u ? cur[f].y : t == 2u ? cur[f].z : cur[f].w;
+                    op[f] = ps_da_v8i{ (int)ps_da_lut(raw, colofs, 0u), (int)ps_da_lut(raw, colofs, 1u), (int)ps_da_lut(raw, colofs, 2u),
+                                       (int)ps_da_lut(raw, colofs, 3u), 0, 0, 0, 0 };
+                }
+#pragma unroll
+                for (uint32_t a = 0; a < 4u; a++)
+#pragma unroll
+                    for (uint32_t b = 0; b < NB; b++)
+                        acc[a][b] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(op[a], op[4u + b], acc[a][b], 4, 4, 0, one, 0, one);
+            }
+#pragma unroll
+            for (uint32_t f = 0; f < 4u + NB; f++) cur[f] = nxt[f];
+        }
+        return;
+    }
+    ps_u32x4_acc opA[4 + NB], opB[4 + NB];
+    auto fetch = [&](const uint4 &w, uint32_t t, ps_u32x4_acc &op) {
+        const uint32_t raw = t == 0u ? w.x : t == 1u ? w.y : t == 2u ? w.z : w.w;
+        op = ps_u32x4_acc{ ps_da_lut(raw, colofs, 0u), ps_da_lut(raw, colofs, 1u), ps_da_lut(raw, colofs, 2u), ps_da_lut(raw, colofs, 3u) };
+    };
+#pragma unroll
+    for (uint32_t f = 0; f < 4u + NB; f++) cur[f] = *(const uint4 *)((f < 4u ? srcA[f] : srcB[f - 4u]));
+#pragma unroll
+    for (uint32_t f = 0; f < 4u + NB; f++) fetch(cur[f], 0u, opA[f]);
+    for (uint32_t c = 0; c < nch; c++) {
+        const uint32_t cn = min(c + 1u, nch - 1u);
+#pragma unroll
+        for (uint32_t f = 0; f < 4u + NB; f++) nxt[f] = *(const uint4 *)((f < 4u ? srcA[f] : srcB[f - 4u]) + (size_t)cn * 256u);
+#pragma unroll
+        for (uint32_t t = 0; t < 4u; t++) {
+            const uint32_t tn = (t + 1u) & 3u;
+#pragma unroll
+            for (uint32_t f = 0; f < 4u + NB; f++) {
+                if (t & 1u) fetch((t == 3u) ? nxt[f] : cur[f], tn, opA[f]);
+                else fetch((t == 3u) ? nxt[f] : cur[f], tn, opB[f]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (uint32_t a = 0; a < 4u; a++)
+#pragma unroll
+                for (uint32_t b = 0; b < NB; b++) {
+                    const ps_u32x4_acc &xa = (t & 1u) ? opB[a] : opA[a], &xb = (t & 1u) ? opB[4u + b] : opA[4u + b];
+                    const ps_da_v8i va = { (int)xa.x, (int)xa.y, (int)xa.z, (int)xa.w, 0, 0, 0, 0 };
+                    const ps_da_v8i vb = { (int)xb.x, (int)xb.y, (int)xb.z, (int)xb.w, 0, 0, 0, 0 };
+                    acc[a][b] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(va, vb, acc[a][b], 4, 4, 0, one, 0, one);
+                }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (uint32_t f = 0; f < 4u + NB; f++) cur[f] = nxt[f];
+    }
+}
+
 template <uint32_t NB>
 __global__ void __launch_bounds__(256, NB == 2u ? 2 : 1) acc_intersections_mfma_kernel(const uint32_t *rowsP, uint32_t WP, uint32_t Npad,
                                                                                       uint32_t i_lo, uint32_t i_cnt, uint32_t jsteps,
@@ -1132,15 +1218,14 @@ __global__ void __launch_bounds__(256, NB == 2u ? 2 : 1) acc_intersections_mfma_
     const uint32_t i_rel = (blockIdx.x * 4u + wave) * 32u * NB;       // first row of this wave inside the shard
     if (i_rel >= i_cnt) return;                          // (wave-uniform; no barrier follows)
     const uint32_t *srcB[NB];
-#pragma unroll
-    for (uint32_t b = 0; b < NB; b++) srcB[b] = rowsP + (size_t)min(i_lo + i_rel + 32u * b + r, Npad - 1u) * WP + h * 4u;
     const uint32_t nch = WP / 8u;
-    const int one = 0x7f7f7f7f;          // E8M0 block scale 2^0 in every byte
+#pragma unroll
+    for (uint32_t b = 0; b < NB; b++) srcB[b] = rowsP + ps_da_row_offset(min(i_lo + i_rel + 32u * b + r, Npad - 1u), nch) + h * 128u;
     const uint32_t j_begin = blockIdx.y * jsteps * 128u, j_end = min(Npad, j_begin + jsteps * 128u);
     for (uint32_t j0 = j_begin; j0 < j_end; j0 += 128u) {
         const uint32_t *srcA[4];
 #pragma unroll
-        for (uint32_t a = 0; a < 4u; a++) srcA[a] = rowsP + (size_t)(j0 + 32u * a + r) * WP + h * 4u;
+        for (uint32_t a = 0; a < 4u; a++) srcA[a] = rowsP + ps_da_row_offset(j0 + 32u * a + r, nch) + h * 128u;
         ps_da_v16f acc[4][NB];
 #pragma unroll
         for (uint32_t a = 0; a < 4u; a++)
@@ -1148,31 +1233,9 @@ __global__ void __launch_bounds__(256, NB == 2u ? 2 : 1) acc_intersections_mfma_
             for (uint32_t b = 0; b < NB; b++)
 #pragma unroll
                 for (int v = 0; v < 16; v++) acc[a][b][v] = 0.0f;
-        uint4 cur[4 + NB], nxt[4 + NB];
-#pragma unroll
-        for (uint32_t f = 0; f < 4u + NB; f++) cur[f] = *(const uint4 *)((f < 4u ? srcA[f] : srcB[f - 4u]));
-        for (uint32_t c = 0; c < nch; c++) {
-            const uint32_t cn = min(c + 1u, nch - 1u);
-#pragma unroll
-            for (uint32_t f = 0; f < 4u + NB; f++) nxt[f] = *(const uint4 *)((f < 4u ? srcA[f] : srcB[f - 4u]) + (size_t)cn * 8u);
-#pragma unroll
-            for (uint32_t t = 0; t < 4u; t++) {
-                ps_da_v8i op[4 + NB];
-#pragma unroll
-                for (uint32_t f = 0; f < 4u + NB; f++) {
-                    const uint32_t raw = t == 0u ? cur[f].x : t == 1u ? cur[f].y : t == 2u ? cur[f].z : cur[f].w;
-                    op[f] = ps_da_v8i{ (int)ps_da_lut(raw, colofs, 0u), (int)ps_da_lut(raw, colofs, 1u), (int)ps_da_lut(raw, colofs, 2u),
-                                       (int)ps_da_lut(raw, colofs, 3u), 0, 0, 0, 0 };
-                }
-#pragma unroll
-                for (uint32_t a = 0; a < 4u; a++)
-#pragma unroll
-                    for (uint32_t b = 0; b < NB; b++)
-                        acc[a][b] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(op[a], op[4u + b], acc[a][b], 4, 4, 0, one, 0, one);
-            }
-#pragma unroll
-            for (uint32_t f = 0; f < 4u + NB; f++) cur[f] = nxt[f];
-        }
+        // (carrying the pipeline over the j steps -- the next step's first chunk loaded and expanded during this step's last --
+        // changed nothing: 0.987 against 0.98 ms for a row shard of 8 at N = 65536)
+        ps_da_contract<NB, (NB <= 2u)>(srcA, srcB, nch, colofs, acc);
         // block (a, b): column i = i_rel + 32 b + r, rows j0 + 32 a + 8 g + 4 h + q (q = 0..3): four consecutive j per group
 #pragma unroll
         for (uint32_t b = 0; b < NB; b++) {
@@ -1296,21 +1359,20 @@ __global__ void __launch_bounds__(256, NB == 2u ? 2 : 1) acc_average_distance_mf
     const uint32_t i_base = i_lo + (blockIdx.x * 4u + wave) * 32u * NB;
     if (i_base >= i_lo + i_cnt) return;                  // (wave-uniform; no barrier follows)
     const uint32_t *srcB[NB];
+    const uint32_t nch = WP / 8u;
     uint32_t ci[NB];
     double sum[NB];
 #pragma unroll
     for (uint32_t b = 0; b < NB; b++) {
         const uint32_t i = min(i_base + 32u * b + r, Npad - 1u);
-        srcB[b] = rowsP + (size_t)i * WP + h * 4u;
+        srcB[b] = rowsP + ps_da_row_offset(i, nch) + h * 128u;
         ci[b] = rowcnt[i];
         sum[b] = 0.0;
     }
-    const uint32_t nch = WP / 8u;
-    const int one = 0x7f7f7f7f;          // E8M0 block scale 2^0 in every byte
     for (uint32_t j0 = 0; j0 < Npad; j0 += 128u) {
         const uint32_t *srcA[4];
 #pragma unroll
-        for (uint32_t a = 0; a < 4u; a++) srcA[a] = rowsP + (size_t)(j0 + 32u * a + r) * WP + h * 4u;
+        for (uint32_t a = 0; a < 4u; a++) srcA[a] = rowsP + ps_da_row_offset(j0 + 32u * a + r, nch) + h * 128u;
         ps_da_v16f acc[4][NB];
 #pragma unroll
         for (uint32_t a = 0; a < 4u; a++)
@@ -1318,31 +1380,7 @@ __global__ void __launch_bounds__(256, NB == 2u ? 2 : 1) acc_average_distance_mf
             for (uint32_t b = 0; b < NB; b++)
 #pragma unroll
                 for (int v = 0; v < 16; v++) acc[a][b][v] = 0.0f;
-        uint4 cur[4 + NB], nxt[4 + NB];
-#pragma unroll
-        for (uint32_t f = 0; f < 4u + NB; f++) cur[f] = *(const uint4 *)((f < 4u ? srcA[f] : srcB[f - 4u]));
-        for (uint32_t c = 0; c < nch; c++) {
-            const uint32_t cn = min(c + 1u, nch - 1u);
-#pragma unroll
-            for (uint32_t f = 0; f < 4u + NB; f++) nxt[f] = *(const uint4 *)((f < 4u ? srcA[f] : srcB[f - 4u]) + (size_t)cn * 8u);
-#pragma unroll
-            for (uint32_t t = 0; t < 4u; t++) {
-                ps_da_v8i op[4 + NB];
-#pragma unroll
-                for (uint32_t f = 0; f < 4u + NB; f++) {
-                    const uint32_t raw = t == 0u ? cur[f].x : t == 1u ? cur[f].y : t == 2u ? cur[f].z : cur[f].w;
-                    op[f] = ps_da_v8i{ (int)ps_da_lut(raw, colofs, 0u), (int)ps_da_lut(raw, colofs, 1u), (int)ps_da_lut(raw, colofs, 2u),
-                                       (int)ps_da_lut(raw, colofs, 3u), 0, 0, 0, 0 };
-                }
-#pragma unroll
-                for (uint32_t a = 0; a < 4u; a++)
-#pragma unroll
-                    for (uint32_t b = 0; b < NB; b++)
-                        acc[a][b] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(op[a], op[4u + b], acc[a][b], 4, 4, 0, one, 0, one);
-            }
-#pragma unroll
-            for (uint32_t f = 0; f < 4u + NB; f++) cur[f] = nxt[f];
-        }
+        ps_da_contract<NB, (NB == 1u)>(srcA, srcB, nch, colofs, acc);
         // distances and the ordered fold.  Block (a, b): column i = i_base + 32 b + r, rows j0 + 32 a + (v & 3) + 8 (v >> 2) + 4 h.
         // The epilogue is VALU work -- PMC: 30 instructions per distance in the plain form, more wave-cycles than the
         // contraction itself -- so it is written lean, without changing a bit of any distance:

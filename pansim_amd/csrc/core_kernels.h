@@ -1863,13 +1863,21 @@ __global__ void core_pair_lookup_kernel(const uint32_t *H, uint32_t N, const uin
 #ifndef PS_PT_WB
 #define PS_PT_WB 32u    // dwords per individual per tile
 #endif
-template <bool NIB>
+// BLOCKED (the matrix-core all-pairs kernels): the same strings cut into the pieces one operand fragment loads at a time --
+// packT[group of 32 individuals][chunk of 8 dwords][half h][r][4 dwords], 1 KB per (group, chunk), so that a wave's 64 x 16-byte
+// load is 1 KB of consecutive addresses (individual-major strings gave it 32 bytes of 32 different 128-byte lines per chunk:
+// every line crossed the L2 -> L1 path four times).  Rows of the last group past N are written as zeros.
+// PLANES (with BLOCKED; the signed all-pairs kernel): the 16 bytes of a lane hold bit PLANES instead of 2-bit codes -- the high
+// code bits of its first and second 32 sites, then the low code bits of the same sites (lane (h, r): sites [64 h, 64 h + 64)
+// of the chunk's 128).
+template <bool NIB, bool BLOCKED = false, bool PLANES = false>
 __global__ void __launch_bounds__(256) core_packT_kernel(const uint8_t *state, uint32_t N, uint32_t pitch, uint32_t rows,
                                                          uint32_t *packT, uint32_t WT)
 {
     constexpr uint32_t SPW = NIB ? 8u : 16u;          // sites per dword
     constexpr uint32_t RS = PS_PT_IB + 4u;            // LDS row stride in dwords (16-byte aligned, banks shifted by 4 per word)
     __shared__ __attribute__((aligned(16))) uint32_t T[PS_PT_WB * RS];   // T[w][individual]
+    static_assert(!PLANES || (BLOCKED && !NIB), "bit planes: blocked strings of one-hot matrices");
     const uint32_t tid = threadIdx.x;
     // consecutive workgroups take consecutive individual blocks of the same 512 (256) site rows
     const uint32_t nib = (N + PS_PT_IB - 1u) / PS_PT_IB;
@@ -1896,9 +1904,23 @@ __global__ void __launch_bounds__(256) core_packT_kernel(const uint8_t *state, u
             ps_nibble_pack8(v, o);
         } else {
             uint32_t t[4];
+            if (PLANES) {
+                // byte j of t[0], t[1]: the high code bit (one-hot byte 4 or 8) of sites 0..7, 8..15 of individual j;
+                // t[2], t[3]: the low code bit (byte 2 or 8).  o[j] = high bits of the 16 sites | low bits << 16
+                t[0] = t[1] = t[2] = t[3] = 0u;
+#pragma unroll
+                for (uint32_t b = 0; b < 8u; b++) {
+                    const uint32_t x = v[b], y = v[8u + b];
+                    t[0] |= (((x >> 2) | (x >> 3)) & 0x01010101u) << b;
+                    t[1] |= (((y >> 2) | (y >> 3)) & 0x01010101u) << b;
+                    t[2] |= (((x >> 1) | (x >> 3)) & 0x01010101u) << b;
+                    t[3] |= (((y >> 1) | (y >> 3)) & 0x01010101u) << b;
+                }
+            } else {
 #pragma unroll
             for (int m = 0; m < 4; m++)      // byte j of t[m]: sites 4m .. 4m+3 of individual j
                 t[m] = ps_code2(v[4 * m]) | (ps_code2(v[4 * m + 1]) << 2) | (ps_code2(v[4 * m + 2]) << 4) | (ps_code2(v[4 * m + 3]) << 6);
+            }
             const uint32_t a01 = __builtin_amdgcn_perm(t[1], t[0], 0x05010400u), b01 = __builtin_amdgcn_perm(t[1], t[0], 0x07030602u);
             const uint32_t a23 = __builtin_amdgcn_perm(t[3], t[2], 0x05010400u), b23 = __builtin_amdgcn_perm(t[3], t[2], 0x07030602u);
             o[0] = __builtin_amdgcn_perm(a23, a01, 0x05040100u);
@@ -1909,6 +1931,24 @@ __global__ void __launch_bounds__(256) core_packT_kernel(const uint8_t *state, u
         *(uint4 *)(T + w * RS + 4u * qd) = make_uint4(o[0], o[1], o[2], o[3]);
     }
     __syncthreads();
+    if (BLOCKED) {
+        // a wave writes the 1 KB of one (group, chunk): lane = h * 32 + r, 4 chunks of the tile = 4 waves, 8 groups = 8 passes
+        static_assert(PS_PT_WB == 32u && PS_PT_IB == 256u, "tile = 8 groups x 4 chunks");
+        const uint32_t lane = tid & 63u, cc = tid >> 6, r = lane & 31u, h = lane >> 5;
+        const uint32_t n_chunks = WT / 8u, ngroups = (N + 31u) / 32u;
+        for (uint32_t gi = 0; gi < 8u; gi++) {
+            const uint32_t g = i0 / 32u + gi, ind = gi * 32u + r;
+            if (g >= ngroups) break;
+            const uint32_t *src = T + (8u * cc + 4u * h) * RS + ind;
+            uint4 o = make_uint4(src[0], src[RS], src[2u * RS], src[3u * RS]);
+            if (PLANES)         // four (high | low << 16) words of 16 sites -> high bits of 2 x 32 sites, low bits of 2 x 32 sites
+                o = make_uint4(__builtin_amdgcn_perm(o.y, o.x, 0x05040100u), __builtin_amdgcn_perm(o.w, o.z, 0x05040100u),
+                               __builtin_amdgcn_perm(o.y, o.x, 0x07060302u), __builtin_amdgcn_perm(o.w, o.z, 0x07060302u));
+            if (i0 + ind >= N) o = make_uint4(0u, 0u, 0u, 0u);
+            *(uint4 *)(packT + ((size_t)g * n_chunks + w0 / 8u + cc) * 256u + lane * 4u) = o;
+        }
+        return;
+    }
     // 8 lanes write the 128 bytes of one individual; 32 individuals per pass of the workgroup
     constexpr uint32_t LPI = PS_PT_WB / 4u;             // lanes per individual (16 bytes each)
     const uint32_t k4 = tid % LPI;
@@ -1974,8 +2014,8 @@ __global__ void __launch_bounds__(256) core_pair_counts_rows(const uint32_t *pac
 //     c(lane), and the 16 lanes the LDS serves together (MI355X_MICROARCH.md, ds_read_b128 lane groups) have 16
 //     different copies = 16 different bank groups, so the data-dependent reads never conflict.  The address is
 //     one v_perm: (byte << 8) | (copy << 4).
-//   * Partial counts of a (tile, chunk range) are added to H with one atomic per pair; 32 consecutive lanes add to
-//     32 consecutive words.
+//   * Partial counts of a (tile, chunk range) are stored to slice `range` of H (gridDim.y slices of N x N words; 32
+//     consecutive lanes store 32 consecutive words); core_allpairs_sum_slices_kernel leaves their sum in slice 0.
 // ---------------------------------------------------------------------------
 typedef int ps_v4i __attribute__((ext_vector_type(4)));
 typedef int ps_v16i __attribute__((ext_vector_type(16)));
@@ -2025,10 +2065,12 @@ __global__ void __launch_bounds__(512) core_allpairs_mfma_kernel(const uint32_t 
     const uint32_t wi = wave >> 2, wj = wave & 3u;
     const uint32_t r = lane & 31u, h = lane >> 5;
     const uint32_t *src[6];
+    const uint32_t ngroups = (N + 31u) / 32u;
 #pragma unroll
     for (uint32_t f = 0; f < 6u; f++) {
-        const uint32_t ind = f < 4u ? ti * PS_MF_TILE + wi * 128u + f * 32u + r : tj * PS_MF_TILE + wj * 64u + (f - 4u) * 32u + r;
-        src[f] = packT + (size_t)min(ind, N - 1u) * WT + h * 4u;      // (individuals past N repeat the last one; never stored)
+        const uint32_t grp = f < 4u ? ti * (PS_MF_TILE / 32u) + wi * 4u + f : tj * (PS_MF_TILE / 32u) + wj * 2u + (f - 4u);
+        // (groups past the population repeat the last one; never stored.  Blocked strings: 256 dwords per (group, chunk))
+        src[f] = packT + (size_t)min(grp, ngroups - 1u) * (WT / PS_MF_CHUNK_DW) * 256u + lane * 4u;
     }
     ps_v16i acc[4][2];
 #pragma unroll
@@ -2041,7 +2083,7 @@ __global__ void __launch_bounds__(512) core_allpairs_mfma_kernel(const uint32_t 
     if (c_lo >= c_hi) return;       // (wave-uniform: the whole workgroup leaves)
     uint4 cur[6], nxt[6];
 #pragma unroll
-    for (uint32_t f = 0; f < 6u; f++) cur[f] = *(const uint4 *)(src[f] + (size_t)c_lo * PS_MF_CHUNK_DW);
+    for (uint32_t f = 0; f < 6u; f++) cur[f] = *(const uint4 *)(src[f] + (size_t)c_lo * 256u);
     __syncthreads();        // the table is complete
     // Software pipeline over the K-steps: the six table reads of step t + 1 are issued before the eight MFMAs of
     // step t (two operand sets, ping-pong by the parity of t; 16 steps per chunk, so the parity carries over the
@@ -2052,7 +2094,7 @@ __global__ void __launch_bounds__(512) core_allpairs_mfma_kernel(const uint32_t 
     for (uint32_t c = c_lo; c < c_hi; c++) {
         const uint32_t cn = min(c + 1u, c_hi - 1u);
 #pragma unroll
-        for (uint32_t f = 0; f < 6u; f++) nxt[f] = *(const uint4 *)(src[f] + (size_t)cn * PS_MF_CHUNK_DW);
+        for (uint32_t f = 0; f < 6u; f++) nxt[f] = *(const uint4 *)(src[f] + (size_t)cn * 256u);
 #pragma unroll
         for (uint32_t t = 0; t < 16u; t++) {
             const uint32_t tn = (t + 1u) & 15u;
@@ -2076,7 +2118,11 @@ __global__ void __launch_bounds__(512) core_allpairs_mfma_kernel(const uint32_t 
         for (uint32_t f = 0; f < 6u; f++) cur[f] = nxt[f];
     }
     // C layout of the 32 x 32 blocks (dtype independent): col = lane & 31, row = (v & 3) + 8 * (v >> 2) + 4 * (lane >> 5)
+    // (plain stores into this chunk range's own slice of H; core_allpairs_sum_slices_kernel adds the slices.  One atomic per
+    // pair and range into a single N x N array was 47 of the kernel's 51 ms at N = 8192: device-scope atomics do not run in
+    // the L2 of an XCD)
     const uint32_t sites = (c_hi - c_lo) * PS_MF_CHUNK_DW * 16u;
+    uint32_t *Hs = H + (size_t)blockIdx.y * N * N;
 #pragma unroll
     for (int a = 0; a < 4; a++)
 #pragma unroll
@@ -2086,7 +2132,7 @@ __global__ void __launch_bounds__(512) core_allpairs_mfma_kernel(const uint32_t 
             for (int v = 0; v < 16; v++) {
                 const uint32_t i = ti * PS_MF_TILE + wi * 128u + (uint32_t)a * 32u + (uint32_t)((v & 3) + 8 * (v >> 2)) + 4u * h;
                 const uint32_t mism = sites - (uint32_t)acc[a][b][v];
-                if (i < N && j < N && mism) atomicAdd(&H[(size_t)i * N + j], 2u * mism);
+                if (i < N && j < N) Hs[(size_t)i * N + j] = 2u * mism;
             }
         }
 }
@@ -2133,10 +2179,12 @@ __global__ void __launch_bounds__(512) core_allpairs_mfma_fp4_kernel(const uint3
     const uint32_t wi = wave >> 2, wj = wave & 3u;
     const uint32_t r = lane & 31u, h = lane >> 5;
     const uint32_t *src[6];
+    const uint32_t ngroups = (N + 31u) / 32u;
 #pragma unroll
     for (uint32_t f = 0; f < 6u; f++) {
-        const uint32_t ind = f < 4u ? ti * PS_MF_TILE + wi * 128u + f * 32u + r : tj * PS_MF_TILE + wj * 64u + (f - 4u) * 32u + r;
-        src[f] = packT + (size_t)min(ind, N - 1u) * WT + h * 4u;
+        const uint32_t grp = f < 4u ? ti * (PS_MF_TILE / 32u) + wi * 4u + f : tj * (PS_MF_TILE / 32u) + wj * 2u + (f - 4u);
+        // (groups past the population repeat the last one; never stored.  Blocked strings: 256 dwords per (group, chunk))
+        src[f] = packT + (size_t)min(grp, ngroups - 1u) * (WT / PS_MF_CHUNK_DW) * 256u + lane * 4u;
     }
     ps_v16f acc[4][2];
 #pragma unroll
@@ -2149,7 +2197,7 @@ __global__ void __launch_bounds__(512) core_allpairs_mfma_fp4_kernel(const uint3
     if (c_lo >= c_hi) return;
     uint4 cur[6], nxt[6];
 #pragma unroll
-    for (uint32_t f = 0; f < 6u; f++) cur[f] = *(const uint4 *)(src[f] + (size_t)c_lo * PS_MF_CHUNK_DW);
+    for (uint32_t f = 0; f < 6u; f++) cur[f] = *(const uint4 *)(src[f] + (size_t)c_lo * 256u);
     __syncthreads();
     // 8 K-steps per chunk: step t takes bytes 2t, 2t+1 of the lane's 16 (= dword t >> 1, byte pair t & 1)
     uint2 opA[6][2], opB[6][2];
@@ -2164,7 +2212,7 @@ __global__ void __launch_bounds__(512) core_allpairs_mfma_fp4_kernel(const uint3
     for (uint32_t c = c_lo; c < c_hi; c++) {
         const uint32_t cn = min(c + 1u, c_hi - 1u);
 #pragma unroll
-        for (uint32_t f = 0; f < 6u; f++) nxt[f] = *(const uint4 *)(src[f] + (size_t)cn * PS_MF_CHUNK_DW);
+        for (uint32_t f = 0; f < 6u; f++) nxt[f] = *(const uint4 *)(src[f] + (size_t)cn * 256u);
 #pragma unroll
         for (uint32_t t = 0; t < 8u; t++) {
             const uint32_t tn = (t + 1u) & 7u;
@@ -2188,7 +2236,11 @@ __global__ void __launch_bounds__(512) core_allpairs_mfma_fp4_kernel(const uint3
 #pragma unroll
         for (uint32_t f = 0; f < 6u; f++) cur[f] = nxt[f];
     }
+    // (plain stores into this chunk range's own slice of H; core_allpairs_sum_slices_kernel adds the slices.  One atomic per
+    // pair and range into a single N x N array was 47 of the kernel's 51 ms at N = 8192: device-scope atomics do not run in
+    // the L2 of an XCD)
     const uint32_t sites = (c_hi - c_lo) * PS_MF_CHUNK_DW * 16u;
+    uint32_t *Hs = H + (size_t)blockIdx.y * N * N;
 #pragma unroll
     for (int a = 0; a < 4; a++)
 #pragma unroll
@@ -2198,9 +2250,149 @@ __global__ void __launch_bounds__(512) core_allpairs_mfma_fp4_kernel(const uint3
             for (int v = 0; v < 16; v++) {
                 const uint32_t i = ti * PS_MF_TILE + wi * 128u + (uint32_t)a * 32u + (uint32_t)((v & 3) + 8 * (v >> 2)) + 4u * h;
                 const uint32_t mism = sites - (uint32_t)acc[a][b][v];
-                if (i < N && j < N && mism) atomicAdd(&H[(size_t)i * N + j], 2u * mism);
+                if (i < N && j < N) Hs[(size_t)i * N + j] = 2u * mism;
             }
         }
+}
+
+// The same counts from 3 products per site instead of 4 (round 6).  With the 2-bit allele code (h, l) as signs s_h = 1 - 2 h,
+// s_l = 1 - 2 l, two alleles are equal iff (1 + s_h s_h')(1 + s_l s_l') = 4, i.e. the three products s_h s_h' + s_l s_l' +
+// (s_h s_l)(s_h' s_l') add to 3 for equal alleles and to -1 for different ones: over a range of `sites` sites the contraction of
+// the three +-1 features per site is S = 4 matches - sites, mismatches = (3 sites - S) / 4.  +-1.0 are E2M1 values (0b0010,
+// 0b1010), products and f32 sums of at most 3 * sites < 2^24 in magnitude are exact, so the integers equal the one-hot forms'.
+// Operands: the bit planes of core_packT_kernel<false, true, true>; a K-step is one feature of 32 sites per lane (the third plane
+// is the xor of the two stored ones), expanded bit -> nibble by four reads of a byte -> 8-nibble table (256 entries x 64
+// copies x 4 bytes = 64 KB at LDS offset 0, copy = lane: 64 different banks).  6 K-steps per 128-site chunk where the one-hot
+// form takes 8: 25 % fewer matrix-core cycles and LDS bytes for the same pairs.
+__device__ __forceinline__ uint32_t ps_mf_lut_read32(uint32_t raw, uint32_t colofs, uint32_t b)
+{
+    uint32_t addr;      // (byte b of raw) << 8 | colofs  (colofs = lane * 4 < 256)
+    switch (b) {
+    case 0: addr = __builtin_amdgcn_perm(raw, colofs, 0x0c0c0400u); break;
+    case 1: addr = __builtin_amdgcn_perm(raw, colofs, 0x0c0c0500u); break;
+    case 2: addr = __builtin_amdgcn_perm(raw, colofs, 0x0c0c0600u); break;
+    default: addr = __builtin_amdgcn_perm(raw, colofs, 0x0c0c0700u); break;
+    }
+    return *(const __attribute__((address_space(3))) uint32_t *)(uintptr_t)addr;
+}
+
+__global__ void __launch_bounds__(512) core_allpairs_mfma_signed_kernel(const uint32_t *packT, uint32_t WT, uint32_t N, uint32_t *H,
+                                                                        uint32_t chunks_per_range, uint32_t n_chunks, uint32_t ntile)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t lut[];      // 256 entries x 64 copies x 4 bytes = 64 KB, at LDS offset 0
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    for (uint32_t x = tid; x < 256u * 64u; x += 512u) {
+        const uint32_t e = x >> 6;
+        uint32_t v = 0x22222222u;        // bit k of the byte set -> nibble k = -1.0 (0b1010), clear -> +1.0 (0b0010)
+#pragma unroll
+        for (uint32_t k = 0; k < 8u; k++) v |= ((e >> k) & 1u) << (4u * k + 3u);
+        *(uint32_t *)(lut + (size_t)x * 4u) = v;         // x = e * 64 + copy
+    }
+    const uint32_t colofs = lane << 2;
+    uint32_t ti = 0, rem = blockIdx.x;
+    while (rem >= ntile - ti) { rem -= ntile - ti; ti++; }
+    const uint32_t tj = ti + rem;
+    const uint32_t wi = wave >> 2, wj = wave & 3u;
+    const uint32_t r = lane & 31u, h = lane >> 5;
+    const uint32_t *src[6];
+    const uint32_t ngroups = (N + 31u) / 32u;
+#pragma unroll
+    for (uint32_t f = 0; f < 6u; f++) {
+        const uint32_t grp = f < 4u ? ti * (PS_MF_TILE / 32u) + wi * 4u + f : tj * (PS_MF_TILE / 32u) + wj * 2u + (f - 4u);
+        src[f] = packT + (size_t)min(grp, ngroups - 1u) * (WT / PS_MF_CHUNK_DW) * 256u + lane * 4u;
+    }
+    ps_v16f acc[4][2];
+#pragma unroll
+    for (int a = 0; a < 4; a++)
+#pragma unroll
+        for (int b = 0; b < 2; b++)
+#pragma unroll
+            for (int v = 0; v < 16; v++) acc[a][b][v] = 0.0f;
+    const uint32_t c_lo = blockIdx.y * chunks_per_range, c_hi = min(n_chunks, c_lo + chunks_per_range);
+    if (c_lo >= c_hi) return;
+    uint4 cur[6], nxt[6];
+#pragma unroll
+    for (uint32_t f = 0; f < 6u; f++) cur[f] = *(const uint4 *)(src[f] + (size_t)c_lo * 256u);
+    __syncthreads();
+    // 6 K-steps per chunk: (first 32 sites: high plane, low plane, their xor), (second 32 sites: the same)
+    ps_v4i opA[6], opB[6];
+    auto fetch = [&](const uint4 &w, uint32_t t, ps_v4i &op) {
+        const uint32_t hi = t < 3u ? w.x : w.y, lo = t < 3u ? w.z : w.w;
+        const uint32_t raw = (t % 3u) == 0u ? hi : (t % 3u) == 1u ? lo : (hi ^ lo);
+        op = ps_v4i{ (int)ps_mf_lut_read32(raw, colofs, 0u), (int)ps_mf_lut_read32(raw, colofs, 1u), (int)ps_mf_lut_read32(raw, colofs, 2u),
+                     (int)ps_mf_lut_read32(raw, colofs, 3u) };
+    };
+#pragma unroll
+    for (uint32_t f = 0; f < 6u; f++) fetch(cur[f], 0u, opA[f]);
+    const int one = 0x7f7f7f7f;          // E8M0 block scale 2^0 in every byte
+    for (uint32_t c = c_lo; c < c_hi; c++) {
+        const uint32_t cn = min(c + 1u, c_hi - 1u);
+#pragma unroll
+        for (uint32_t f = 0; f < 6u; f++) nxt[f] = *(const uint4 *)(src[f] + (size_t)cn * 256u);
+#pragma unroll
+        for (uint32_t t = 0; t < 6u; t++) {
+            const uint32_t tn = t == 5u ? 0u : t + 1u;
+#pragma unroll
+            for (uint32_t f = 0; f < 6u; f++) {
+                if (t & 1u) fetch((t == 5u) ? nxt[f] : cur[f], tn, opA[f]);
+                else fetch((t == 5u) ? nxt[f] : cur[f], tn, opB[f]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int a = 0; a < 4; a++)
+#pragma unroll
+                for (int b = 0; b < 2; b++) {
+                    const ps_v4i &xa = (t & 1u) ? opB[a] : opA[a], &xb = (t & 1u) ? opB[4 + b] : opA[4 + b];
+                    const ps_v8i va = { xa.x, xa.y, xa.z, xa.w, 0, 0, 0, 0 };
+                    const ps_v8i vb = { xb.x, xb.y, xb.z, xb.w, 0, 0, 0, 0 };
+                    acc[a][b] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(va, vb, acc[a][b], 4, 4, 0, one, 0, one);
+                }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (uint32_t f = 0; f < 6u; f++) cur[f] = nxt[f];
+    }
+    const int32_t sites3 = (int32_t)(3u * (c_hi - c_lo) * PS_MF_CHUNK_DW * 16u);
+    uint32_t *Hs = H + (size_t)blockIdx.y * N * N;
+#pragma unroll
+    for (int a = 0; a < 4; a++)
+#pragma unroll
+        for (int b = 0; b < 2; b++) {
+            const uint32_t j = tj * PS_MF_TILE + wj * 64u + (uint32_t)b * 32u + r;
+#pragma unroll
+            for (int v = 0; v < 16; v++) {
+                const uint32_t i = ti * PS_MF_TILE + wi * 128u + (uint32_t)a * 32u + (uint32_t)((v & 3) + 8 * (v >> 2)) + 4u * h;
+                // S = 4 matches - sites; the reference's numerator counts 2 per differing site (distances.rs:22-52)
+                const uint32_t mism = (uint32_t)(sites3 - (int32_t)acc[a][b][v]) >> 2;
+                if (i < N && j < N) Hs[(size_t)i * N + j] = 2u * mism;
+            }
+        }
+}
+
+// H[0][i][j] += H[1 ..][i][j] over the 256-tiles with ti <= tj (the only ones the kernels above store): one workgroup per
+// row i, 16 bytes per lane from the row's first computed column on
+__global__ void __launch_bounds__(256) core_allpairs_sum_slices_kernel(uint32_t *H, uint32_t N, uint32_t slices)
+{
+    const uint32_t i = blockIdx.x;
+    const size_t NN = (size_t)N * N;
+    uint32_t *row = H + (size_t)i * N;
+    const uint32_t j_lo = (i >> 8) << 8;
+    if ((N & 3u) == 0u) {
+        for (uint32_t j = j_lo + 4u * threadIdx.x; j < N; j += 1024u) {
+            uint4 a = *(const uint4 *)(row + j);
+            for (uint32_t s = 1; s < slices; s++) {
+                const uint4 b = *(const uint4 *)(row + s * NN + j);
+                a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+            }
+            *(uint4 *)(row + j) = a;
+        }
+    } else {
+        for (uint32_t j = j_lo + threadIdx.x; j < N; j += 256u) {
+            uint32_t a = row[j];
+            for (uint32_t s = 1; s < slices; s++) a += row[s * NN + j];
+            row[j] = a;
+        }
+    }
 }
 
 // out[slot] = H[i][j] for the 256-tiles of core_allpairs_mfma_kernel (tiles ti <= tj were computed; a diagonal

@@ -549,7 +549,7 @@ extern "C" int ps_set_tuning(ps_population *p, const char *key, int64_t value)
         if (value < 0 || value > 2) return ps_fail(PS_ERR_INVALID, "hgt_mode must be 0 (auto), 1 (one atomic per event) or 2 (binned by recipient partition, two passes)");
         p->hgt_mode = (int)value;
     } else if (k == "pair_mode") {
-        if (value < 0 || value > 6) return ps_fail(PS_ERR_INVALID, "pair_mode must be 0 (auto), 1 (sampled), 2 (all pairs), 3 (sampled, nibble form even for one-hot matrices), 4 (transposed bit strings, streamed per pair), 5 (all pairs, xor + popcount tiles even for one-hot matrices) or 6 (all pairs, i8 matrix cores when the matrix is one-hot; mode 2 takes the FP4 form)");
+        if (value < 0 || value > 7) return ps_fail(PS_ERR_INVALID, "pair_mode must be 0 (auto), 1 (sampled), 2 (all pairs), 3 (sampled, nibble form even for one-hot matrices), 4 (transposed bit strings, streamed per pair), 5 (all pairs, xor + popcount tiles even for one-hot matrices), 6 (all pairs, i8 matrix cores when the matrix is one-hot; mode 2 takes the FP4 form) or 7 (the FP4 form on three +-1 features per site)");
         p->pair_mode = (int)value;
     } else if (k == "pair_ranges") {
         if (value < 0 || value > 65535) return ps_fail(PS_ERR_INVALID, "pair_ranges must be 0 (choose)..65535");
@@ -1959,7 +1959,7 @@ static core_pair_plan plan_core_pairs(const ps_population *p, uint64_t P)
         const bool mfma_ok = p->onehot_safe && p->pair_mode != 5;
         const double t_rows = (1.25 * (double)N * rows + (double)P * rows * (p->onehot_safe ? 0.5 : 1.0)) / 5.0e12;
         const double t_all = all_pairs * rows / (mfma_ok ? 3.5e14 : 1.3e14);
-        const bool force_all = p->pair_mode == 2 || p->pair_mode == 5 || p->pair_mode == 6;
+        const bool force_all = p->pair_mode == 2 || p->pair_mode == 5 || p->pair_mode == 6 || p->pair_mode == 7;
         const bool use_rows = p->nibble_safe && !force_all
                               && (p->pair_mode == 4 || (!W && (p->pair_mode == 1 || p->pair_mode == 3 || !all_fits || t_rows < t_all)));
         // against the sampled LDS-tile kernels (one-hot: ~6.4e13 pair-sites/s): the xor + popcount all-pairs tiles from
@@ -2020,7 +2020,7 @@ static int pair_counts_device(ps_population *p, uint64_t P, const uint32_t *d_r1
             // one-hot matrix: X X^T on the i8 matrix cores from the individual-major 2-bit strings
             p->last_pair_form = PS_PAIR_FORM_ALLPAIRS_MFMA;
             const uint32_t WT = ((rows + 15u) / 16u + PS_PT_WB - 1u) / PS_PT_WB * PS_PT_WB;
-            const uint64_t need = (uint64_t)N * WT;
+            const uint64_t need = (uint64_t)((N + 31u) / 32u * 32u) * WT;       // blocked strings: whole groups of 32 individuals
             if (p->pack2_cap < need) {
                 if (p->d_pack2) HIPCHK(hipFree(p->d_pack2));
                 p->d_pack2 = nullptr;
@@ -2030,15 +2030,6 @@ static int pair_counts_device(ps_population *p, uint64_t P, const uint32_t *d_r1
             }
             const uint64_t ptiles = (uint64_t)((N + PS_PT_IB - 1u) / PS_PT_IB) * (WT / PS_PT_WB);
             if (ptiles > 0x7FFFFFFFull) return ps_fail(PS_ERR_INVALID, "matrix too large for the transposed distance form");
-            core_packT_kernel<false><<<dim3((uint32_t)ptiles), 256, 0, st>>>(p->state, N, p->pitch, rows, p->d_pack2, WT);
-            if (p->H_cap < (uint64_t)N * N) {
-                if (p->d_H) HIPCHK(hipFree(p->d_H));
-                p->d_H = nullptr;
-                p->H_cap = 0;
-                HIPCHK(hipMalloc(&p->d_H, (uint64_t)N * N * sizeof(uint32_t)));
-                p->H_cap = (uint64_t)N * N;
-            }
-            HIPCHK(hipMemsetAsync(p->d_H, 0, (uint64_t)N * N * sizeof(uint32_t), st));
             const uint32_t ntile = (N + PS_MF_TILE - 1u) / PS_MF_TILE;
             const uint32_t tile_pairs = ntile * (ntile + 1u) / 2u;
             const uint32_t n_chunks = WT / PS_MF_CHUNK_DW;
@@ -2047,23 +2038,43 @@ static int pair_counts_device(ps_population *p, uint64_t P, const uint32_t *d_r1
             // 528 tiles x 16 ranges = 33 rounds exactly, where 3 ranges left the 7th round 19 % full
             uint32_t ranges = 1;
             {
-                const double cu_rate = 7.0e14 / 256.0, fixed = 15.0e-6;
+                const double cu_rate = 7.0e14 / 256.0, fixed = 10.0e-6;
                 double best = 1.0e300;
-                const uint32_t r_hi = std::min(n_chunks, std::max(1u, (256u * 64u) / tile_pairs));
-                const uint32_t r_lo = std::min(r_hi, (256u * 4u + tile_pairs - 1u) / tile_pairs);      // >= 4 rounds: edge tiles are lighter
-                for (uint32_t r = r_lo; r <= r_hi; r++) {
+                // (every range stores its own N x N slice of partial counts: at most ~8 GB of them)
+                const uint32_t r_mem = (uint32_t)std::max<uint64_t>(1, (8ull << 30) / ((uint64_t)N * N * 4));
+                const uint32_t r_hi = std::min(std::min(n_chunks, r_mem), std::max(1u, (256u * 64u) / tile_pairs));
+                for (uint32_t r = 1; r <= r_hi; r++) {
                     const uint32_t c = (n_chunks + r - 1u) / r, rr = (n_chunks + c - 1u) / c;     // ranges actually launched
                     const double blocks = (double)tile_pairs * rr;
-                    const double t = std::ceil(blocks / 256.0) * (65536.0 * (double)c * PS_MF_CHUNK_DW * 16.0 / cu_rate + fixed);
+                    // rounds x (a workgroup's chunks + table, stores) + the slices written and read once more
+                    const double t = std::ceil(blocks / 256.0) * (65536.0 * (double)c * PS_MF_CHUNK_DW * 16.0 / cu_rate + fixed)
+                                     + (rr > 1u ? (double)rr * N * N * 4.0 * 1.5 / 4.0e12 : 0.0);
                     if (t < best) { best = t; ranges = rr; }
                 }
             }
             const uint32_t cpr = (n_chunks + ranges - 1u) / ranges;
-            ranges = (n_chunks + cpr - 1u) / cpr;
+            ranges = (n_chunks + cpr - 1u) / cpr;          // (every range holds at least one chunk: every slice is written)
+            if (p->H_cap < (uint64_t)N * N * ranges) {
+                if (p->d_H) HIPCHK(hipFree(p->d_H));
+                p->d_H = nullptr;
+                p->H_cap = 0;
+                HIPCHK(hipMalloc(&p->d_H, (uint64_t)N * N * ranges * sizeof(uint32_t)));
+                p->H_cap = (uint64_t)N * N * ranges;
+            }
             const uint32_t lds = 256u * 16u * 16u;
-            // i8 (pair_mode 6) or the block-scaled FP4 form (default: twice the sites per instruction at the same cycles;
-            // a range must stay below 2^24 sites for the f32 sums to be exact)
+            // i8 (pair_mode 6), the block-scaled FP4 form on one-hot {0, 1} nibbles (the default: twice the sites per instruction
+            // at the same cycles; a range must stay below 2^24 sites for the f32 sums to be exact) or (pair_mode 7) the FP4 form
+            // on three +-1 features per site: 6 instructions per 128 sites instead of 8, but twice the table reads per
+            // instruction -- no faster (N = 8192: 51.9 ms both; N = 3000: 3.5 against 2.7 ms), kept as a cross-check
             const bool fp4 = p->pair_mode != 6 && (uint64_t)cpr * PS_MF_CHUNK_DW * 16u < (1u << 24);
+            const bool sgn = fp4 && p->pair_mode == 7 && 3ull * cpr * PS_MF_CHUNK_DW * 16u < (1u << 24);
+            if (sgn) core_packT_kernel<false, true, true><<<dim3((uint32_t)ptiles), 256, 0, st>>>(p->state, N, p->pitch, rows, p->d_pack2, WT);
+            else core_packT_kernel<false, true><<<dim3((uint32_t)ptiles), 256, 0, st>>>(p->state, N, p->pitch, rows, p->d_pack2, WT);
+            if (sgn) {
+                HIPCHK(hipFuncSetAttribute((const void *)core_allpairs_mfma_signed_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                hipLaunchKernelGGL(core_allpairs_mfma_signed_kernel, dim3(tile_pairs, ranges), dim3(512), lds, st, p->d_pack2, WT, N, p->d_H, cpr, n_chunks, ntile);
+                p->last_pair_form = PS_PAIR_FORM_ALLPAIRS_MFMA_SIGNED;
+            } else
             if (fp4) {
                 HIPCHK(hipFuncSetAttribute((const void *)core_allpairs_mfma_fp4_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
                 hipLaunchKernelGGL(core_allpairs_mfma_fp4_kernel, dim3(tile_pairs, ranges), dim3(512), lds, st, p->d_pack2, WT, N, p->d_H, cpr, n_chunks, ntile);
@@ -2072,6 +2083,7 @@ static int pair_counts_device(ps_population *p, uint64_t P, const uint32_t *d_r1
             HIPCHK(hipFuncSetAttribute((const void *)core_allpairs_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             hipLaunchKernelGGL(core_allpairs_mfma_kernel, dim3(tile_pairs, ranges), dim3(512), lds, st, p->d_pack2, WT, N, p->d_H, cpr, n_chunks, ntile);
             }
+            if (ranges > 1u) core_allpairs_sum_slices_kernel<<<N, 256, 0, st>>>(p->d_H, N, ranges);
             core_pair_lookup256_kernel<<<(uint32_t)((P + 255) / 256), 256, 0, st>>>(p->d_H, N, d_r1, d_r2, d_perm, P, d_a);
         } else
         if (use_all) {

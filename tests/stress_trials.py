@@ -31,7 +31,7 @@ def run(trials, seed=1, log=print):
             r1[:] = r1[0]                                  # one long run of equal first individuals
         want = o.pairwise_hamming_counts(m, 0, L, r1, r2)
         pop = pa.Population(N, L, 4, True, 0.0, 0, 0)
-        pop.set_tuning("pair_mode", int(rng.integers(0, 7)))
+        pop.set_tuning("pair_mode", int(rng.integers(0, 8)))
         pop.load_matrix(m)
         (got,) = pop.pairwise_counts(r1, r2)
         if not np.array_equal(got, want):

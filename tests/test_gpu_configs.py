@@ -348,7 +348,7 @@ def test_config4_full_size_properties(pa):
 
 def test_config5_full_size_distance_forms_agree(pa):
     # BASELINE configs[4]: --pop_size 8192 --max_distances 33554432 at the full 1.2 M sites: the 2^25-pair phase through
-    # the block-scaled FP4 matrix-core form (the default), the i8 matrix-core form and the xor + popcount tiles must give
+    # the block-scaled FP4 matrix-core form (the default), its signed variant, the i8 matrix-core form and the xor + popcount tiles must give
     # the same integers; two generations first so that the population is not clonal
     kw = dict(pop_size=8192, core_size=1200000, pan_genes=6000, core_genes=2000)
     P, gens = 1 << 25, 2
@@ -357,13 +357,13 @@ def test_config5_full_size_distance_forms_agree(pa):
     sim.sync()
     assert sim.core_genome.last_sweep_form() == 3
     got = {}
-    for mode, form in ((0, 7), (6, 6), (5, 2)):
+    for mode, form in ((0, 7), (7, 8), (6, 6), (5, 2)):
         sim.core_genome.set_tuning("pair_mode", mode)
         (cnt,) = sim.core_genome.pairwise_counts(sim.range1, sim.range2)
         assert sim.core_genome.last_pair_form() == form
         got[mode] = cnt
     assert (got[0] % 2 == 0).all() and got[0].max() > 0
-    assert np.array_equal(got[0], got[6]) and np.array_equal(got[0], got[5])
+    assert np.array_equal(got[0], got[6]) and np.array_equal(got[0], got[5]) and np.array_equal(got[0], got[7])
     # a pair of an individual with itself would count 0; the pair list never holds one (main.rs:413-427)
     assert (sim.range1 != sim.range2).all()
     # replay: the same generations again give the same numerators and gene frequencies

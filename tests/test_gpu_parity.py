@@ -279,12 +279,12 @@ def test_pairwise_core_kernels_agree(pa, orc, N, L, P):
     m = _rand_core(rng, N, L)
     r1, r2 = orc.sample_pairs(5, N, P)
     want = orc.pairwise_hamming_counts(m, 0, L, r1, r2)
-    for mode in (1, 2, 3, 5, 6):
+    for mode in (1, 2, 3, 5, 6, 7):
         pop = pa.Population(N, L, 4, True, 0.0, 0, 0)
         pop.set_tuning("pair_mode", mode)
         pop.load_matrix(m)
         assert np.array_equal(pop.pairwise_counts(r1, r2)[0], want)
-        assert pop.last_pair_form() == {1: 1, 2: 7, 3: 3, 5: 2, 6: 6}[mode]
+        assert pop.last_pair_form() == {1: 1, 2: 7, 3: 3, 5: 2, 6: 6, 7: 8}[mode]
         pop.close()
 
 
@@ -307,7 +307,7 @@ def test_allpairs_matrix_core_form(pa, orc, N, L):
     want = orc.pairwise_hamming_counts(m, 0, L, r1, r2)
     pop = pa.Population(N, L, 4, True, 0.0, 0, 0)
     pop.load_matrix(m)
-    for mode, form in ((6, 6), (2, 7)):          # i8, then the block-scaled FP4 form
+    for mode, form in ((6, 6), (2, 7), (7, 8)):          # i8, the block-scaled FP4 form on one-hot nibbles, on +-1 features
         pop.set_tuning("pair_mode", mode)
         (got,) = pop.pairwise_counts(np.ascontiguousarray(r1), np.ascontiguousarray(r2))
         assert pop.last_pair_form() == form
