@@ -196,9 +196,10 @@ int ps_sync(ps_population *p);
  * matrix cores in modes 0 and 2 (FP4 form on one-hot nibbles), 6 and 7), "pair_ranges" (site ranges of the tiled
  * sampled-pair kernels, 0 = choose; the 16-bit counter cap still applies),
  * "davg_form" (average_distance: 0 = choose, 1 = LDS-tile popcount kernels, 2 = intersections on the matrix cores in one kernel --
- * the choice above pop_size 24576 --, 3 = the same in two phases, u16 counts then division + ordered fold -- the choice for row
- * shards and for 8192 < pop_size <= 24576), "davg_nb" (matrix-core forms: 32-individual fragments per wave, 0 = choose, 1, 2, or --
- * two-phase form only; the one-kernel form then chooses by itself -- 4),
+ * the choice above pop_size 53248 --, 3 = the same in two phases, u16 counts then division + ordered fold -- the choice for row
+ * shards and for 8192 < pop_size <= 53248), "davg_nb" (matrix-core forms: 32-individual fragments per wave, 0 = choose, 1, 2, or --
+ * two-phase form only; the one-kernel form then chooses by itself -- 4), "davg_ib" (two-phase form: individuals per workgroup of the
+ * division + fold phase, 0 = choose, 16 or 32),
  * "hgt_mode" (accessory recombination: 0 = choose, 1 = one atomic per event, 2 = two passes: bin
  * by recipient partition, OR in LDS images), "hgt_slices" (binned HGT: event slices, 0 = choose), "hgt_list_in_global" (0/1: donor gene lists in
  * global scratch instead of LDS; "hgt_bin_list_in_global": the same for the bin pass of the binned form),

@@ -1256,22 +1256,23 @@ __global__ void __launch_bounds__(256, NB == 2u ? 2 : 1) acc_intersections_mfma_
 }
 
 // phase 2 (see above).  Counts of rows [i_lo, i_lo + i_cnt) against all N columns; out[i] for those rows only.
-// Workgroup = 32 individuals, FIVE waves: waves 0..3 stage (every thread turns 8 consecutive j of one individual into
-// distances per chunk: one 16-byte load of counts), wave 4 does nothing but the fold (32 lanes: one running sum each), so that
+// Workgroup = IB individuals, 8 IB staging threads (every thread turns 8 consecutive j of one individual into distances per
+// chunk: one 16-byte load of counts) + one wave that does nothing but the fold (IB lanes: one running sum each), so that
 // the chain of dependent additions -- the one serial thing here -- shares its wave with no division.  Two chunks of counts
 // are in flight.  (Built for 128 VGPRs: this kernel runs with phase 1, ahead of the sweep, not beside it.)
-#define PS_AC_IB 32u
 #define PS_AC_JB 64u
-#define PS_AC_THREADS 320u
-template <bool FAST>
-__global__ void __launch_bounds__(PS_AC_THREADS, 2) acc_average_from_counts_kernel(const uint16_t *In, uint32_t ld, const uint32_t *rowcnt, uint32_t N,
+// IB individuals per workgroup: 8 IB staging threads + the fold wave (the host chooses: 16 nearly everywhere since round 6 -- the
+// fold's chain of N dependent additions sets a workgroup's duration, and with 16 four workgroups share a CU.  Four columns per
+// staging thread instead of eight, i.e. twice the staging threads, was slower everywhere: 7.0 against 5.4 ms at N = 65536)
+template <bool FAST, uint32_t IB>
+__global__ void __launch_bounds__(IB * 8u + 64u, IB == 32u ? 2 : 4) acc_average_from_counts_kernel(const uint16_t *In, uint32_t ld, const uint32_t *rowcnt, uint32_t N,
                                                                                    uint32_t i_lo, uint32_t i_cnt, double core_genes, uint32_t cg_int,
                                                                                    double *out)
 {
-    __shared__ double S[2][PS_AC_JB * (PS_AC_IB + 1u)];
-    const uint32_t tid = threadIdx.x, i0 = blockIdx.x * PS_AC_IB;       // (relative to the shard)
+    __shared__ double S[2][PS_AC_JB * (IB + 1u)];
+    const uint32_t tid = threadIdx.x, i0 = blockIdx.x * IB;       // (relative to the shard)
     const uint32_t nch = (N + PS_AC_JB - 1u) / PS_AC_JB;
-    const bool folder = tid >= 256u;                                    // (wave-uniform)
+    const bool folder = tid >= IB * 8u;                                    // (wave-uniform)
     if (!folder) {
         const uint32_t ii = tid >> 3, jq = tid & 7u;                    // 8 consecutive j of individual i0 + ii per chunk
         const bool live = i0 + ii < i_cnt;
@@ -1294,7 +1295,7 @@ __global__ void __launch_bounds__(PS_AC_THREADS, 2) acc_average_from_counts_kern
             const uint32_t cjv[8] = { cja.x, cja.y, cja.z, cja.w, cjb.x, cjb.y, cjb.z, cjb.w };
 #pragma unroll
             for (uint32_t q = 0; q < 8u; q++)
-                Sb[(8u * jq + q) * (PS_AC_IB + 1u) + ii] = ps_da_distance<FAST>(in[q], ci + cjv[q] - in[q], core_genes, cg_int);
+                Sb[(8u * jq + q) * (IB + 1u) + ii] = ps_da_distance<FAST>(in[q], ci + cjv[q] - in[q], core_genes, cg_int);
         };
         load(0u, raw0, cja0, cjb0);
         if (nch > 1u) load(1u, raw1, cja1, cjb1);
@@ -1313,14 +1314,14 @@ __global__ void __launch_bounds__(PS_AC_THREADS, 2) acc_average_from_counts_kern
         }
         return;
     }
-    const uint32_t lane = tid - 256u;            // the fold wave: lanes 0..31 hold one running sum each
+    const uint32_t lane = tid - IB * 8u;          // the fold wave: lanes 0..IB-1 hold one running sum each
     const uint32_t i = i_lo + i0 + lane, ib = i_lo + i0;
     double sum = 0.0;
     auto fold = [&](uint32_t c, const double *Sb) {
-        if (lane < PS_AC_IB) {
+        if (lane < IB) {
             const uint32_t jb = c * PS_AC_JB;
-            const bool need_mask = jb + PS_AC_JB > N || (jb < ib + PS_AC_IB && jb + PS_AC_JB > ib);
-            sum = ps_da_fold_chunk<PS_AC_JB, PS_AC_IB + 1u>(Sb, lane, sum, jb, N, i, need_mask);
+            const bool need_mask = jb + PS_AC_JB > N || (jb < ib + IB && jb + PS_AC_JB > ib);
+            sum = ps_da_fold_chunk<PS_AC_JB, IB + 1u>(Sb, lane, sum, jb, N, i, need_mask);
         }
     };
     ps_acc_sync_lds();                           // (chunk 0 is parked)
@@ -1332,7 +1333,7 @@ __global__ void __launch_bounds__(PS_AC_THREADS, 2) acc_average_from_counts_kern
         ps_acc_sync_lds();
     }
     if (c < nch) fold(c, S[0]);
-    if (lane < PS_AC_IB && i0 + lane < i_cnt && i < N) {
+    if (lane < IB && i0 + lane < i_cnt && i < N) {
         double fd = sum / (double)(N - 1u);
         if (fd == 0.0) fd = 2.2250738585072014e-308;    // f64::MIN_POSITIVE, population.rs:774-776
         out[i] = fd;

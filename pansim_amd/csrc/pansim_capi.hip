@@ -258,6 +258,7 @@ struct ps_population {
     void *d_davg_in = nullptr;       // two-phase D-avg: u16 intersection counts of one band of rows
     uint64_t davg_in_cap = 0;
     uint32_t davg_nb = 0;            // matrix-core D-avg: B fragments per wave (0 = choose, 1 or 2; 4 in the two-phase form only)
+    uint32_t davg_ib = 0;            // two-phase D-avg: individuals per workgroup of phase 2 (0 = choose, 16 or 32)
     bool davg_plain_division = false; // matrix-core D-avg: the compiler's f64 division in the epilogue ("davg_plain_division": A/B, tests)
     uint64_t H_cap = 0;
     int pair_mode = 0;               // 0 auto, 1 sampled kernel, 2 all-pairs kernel (tuning/tests)
@@ -542,6 +543,9 @@ extern "C" int ps_set_tuning(ps_population *p, const char *key, int64_t value)
         p->davg_form = (int)value;
     } else if (k == "davg_plain_division") {
         p->davg_plain_division = value != 0;
+    } else if (k == "davg_ib") {
+        if (value != 0 && value != 16 && value != 32) return ps_fail(PS_ERR_INVALID, "davg_ib must be 0 (choose), 16 or 32");
+        p->davg_ib = (uint32_t)value;
     } else if (k == "davg_nb") {
         if (value < 0 || value > 4 || value == 3) return ps_fail(PS_ERR_INVALID, "davg_nb must be 0 (choose), 1, 2 or (two-phase form only) 4");
         p->davg_nb = (uint32_t)value;
@@ -1716,10 +1720,10 @@ static int average_distance_device(ps_population *p, double *d_out, hipStream_t 
     const bool mfma = p->d.G > 0 && N >= 2 && (p->davg_form >= 2 || !whole || (p->davg_form == 0 && N > 8192));
     // Choice between the two matrix-core forms (davg_form 0).  The one-kernel form needs 32 NB rows per wave for the whole fold:
     // a row shard leaves its SIMDs idle (a rank of 8 at N = 65536: 7.6 ms for 8192 rows) and always takes the two phases (1.96 ms);
-    // a whole population takes them while it is small (N = 16384: 1.03 against 1.95 ms) -- from about 24 K rows on the
-    // one-kernel form's fused epilogue is cheaper than the counts written and read back (N = 32768: 3.98 against 4.50 ms;
-    // N = 65536: 11.1 against 14.6)
-    const bool two_phase = mfma && p->davg_form != 2 && p->d.G <= 65535 && (p->davg_form == 3 || !whole || i_cnt <= 24576);      // (u16 counts)
+    // a whole population takes them up to about 52 K rows (round 6, blocked rows + pipelined phase 1 + 16-individual phase 2:
+    // N = 32768 3.57 against 4.46 ms, 49152 7.68 against 8.31) -- above, the one-kernel form's fused epilogue is cheaper than the
+    // counts written and read back (N = 57344: 9.95 against 10.29 ms; N = 65536: 11.1 against 13.3)
+    const bool two_phase = mfma && p->davg_form != 2 && p->d.G <= 65535 && (p->davg_form == 3 || !whole || i_cnt <= 53248);      // (u16 counts)
     if (mfma) {
         const uint32_t WP = (2u * p->d.GW + 7u) & ~7u, Npad = (uint32_t)((N + 127) & ~127ull);
         const uint64_t need = (uint64_t)Npad * WP * 4 + (uint64_t)Npad * 4 + 64;
@@ -1770,11 +1774,16 @@ static int average_distance_device(ps_population *p, double *d_out, hipStream_t 
                     HIPCHK(hipFuncSetAttribute((const void *)acc_intersections_mfma_kernel<1u>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
                     acc_intersections_mfma_kernel<1u><<<grid, 256, lds, st>>>(rowsP, WP, Npad, lo, rows, jsteps, In, ld);
                 }
-                const uint32_t g2 = (rows + PS_AC_IB - 1u) / PS_AC_IB;
-                if (fast)
-                    acc_average_from_counts_kernel<true><<<g2, PS_AC_THREADS, 0, st>>>(In, ld, rowcnt, (uint32_t)N, lo, rows, (double)p->cfg.core_genes, cgi, d_out);
-                else
-                    acc_average_from_counts_kernel<false><<<g2, PS_AC_THREADS, 0, st>>>(In, ld, rowcnt, (uint32_t)N, lo, rows, (double)p->cfg.core_genes, cgi, d_out);
+                // (workgroups of 16 individuals -- four per CU, half the staging per fold -- except where 32 make exactly one round of
+                // one per CU.  N = 65536: whole 4.99 against 5.42 ms, a shard of 8 0.889 against 0.836; N = 32768 whole 3.29
+                // against 3.58 with phase 1, its shard of 8 0.65 against 0.73; N = 16384 shard 0.28 against 0.33)
+                const uint32_t blocks32 = (rows + 31u) / 32u;
+                const bool small = p->davg_ib ? p->davg_ib == 16u : !(blocks32 >= 256u && blocks32 < 512u);
+                const uint32_t ib = small ? 16u : 32u, g2 = (rows + ib - 1u) / ib;
+#define PS_AC_LAUNCH(FAST_, IB_) acc_average_from_counts_kernel<FAST_, IB_><<<g2, IB_ * 8u + 64u, 0, st>>>(In, ld, rowcnt, (uint32_t)N, lo, rows, (double)p->cfg.core_genes, cgi, d_out)
+                if (fast) { if (small) PS_AC_LAUNCH(true, 16u); else PS_AC_LAUNCH(true, 32u); }
+                else { if (small) PS_AC_LAUNCH(false, 16u); else PS_AC_LAUNCH(false, 32u); }
+#undef PS_AC_LAUNCH
             }
         } else {
         // 64 individuals per wave (two B fragments: fewer table reads per MFMA) when that still gives every SIMD a wave

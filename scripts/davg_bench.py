@@ -21,12 +21,14 @@ pop.load_matrix(m)
 del m
 out = {"N": N, "G": G}
 ref = None
-FORMS = (("popcount_tiles", 1, 0), ("matrix_cores_nb1", 2, 1), ("matrix_cores_nb2", 2, 2), ("two_phase_nb2", 3, 2), ("two_phase_nb1", 3, 1), ("two_phase_nb4", 3, 4))
+FORMS = (("popcount_tiles", 1, 0), ("matrix_cores_nb1", 2, 1), ("matrix_cores_nb2", 2, 2), ("two_phase_nb2", 3, 2), ("two_phase_nb1", 3, 1), ("two_phase_nb4", 3, 4),
+         ("two_phase_nb2_ib32", 3, 2), ("two_phase_nb2_ib16", 3, 2))
 if len(sys.argv) > 3:
     FORMS = tuple(f for f in FORMS if f[0] in sys.argv[3].split(","))
 for name, form, nb in FORMS:
     pop.set_tuning("davg_form", form)
     pop.set_tuning("davg_nb", nb)
+    pop.set_tuning("davg_ib", 32 if "ib32" in name else 16 if "ib16" in name else 0)
     v = pop.average_distance()
     if ref is None:
         ref = v

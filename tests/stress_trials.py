@@ -138,6 +138,7 @@ def run(trials, seed=1, log=print):
             acc.load_matrix(a)
             acc.set_tuning("davg_form", int(rng.integers(0, 4)))
             acc.set_tuning("davg_nb", int(rng.choice([0, 1, 2, 4])))
+            acc.set_tuning("davg_ib", int(rng.choice([0, 16, 32])))
             got = acc.average_distance()
             K = int(rng.integers(1, min(N, 5) + 1))
             rows = np.concatenate([acc.average_distance_rows(N * r // K, N * (r + 1) // K - N * r // K) for r in range(K)])

@@ -172,6 +172,7 @@ def test_average_distance_on_the_matrix_cores(pa, orc, N, G, cg, nb):
     for form in (2, 3, 0):
         pop.set_tuning("davg_form", form)
         pop.set_tuning("davg_nb", nb)
+        pop.set_tuning("davg_ib", 32 if form == 3 else 0)       # phase 2 with 32 individuals per workgroup, then its own choice (16 here)
         if form:
             assert np.array_equal(pop.average_distance(), want, equal_nan=True), form
         got = np.concatenate([pop.average_distance_rows(N * r // K, N * (r + 1) // K - N * r // K) for r in range(K)])
