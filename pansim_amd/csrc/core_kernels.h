@@ -2002,7 +2002,7 @@ __global__ void __launch_bounds__(256) core_pair_counts_rows(const uint32_t *pac
 // expansions (4 x {0,1} per site), so all pairs are one X X^T contraction -- SURVEY 8(d) notes this form is
 // MFMA-eligible.  It is exact: v_mfma_i32_32x32x32_i8 multiplies i8 {0,1} and accumulates in i32 (<= L matches);
 // the reference's numerator (distances.rs:22-52: byte popcount, 2 per differing site) is 2 * (sites - matches).
-// Operands come from the individual-major 2-bit strings of core_packT_kernel (16 sites per dword; padding sites
+// Operands come from the blocked 2-bit strings of core_packT_kernel<false, true> (16 sites per dword; padding sites
 // hold code 0 for everybody, i.e. they match and drop out of sites - matches).
 //   * A workgroup of 8 waves owns a 256 x 256 tile of pairs (tiles with ti <= tj only) over a range of 128-site
 //     chunks; a wave owns 128 x 64 pairs: 4 + 2 operand fragments and 4 x 2 accumulator blocks of 32 x 32.

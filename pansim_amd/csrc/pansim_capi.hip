@@ -2026,7 +2026,7 @@ static int pair_counts_device(ps_population *p, uint64_t P, const uint32_t *d_r1
             }
         } else
         if (use_all && mfma_ok) {
-            // one-hot matrix: X X^T on the i8 matrix cores from the individual-major 2-bit strings
+            // one-hot matrix: X X^T on the matrix cores from the blocked 2-bit strings (or bit planes: the signed form)
             p->last_pair_form = PS_PAIR_FORM_ALLPAIRS_MFMA;
             const uint32_t WT = ((rows + 15u) / 16u + PS_PT_WB - 1u) / PS_PT_WB * PS_PT_WB;
             const uint64_t need = (uint64_t)((N + 31u) / 32u * 32u) * WT;       // blocked strings: whole groups of 32 individuals
